@@ -1,0 +1,85 @@
+"""Pin the CPU oracle to the reference: every golden fixture (captured from the reference itself by
+tools/make_golden.py) must be reproduced by oracle/tensorf_oracle.py to fp32 round-off."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tensorf_oracle as O
+from tests.golden_util import CASES, Fixture, GOLDEN, replay_oracle
+
+# tolerances (fp32): values abs, gradients relative to the tensor's max-abs
+TOL_VAL = 2e-6
+TOL_GRAD_REL = 5e-5
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("use_taps", [False, True])
+def test_fixture_replay(name, use_taps):
+    fx = Fixture(name)
+    out = replay_oracle(fx, use_taps=use_taps)
+    # manual taps sum in a different order than grid_sample's kernel: allow a wider band there
+    tol_g = 5e-4 if use_taps else TOL_GRAD_REL
+    if "dense" in name:
+        # acc == 1 (saturated): the render gradient is a cancellation residue ~1e-3 of the L1 term
+        tol_g = 5e-3 if use_taps else 5e-4
+    np.testing.assert_allclose(out["pose"].detach().numpy(), fx.arrays["mid.current_pose"], atol=1e-6)
+    np.testing.assert_allclose(out["center"].detach().reshape(-1, 3).numpy(), fx.arrays["mid.center"], atol=2e-6)
+    np.testing.assert_allclose(out["ray"].detach().reshape(-1, 3).numpy(), fx.arrays["mid.ray_dir"], atol=2e-6)
+    if out["kd"] is not None:
+        np.testing.assert_allclose(out["kd"].numpy(), fx.arrays["mid.kernel_density"], atol=1e-7)
+        np.testing.assert_allclose(out["kc"].numpy(), fx.arrays["mid.kernel_color"], atol=1e-7)
+    np.testing.assert_allclose(out["rgb"].detach().numpy(), fx.arrays["out.rgb"], atol=TOL_VAL)
+    np.testing.assert_allclose(out["opacity"].detach().numpy(), fx.arrays["out.opacity"], atol=TOL_VAL)
+    np.testing.assert_allclose(out["depth"].detach().numpy(), fx.arrays["out.depth"], atol=1e-5)
+    for k, v in out["losses"].items():
+        np.testing.assert_allclose(float(v.detach()), float(fx.arrays["loss." + k]), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(float(out["total"].detach()), float(fx.arrays["loss.all"]), rtol=2e-5)
+    for n, g in out["grads"].items():
+        key = fx.grad_key(n)
+        ref = fx.arrays[key]
+        assert g is not None, n
+        assert _rel(g.numpy(), ref) < tol_g, (n, _rel(g.numpy(), ref))
+    assert _rel(out["grad_se3"].numpy(), fx.arrays["grad.se3_refine.weight"]) < tol_g
+
+
+def test_known_answers():
+    d = np.load(GOLDEN + "/known_answers.npz")
+    wu = torch.tensor(d["se3.wu"], requires_grad=True)
+    Rt = O.se3_to_SE3(wu)
+    np.testing.assert_allclose(Rt.detach().numpy(), d["se3.Rt"], atol=1e-6)
+    (Rt * torch.tensor(d["se3.cot"])).sum().backward()
+    np.testing.assert_allclose(wu.grad.numpy(), d["se3.grad_wu"], atol=2e-5, rtol=1e-4)
+    ab = O.compose_pair(torch.tensor(d["compose.a"]), torch.tensor(d["compose.b"]))
+    np.testing.assert_allclose(ab.numpy(), d["compose.ab"], atol=1e-6)
+    for i, s in enumerate(d["gauss.sigma"]):
+        np.testing.assert_allclose(O.gaussian_kernel(s, 64).numpy(), d["gauss.k65"][i], atol=1e-7)
+        np.testing.assert_allclose(O.gaussian_kernel(s, 8).numpy(), d["gauss.k9"][i], atol=1e-7)
+    k = torch.tensor(d["blur.kernel"])
+    cub = O.blur_plane(k, torch.tensor(d["blur.cubic.in"]), 11, 11)
+    np.testing.assert_allclose(cub.numpy(), d["blur.cubic.out"], atol=1e-5)
+    non = O.blur_plane(k, torch.tensor(d["blur.noncubic.in"]), 9, 13)
+    assert non.shape == d["blur.noncubic.out"].shape == (1, 4, 9, 13)
+    np.testing.assert_allclose(non.numpy(), d["blur.noncubic.out"], atol=1e-5)
+    ln = O.blur_line(k, torch.tensor(d["blur.line.in"]))
+    np.testing.assert_allclose(ln.numpy(), d["blur.line.out"], atol=1e-5)
+
+
+def test_lattice_and_schedule_helpers():
+    # 2048 rays over 100 views of 400x400 -> step 90; 65536 -> step 16 -> 625/view
+    idx, step, gh, gw = O.rand_grid_ray_idx(400, 400, 2048, 100, 5, 7)
+    assert step == 90 and len(idx) == gh * gw and 16 <= len(idx) <= 25
+    idx, step, gh, gw = O.rand_grid_ray_idx(400, 400, 65536, 100, 0, 0)
+    assert step == 16 and len(idx) == 625
+    # stage table of bat_blender_VM
+    n_voxels = [262144, 1036216, 4095998, 16190876, 64000012]
+    res = [O.find_resolution([-1.5] * 3 + [1.5] * 3, n)[0] for n in n_voxels]
+    assert res == [64, 101, 159, 252, 400]
+    S = [O.find_n_samples([r] * 3, 0.5, 1000) for r in res]
+    assert S == [221, 349, 550, 872, 1000]
+    assert abs(O.interp_schedule(0.05, [0.3, 0.15, 0.07] + [0.0] * 8) - 0.225) < 1e-9
+    assert O.resolve_blur(0.9, [0.3, 0.15, 0.07] + [0.0] * 8, [0.3, 0.15, 0.07] + [0.0] * 8, "train", 1.0) == (None, None)

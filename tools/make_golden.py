@@ -1,0 +1,475 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by importing the reference (CPU, this container only).
+
+Runs ONLY where /root/reference exists (the build container).  It imports the reference's
+own `model/bat.py` Graph with throw-away stand-ins for its *non-arithmetic* third-party
+imports (easydict, icecream, wandb, ...), drives
+`Graph.forward -> compute_loss -> backward` on tiny synthetic scenes and stores the captured
+inputs, outputs and gradients as small .npz fixtures under tests/golden/.
+
+The fixtures are data only: tensors that went in and tensors that came out.  Nothing of the
+reference's source travels.  Re-run:  python tools/make_golden.py  [--out tests/golden]
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+
+
+# ----------------------------------------------------------------------------------------------
+# stand-ins for the reference's non-arithmetic imports
+# ----------------------------------------------------------------------------------------------
+class EasyDict(dict):
+    """Minimal recursive attribute dict (the reference uses easydict.EasyDict)."""
+
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        d = {} if d is None else dict(d)
+        d.update(kw)
+        for k, v in d.items():
+            self[k] = v
+
+    @classmethod
+    def _conv(cls, v):
+        if isinstance(v, dict) and not isinstance(v, cls):
+            return cls(v)
+        if isinstance(v, list):
+            return [cls._conv(e) for e in v]
+        return v
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, self._conv(v))
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def update(self, *a, **kw):
+        for k, v in dict(*a, **kw).items():
+            self[k] = v
+
+
+def _install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Anything:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return a[0] if len(a) == 1 else (a if a else None)
+
+        def __getattr__(self, k):
+            return _Anything()
+
+    mod("easydict", EasyDict=EasyDict)
+    ic = _Anything()
+    mod("icecream", ic=ic)
+    mod("wandb", log=lambda *a, **k: None, init=_Anything(), Image=_Anything, Video=_Anything,
+        run=_Anything())
+    mod("lpips", LPIPS=_Anything)
+    mod("visdom", Visdom=_Anything)
+    tv = mod("torchvision")
+    tvt = mod("torchvision.transforms")
+    tvf = mod("torchvision.transforms.functional")
+    tv.transforms = tvt
+    tvt.functional = tvf
+    tv.utils = mod("torchvision.utils", make_grid=_Anything(), save_image=_Anything())
+    mod("termcolor", colored=lambda s, **k: str(s))
+    mod("ipdb", set_trace=lambda *a, **k: None)
+    mod("imageio", imread=_Anything(), imwrite=_Anything())
+    tb = mod("torch.utils.tensorboard", SummaryWriter=_Anything)
+    torch.utils.tensorboard = tb
+    ext = mod("external")
+    ssim = mod("external.pohsun_ssim")
+    ext.pohsun_ssim = ssim
+    ssim.pytorch_ssim = mod("external.pohsun_ssim.pytorch_ssim", ssim=_Anything())
+
+
+def import_reference():
+    _install_stubs()
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    import options  # noqa
+    import camera  # noqa
+    import model.bat as bat  # noqa
+    import model.kernels as kernels  # noqa
+    return options, camera, bat, kernels
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic scene
+# ----------------------------------------------------------------------------------------------
+def look_at_pose(eye):
+    """world->camera [R|t] looking at the origin (camera looks along +z, reference convention)."""
+    eye = np.asarray(eye, dtype=np.float64)
+    fwd = -eye / np.linalg.norm(eye)
+    up = np.array([0.0, 0.0, 1.0])
+    if abs(fwd @ up) > 0.99:
+        up = np.array([0.0, 1.0, 0.0])
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    R = np.stack([right, down, fwd], 0)  # rows = camera axes in world coords
+    t = -R @ eye
+    return np.concatenate([R, t[:, None]], 1).astype(np.float32)
+
+
+def make_opt(options, yaml_name, H, W, n_voxel_init, extra=None):
+    opt = options.load_options("options/{}.yaml".format(yaml_name))
+    over = dict(model="bat", yaml=yaml_name, data=dict(image_size=[H, W]),
+                train_schedule=dict(n_voxel_init=n_voxel_init))
+    if extra:
+        for k, v in extra.items():
+            over[k] = v
+    opt = options.override_options(opt, EasyDict(over), key_stack=[])
+    opt.device = "cpu"
+    opt.H, opt.W = H, W
+    opt.output_path = "/tmp/jt_golden_out"
+    return opt
+
+
+def build_graph(bat, camera, opt, n_views, seed, se3_scale=0.01, noise=True):
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    graph = bat.Graph(opt)
+    graph.se3_refine = torch.nn.Embedding(n_views, 6)
+    with torch.no_grad():
+        graph.se3_refine.weight.copy_(torch.randn(n_views, 6) * se3_scale)
+    if noise:
+        se3_noise = torch.randn(n_views, 6) * float(opt.camera.noise)
+        graph.pose_noise = torch.nn.Parameter(camera.lie.se3_to_SE3(se3_noise), requires_grad=False)
+    graph.train()
+    return graph
+
+
+def make_var(opt, n_views, seed, llff=False):
+    g = torch.Generator().manual_seed(seed + 100)
+    H, W = opt.H, opt.W
+    if llff:
+        # near-identity world->camera poses (LLFF after recentering), looking along +z
+        poses = []
+        for i in range(n_views):
+            eye = np.array([0.15 * np.cos(2.1 * i), 0.12 * np.sin(1.3 * i), 0.02 * i])
+            P = np.eye(3, 4, dtype=np.float32)
+            P[:, 3] = -eye
+            poses.append(P)
+        f = 0.8 * W
+    else:
+        poses = []
+        for i in range(n_views):
+            th = 2 * np.pi * i / n_views + 0.3
+            ph = 0.5 + 0.2 * np.sin(1.7 * i)
+            eye = 4.0 * np.array([np.cos(th) * np.cos(ph), np.sin(th) * np.cos(ph), np.sin(ph)])
+            poses.append(look_at_pose(eye))
+        f = 0.5 * W / np.tan(0.5 * 0.69)
+    pose = torch.tensor(np.stack(poses))
+    intr = torch.tensor([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]], dtype=torch.float32)
+    intr = intr[None].repeat(n_views, 1, 1)
+    var = EasyDict(
+        idx=torch.arange(n_views),
+        pose=pose,
+        intr=intr,
+        intr_inv=intr.inverse(),
+        image=torch.rand(n_views, 3, H, W, generator=g),
+    )
+    var.train_edge_masks = (torch.rand(n_views, H * W, generator=g) < 0.5).to(torch.uint8)
+    return var
+
+
+class Recorder:
+    """Records the host/device random draws the reference makes on the path."""
+
+    def __init__(self):
+        self.rand_like = []
+        self.np_choice = []
+        self.np_randint = []
+        self.coin = []
+
+    def install(self, tensorBase_mod, batBase_mod):
+        rec = self
+        _rand_like = torch.rand_like
+        _choice = np.random.choice
+        _randint = np.random.randint
+        _rand = torch.rand
+
+        def rand_like(x, *a, **k):
+            r = _rand_like(x, *a, **k)
+            rec.rand_like.append(r.detach().clone())
+            return r
+
+        def choice(pool, *a, **k):
+            r = _choice(pool, *a, **k)
+            rec.np_choice.append(float(r))
+            return r
+
+        def randint(*a, **k):
+            r = _randint(*a, **k)
+            rec.np_randint.append(int(r))
+            return r
+
+        def rand(*a, **k):
+            r = _rand(*a, **k)
+            if tuple(r.shape) == (1,):
+                rec.coin.append(float(r))
+            return r
+
+        torch.rand_like = rand_like
+        np.random.choice = choice
+        np.random.randint = randint
+        torch.rand = rand
+        self._restore = (_rand_like, _choice, _randint, _rand)
+
+    def uninstall(self):
+        torch.rand_like, np.random.choice, np.random.randint, torch.rand = self._restore
+
+
+def state_np(graph):
+    return {"param." + k: v.detach().cpu().numpy().copy() for k, v in graph.state_dict().items()}
+
+
+def run_case(bat, camera, opt, graph, var, mode, it, progress, out_path, llff=False, extra_meta=None,
+             torch_seed=None):
+    import model.tensorf_repr.tensorBase as tB
+    import model.tensorf_repr.batBase as bB
+    import util
+
+    if torch_seed is not None:
+        torch.manual_seed(torch_seed)
+    graph.it = it
+    graph.nerf.progress.data.fill_(progress)
+    for p in graph.parameters():
+        p.grad = None
+    rec = Recorder()
+    rec.install(tB, bB)
+    # capture what tensorf.forward is called with (blur params after random scale/cut-off etc.)
+    tf = graph.nerf.tensorf
+    captured = {}
+    orig_forward = tf.forward
+
+    def forward_spy(opt_, **kw):
+        captured.update({k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()})
+        captured["near_far"] = [float(tf.near_far[0]), float(tf.near_far[1])]
+        out = orig_forward(opt_, **kw)
+        captured["kernel_density"] = None if tf.kernel_density is None else tf.kernel_density.detach().clone()
+        captured["kernel_color"] = None if tf.kernel_color is None else tf.kernel_color.detach().clone()
+        return out
+
+    tf.forward = forward_spy
+    try:
+        v = EasyDict(var)
+        if mode == "vis":
+            # deterministic path used by render_by_slices (nerf.py:728-740): one slice of ray_idx
+            pose = graph.get_pose(opt, v, mode="train")
+            ray_idx = torch.arange(0, opt.H * opt.W, 7)[:24]
+            ret = graph.render(opt, pose, intr_inv=v.intr_inv, ray_idx=ray_idx, mode="vis", intr=v.intr)
+            v.update(ret)
+            v.ray_idx = ray_idx
+            v.current_pose = pose
+            loss_in = v.rgb
+            loss = EasyDict(render=((v.rgb - 0.3) ** 2).mean())
+            loss_all = loss.render
+        else:
+            v = graph.forward(opt, v, mode=mode)
+            loss = graph.compute_loss(opt, v, mode=mode)
+            loss_all = 0.0
+            w_l1 = float(opt.loss_weight.L1.init)
+            for k in loss:
+                if k == "L1":
+                    loss_all = loss_all + w_l1 * loss[k]
+                elif opt.loss_weight[k] is not None:
+                    loss_all = loss_all + float(opt.loss_weight[k]) * loss[k]
+        loss_all.backward()
+    finally:
+        rec.uninstall()
+        tf.forward = orig_forward
+
+    out = {}
+    out.update(state_np(graph))
+    for k, p in graph.named_parameters():
+        if p.grad is not None:
+            out["grad." + k] = p.grad.detach().cpu().numpy().copy()
+    out["in.pose_gt"] = var.pose.numpy()
+    out["in.intr"] = var.intr.numpy()
+    out["in.intr_inv"] = var.intr_inv.numpy()
+    out["in.idx"] = var.idx.numpy()
+    out["in.image"] = var.image.numpy()
+    out["in.train_edge_masks"] = var.train_edge_masks.numpy()
+    out["in.ray_idx"] = v.ray_idx.numpy()
+    out["mid.current_pose"] = v.current_pose.detach().numpy()
+    out["mid.center"] = captured["center"].numpy()
+    out["mid.ray_dir"] = captured["ray_dir"].numpy()
+    if rec.rand_like:
+        out["in.jitter"] = rec.rand_like[0].numpy()
+    out["out.rgb"] = v.rgb.detach().numpy()
+    out["out.depth"] = v.depth.detach().numpy()
+    out["out.opacity"] = v.opacity.detach().numpy()
+    for k in loss:
+        out["loss." + k] = np.float32(loss[k].detach().item() if isinstance(loss[k], torch.Tensor) else loss[k])
+    out["loss.all"] = np.float32(loss_all.detach().item())
+    if captured["kernel_density"] is not None:
+        out["mid.kernel_density"] = captured["kernel_density"].numpy()
+        out["mid.kernel_color"] = captured["kernel_color"].numpy()
+    meta = dict(
+        mode=mode, it=it, progress=float(progress), H=opt.H, W=opt.W, llff=bool(llff),
+        yaml=str(opt.yaml),
+        white_bg=bool(captured["white_bg"]), is_train=bool(captured["is_train"]),
+        ndc_ray=bool(captured["ndc_ray"]), N_samples=int(captured["N_samples"]),
+        c2f_parameter_density=None if captured["c2f_parameter_density"] is None else float(captured["c2f_parameter_density"]),
+        c2f_parameter_color=None if captured["c2f_parameter_color"] is None else float(captured["c2f_parameter_color"]),
+        c2f_mode=captured["c2f_mode"], c2f_kernel_size=captured["c2f_kernel_size"],
+        fea_pe_progress=float(captured["fea_pe_progress"]), view_pe_progress=float(captured["view_pe_progress"]),
+        is_test_optim=bool(captured["is_test_optim"]),
+        near_far=captured["near_far"],
+        coin=rec.coin, np_choice=rec.np_choice, np_randint=rec.np_randint,
+        gridSize=[int(x) for x in tf.gridSize.tolist()],
+        aabb=[float(x) for x in tf.aabb.view(-1).tolist()],
+        stepSize=float(tf.stepSize), step_ratio=float(tf.step_ratio),
+        density_shift=float(tf.density_shift), distance_scale=float(tf.distance_scale),
+        fea2denseAct=str(tf.fea2denseAct), rayMarch_weight_thres=float(tf.rayMarch_weight_thres),
+        shadingMode=str(tf.shadingMode), view_pe=int(tf.view_pe), fea_pe=int(tf.fea_pe),
+        density_n_comp=[int(x) for x in tf.density_n_comp], app_n_comp=[int(x) for x in tf.app_n_comp],
+        app_dim=int(tf.app_dim), featureC=int(tf.featureC),
+        L1_weight=float(opt.loss_weight.L1.init),
+        TV_density_weight=float(opt.loss_weight.TV_density), TV_color_weight=float(opt.loss_weight.TV_color),
+        ndc_near_plane=float(opt.arch.ndc_near_plane) if hasattr(opt.arch, "ndc_near_plane") else 1.0,
+        edge_loss=dict(on=bool(getattr(opt, "edge_mask_on_render_loss", False)),
+                       alternate=bool(getattr(opt, "alternate_edge_loss", False)),
+                       before_iter=int(getattr(opt, "edge_mask_before_iter", 0)),
+                       edge_factor=float(getattr(opt, "edge_loss_factor", 1.0)),
+                       non_edge_factor=float(getattr(opt, "non_edge_loss_factor", 1.0))),
+        ray_sampling_strategy=str(opt.nerf.ray_sampling_strategy),
+        grid_H=int(v.grid_H) if "grid_H" in v else -1, grid_W=int(v.grid_W) if "grid_W" in v else -1,
+    )
+    if extra_meta:
+        meta.update(extra_meta)
+    import json
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(out_path, **out)
+    print("wrote", out_path, "loss.all=%.6f" % out["loss.all"], "R=%d S=%d" % (out["out.rgb"].shape[0] * out["out.rgb"].shape[1], meta["N_samples"]),
+          "size=%.0f KB" % (os.path.getsize(out_path) / 1024))
+
+
+def known_answers(camera, kernels, bat, out_path):
+    """Known-answer vectors for the small pure functions on the path."""
+    import model.tensorf_repr.bateRF as bateRF
+    torch.manual_seed(7)
+    out = {}
+    wu = torch.cat([torch.randn(6, 6) * 0.3, torch.zeros(1, 6), torch.randn(2, 6) * 1e-4,
+                    torch.tensor([[3.0, 0.1, -0.2, 0.5, -0.4, 0.3]])], 0).requires_grad_(True)
+    Rt = camera.lie.se3_to_SE3(wu)
+    cot = torch.randn(Rt.shape)
+    (Rt * cot).sum().backward()
+    out["se3.wu"] = wu.detach().numpy()
+    out["se3.Rt"] = Rt.detach().numpy()
+    out["se3.cot"] = cot.numpy()
+    out["se3.grad_wu"] = wu.grad.numpy()
+    pa, pb = torch.randn(5, 3, 4), torch.randn(5, 3, 4)
+    out["compose.a"] = pa.numpy()
+    out["compose.b"] = pb.numpy()
+    out["compose.ab"] = camera.pose.compose_pair(pa, pb).numpy()
+    sig = [1e-5, 0.05, 0.37, 1.0, 2.68, 4.8, 6.4, 7.94]
+    out["gauss.sigma"] = np.array(sig, np.float32)
+    out["gauss.k65"] = np.stack([kernels.get_gaussian_kernel(torch.tensor(s), 64).numpy() for s in sig])
+    out["gauss.k9"] = np.stack([kernels.get_gaussian_kernel(torch.tensor(s), 8).numpy() for s in sig])
+    # separable blur of planes/lines through the reference's own methods (cubic and non-cubic)
+    conv_plane = bateRF.BAT_VMSplit.convolute_plane
+    conv_line = bateRF.BAT_VMSplit.convolute_line
+    k = kernels.get_gaussian_kernel(torch.tensor(2.3), 16).view(1, 1, -1)
+    out["blur.kernel"] = k.view(-1).numpy()
+    for name, (C, gm0, gm1) in dict(cubic=(5, 11, 11), noncubic=(4, 9, 13)).items():
+        plane = torch.randn(1, C, gm1, gm0)  # [1,C,g[m1],g[m0]] as in tensoRF.py:165
+        out["blur.%s.in" % name] = plane.numpy()
+        # reference call site passes (H,W) = (g[m0], g[m1])  (bateRF.py:68,76)
+        out["blur.%s.out" % name] = conv_plane(None, k, plane, gm0, gm1).numpy()
+    line = torch.randn(1, 6, 17, 1)
+    out["blur.line.in"] = line.numpy()
+    out["blur.line.out"] = conv_line(None, k, line).numpy()
+    np.savez_compressed(out_path, **out)
+    print("wrote", out_path)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden"))
+    args = ap.parse_args()
+    outdir = os.path.abspath(args.out)
+    os.makedirs(outdir, exist_ok=True)
+    options, camera, bat, kernels = import_reference()
+    torch.set_num_threads(4)
+
+    known_answers(camera, kernels, bat, os.path.join(outdir, "known_answers.npz"))
+
+    # ---- Blender (bat_blender_VM): cubic grid, MLP_Fea, softplus, white bg -----------------------
+    B = 3
+    opt = make_opt(options, "bat_blender_VM", H=40, W=40, n_voxel_init=14 ** 3,
+                   extra=dict(nerf=dict(n_rays=96)))
+    graph = build_graph(bat, camera, opt, B, seed=1)
+    var = make_var(opt, B, seed=1)
+    run_case(bat, camera, opt, graph, var, "train", it=0, progress=0.0,
+             out_path=os.path.join(outdir, "blender_train_blur.npz"))
+    run_case(bat, camera, opt, graph, var, "train", it=1, progress=0.9,
+             out_path=os.path.join(outdir, "blender_train_sharp.npz"))
+    run_case(bat, camera, opt, graph, var, "vis", it=2, progress=0.05,
+             out_path=os.path.join(outdir, "blender_vis_blur.npz"))
+    # semi-transparent content (acc ~ 0.3-0.9): the numerically most informative case
+    with torch.no_grad():
+        for p in graph.nerf.tensorf.density_plane:
+            p.mul_(22.0)
+    run_case(bat, camera, opt, graph, var, "train", it=6, progress=0.9,
+             out_path=os.path.join(outdir, "blender_train_mid.npz"))
+    run_case(bat, camera, opt, graph, var, "train", it=7, progress=0.2,
+             out_path=os.path.join(outdir, "blender_train_mid_blur.npz"))
+    # denser content: acc ~ 1, part of the samples fall under rayMarch_weight_thres
+    with torch.no_grad():
+        for p in graph.nerf.tensorf.density_plane:
+            p.mul_(40.0 / 22.0)
+    run_case(bat, camera, opt, graph, var, "train", it=3, progress=0.9,
+             out_path=os.path.join(outdir, "blender_train_dense.npz"))
+    run_case(bat, camera, opt, graph, var, "train", it=4, progress=0.1,
+             out_path=os.path.join(outdir, "blender_train_dense_blur.npz"))
+
+    # all_view_rand_rays variant (config C1 uses it)
+    opt2 = make_opt(options, "bat_blender_VM", H=40, W=40, n_voxel_init=14 ** 3,
+                    extra=dict(nerf=dict(n_rays=60, ray_sampling_strategy="all_view_rand_rays")))
+    graph2 = build_graph(bat, camera, opt2, B, seed=2)
+    var2 = make_var(opt2, B, seed=2)
+    run_case(bat, camera, opt2, graph2, var2, "train", it=5, progress=0.5,
+             out_path=os.path.join(outdir, "blender_train_randrays.npz"))
+
+    # ---- LLFF (bat_llff_VM_MLP): NDC rays, non-cubic grid, WeakView MLP, relu ---------------------
+    Bl = 3
+    optl = make_opt(options, "bat_llff_VM_MLP", H=30, W=40, n_voxel_init=2200,
+                    extra=dict(nerf=dict(n_rays=90)))
+    optl.train_schedule.n_rays_init = 90
+    graphl = build_graph(bat, camera, optl, Bl, seed=3, noise=False)
+    varl = make_var(optl, Bl, seed=3, llff=True)
+    # give the field some content so relu density is non-trivial
+    run_case(bat, camera, optl, graphl, varl, "train", it=0, progress=0.9,
+             out_path=os.path.join(outdir, "llff_train_sharp.npz"), llff=True)
+    run_case(bat, camera, optl, graphl, varl, "train", it=1, progress=0.05,
+             out_path=os.path.join(outdir, "llff_train_blur.npz"), llff=True)
+    # thinner content + a seed whose CPU coin (batBase.py:154) comes up < 0.5 -> white background added
+    with torch.no_grad():
+        for p in graphl.nerf.tensorf.density_plane:
+            p.mul_(0.02)
+    run_case(bat, camera, optl, graphl, varl, "train", it=2, progress=0.12,
+             out_path=os.path.join(outdir, "llff_train_thin_whitebg.npz"), llff=True, torch_seed=11)
+
+
+if __name__ == "__main__":
+    main()
