@@ -1,0 +1,214 @@
+/*
+ * jt_render.h -- C ABI of the MI355X (gfx950) TensoRF-VM joint pose + radiance-field renderer.
+ *
+ * The reference (Nemo1999/Joint-TensoRF) is pure Python/PyTorch and has no FFI of its own
+ * (SURVEY.md §8(b)); its seam is the duck-typed scene class reached through
+ * `getattr(tensorf_repr, opt.arch.tensorf.model)` (model/tensorf.py:375-397) and its
+ * `forward(...)` (model/tensorf_repr/batBase.py:44-165).  This header is the boundary a
+ * maintainer binds instead of the stock torch ops on that path; every entry point names the
+ * reference code it replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, sizes, a hipStream_t passed as void*; no torch types.
+ *   - every function returns 0 on success, JT_ERR_* (>0) on bad arguments, or the negated
+ *     hipError_t of a failed launch.  No exceptions, no hidden allocation, no internal
+ *     threads, no host synchronisation: re-entrant per stream and hipGraph-capturable.
+ *   - VM factors are CHANNEL-LAST: plane i is [H_i][W_i][C] floats (logical torch tensor
+ *     [1,C,H,W] = [1,C,g[m1],g[m0]], tensoRF.py:165), line i is [L_i][C] (logical [1,C,g[v],1]).
+ *     matMode = {{0,1},{0,2},{1,2}}, vecMode = {2,1,0} (tensorBase.py:405-406).
+ *   - rays are [R][3] fp32 (origins, un-normalised directions), outputs [R][3] / [R].
+ *   - gradient buffers are ACCUMULATED into (atomics); the caller zeroes them.
+ */
+#ifndef JT_RENDER_H
+#define JT_RENDER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JT_VERSION 1001
+
+#define JT_OK 0
+#define JT_ERR_ARG 1         /* null pointer / bad size */
+#define JT_ERR_UNSUPPORTED 2 /* shape outside what the kernels are instantiated for */
+
+#define JT_ACT_SOFTPLUS 0 /* softplus(x + shift)  tensorBase.py:696-698 */
+#define JT_ACT_RELU 1     /* relu(x + shift)      tensorBase.py:699-700 */
+
+#define JT_MLP_FEA 0      /* MLPRender_Fea          tensorBase.py:101-126 */
+#define JT_MLP_WEAKVIEW 1 /* MLPRender_Fea_WeakView tensorBase.py:180-214 */
+
+/* Scene / call description: 4-byte fields only (mirrored 1:1 by ctypes in joint_tensorf_amd/_lib.py).
+ * Replaces the TensorBase attributes set in tensorBase.py:430-488 plus the per-call keyword
+ * arguments of BatBase.forward (batBase.py:44). */
+typedef struct JtScene {
+  float aabb_lo[3];
+  float aabb_hi[3];
+  int32_t plane_h[3];   /* rows  of plane i as stored (g[m1]; swapped when the reference's    */
+  int32_t plane_w[3];   /* cols  non-cubic blur quirk is reproduced)         */
+  int32_t line_len[3];  /* g[v]                                                               */
+  int32_t n_comp_density; /* channels of every density plane/line (16 in both BAT yamls)      */
+  int32_t n_comp_app;     /* channels of every appearance plane/line (48 Blender, 20 LLFF)    */
+  float step_size;      /* tensorBase.py:484                                                  */
+  float near_plane;     /* near_far[0]                                                        */
+  float far_plane;      /* near_far[1]                                                        */
+  float distance_scale; /* batBase.py:122                                                     */
+  float density_shift;
+  int32_t density_act;  /* JT_ACT_*                                                           */
+  float weight_thres;   /* rayMarch_weight_thres, batBase.py:127                              */
+  int32_t n_samples;    /* N_samples                                                          */
+  int32_t ndc;          /* 1: sample_ray_ndc semantics (tensorBase.py:554-571, batBase.py:61-66) */
+  int32_t white_bg;     /* resolved `white_bg or (is_train and coin<0.5)` batBase.py:154      */
+  int32_t app_dim;      /* basis_mat rows (27 / 20)                                           */
+  int32_t mlp_kind;     /* JT_MLP_*                                                           */
+  int32_t mlp_hidden;   /* featureC (64 / 32)                                                 */
+  int32_t view_pe;
+  int32_t fea_pe;
+  float view_pe_progress;
+  float fea_pe_progress;
+} JtScene;
+
+/* the 12 VM factor tensors (or their gradients) */
+typedef struct JtFactors {
+  float* density_plane[3];
+  float* density_line[3];
+  float* app_plane[3];
+  float* app_line[3];
+} JtFactors;
+
+/* basis_mat.weight [app_dim][3*n_comp_app] and the render MLP (torch Linear layout [out][in]) */
+typedef struct JtMlp {
+  float* basis;
+  float* w1;
+  float* b1;
+  float* w2;
+  float* b2;
+  float* w3;
+  float* b3;
+} JtMlp;
+
+int jt_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Ray generation for the SAMPLED pixels only.
+ * Replaces camera.get_center_and_ray (camera.py:231-261) + `[:,ray_idx]` (model/tensorf.py:159-161)
+ * and, when `ndc` != 0, camera.convert_NDC (camera.py:303-340).
+ *   pose [B][12] (3x4 row-major, world->camera), intr_inv [B][9], intr [B][9] (NDC only, may be
+ *   NULL otherwise), ray_idx [r] int64 flat pixel index y*W+x (same lattice for every view).
+ *   out: rays_o, rays_d [B*r][3].
+ * backward: g_rays_o/g_rays_d [B*r][3] -> g_pose [B][12] (overwritten, deterministic per view). */
+int jt_raygen_forward(const float* pose, const float* intr_inv, const float* intr, const int64_t* ray_idx,
+                      int n_views, int rays_per_view, int image_w, int ndc, float ndc_near,
+                      float* rays_o, float* rays_d, void* stream);
+int jt_raygen_backward(const float* pose, const float* intr_inv, const float* intr, const int64_t* ray_idx,
+                       int n_views, int rays_per_view, int image_w, int ndc, float ndc_near,
+                       const float* g_rays_o, const float* g_rays_d, float* g_pose, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Learnable pose: pose = exp(se3) o noise o gt.
+ * Replaces bat.Graph.get_pose train branch (model/bat.py:341-353), Lie.se3_to_SE3 with the
+ * nth=8 Taylor series (camera.py:81-99,122-145) and Pose.compose_pair (camera.py:50-57).
+ *   se3 [B][6]; noise [B][12] or NULL; gt [B][12] (gt_stride 12) or one [12] shared (gt_stride 0).
+ * backward: g_pose [B][12] -> g_se3 [B][6] (overwritten). */
+int jt_pose_forward(const float* se3, const float* noise, const float* gt, int gt_stride, int n_views,
+                    float* pose, void* stream);
+int jt_pose_backward(const float* se3, const float* noise, const float* gt, int gt_stride, int n_views,
+                     const float* g_pose, float* g_se3, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Separable 1-D blur of a channel-last factor, replicate padding, cross-correlation.
+ * Replaces BAT_VMSplit.convolute_plane / convolute_line (bateRF.py:8-39); taps come from
+ * kernels.get_gaussian_kernel (kernels.py:16-22), n_taps odd (65 for c2f_kernel_size 64).
+ *   in/out [H][W][C]; a line is H = L, W = 1 (only the H pass runs).  tmp: H*W*C floats scratch.
+ * backward is the exact adjoint (g_out -> g_in, overwritten). */
+int jt_blur_forward(const float* in, float* out, float* tmp, int H, int W, int C, const float* taps, int n_taps,
+                    void* stream);
+int jt_blur_backward(const float* g_out, float* g_in, float* tmp, int H, int W, int C, const float* taps,
+                     int n_taps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Staged renderer (forward).  Replaces BatBase.forward (batBase.py:44-165) and everything it
+ * calls: sample_ray / sample_ray_ndc (tensorBase.py:554-612), compute_densityfeature
+ * (bateRF.py:41-94), feature2density (tensorBase.py:696-700), raw2alpha (tensorBase.py:57-65),
+ * compute_appfeature (bateRF.py:97-130), basis_mat (tensoRF.py:156), MLPRender_Fea[_WeakView]
+ * (tensorBase.py:101-126,180-214) and the compositing tail (batBase.py:142-165).
+ *
+ * jt_march_forward: sampling + density + transmittance scan.
+ *   jitter: [R] one uniform draw per ray (tensorBase.py:592-596) or NULL; NDC: zvals [S] holds the
+ *   (jittered) linspace row shared by all rays (tensorBase.py:557-559), jitter ignored.
+ *   out: sigma_feat [R][S], weight [R][S], tmin [R], shade_count [R], shade_offset [R+1]
+ *   (exclusive scan; [R] = number of shaded samples), shade_idx [R][S] uint16 (sample indices with
+ *   weight > thres, in order), opacity [R], depth [R] (batBase.py:147-151).
+ * jt_shade_list: entry -> (ray, sample) map + the positions the appearance path needs.
+ *   out: entry_ray [n], entry_smp [n] (int32), viewdirs [n][3] (normalised when ndc).
+ * jt_app_gather_forward: prod [n][3*Ca] = plane_i^c(p) * line_i^c(p)  (bateRF.py:124-128).
+ * jt_shade_forward (fused, MFMA): prod -> basis -> MLP -> sigmoid, rgb_s [n][3].
+ * jt_composite_forward: rgb [R][3] = sum_k w_k c_k (+ white bg) clamped, clamp_mask [R] bit ch
+ *   set when the un-clamped value lies in [0,1]. */
+int jt_march_forward(const JtScene* scene, const JtFactors* factors, const float* rays_o, const float* rays_d,
+                     const float* jitter, const float* zvals, int n_rays, float* sigma_feat, float* weight,
+                     float* tmin, int32_t* shade_count, int32_t* shade_offset, uint16_t* shade_idx,
+                     float* opacity, float* depth, void* stream);
+int jt_shade_list(const JtScene* scene, const float* rays_d, int n_rays, const int32_t* shade_offset,
+                  const uint16_t* shade_idx, int32_t* entry_ray, int32_t* entry_smp, float* viewdirs,
+                  int n_entries_max, void* stream);
+int jt_app_gather_forward(const JtScene* scene, const JtFactors* factors, const float* rays_o,
+                          const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
+                          const int32_t* shade_offset, int n_rays, const int32_t* entry_ray,
+                          const int32_t* entry_smp, float* prod, int n_entries_max, void* stream);
+int jt_composite_forward(const JtScene* scene, int n_rays, const int32_t* shade_offset,
+                         const uint16_t* shade_idx, const float* weight, const float* rgb_s,
+                         const float* opacity, float* rgb, int32_t* clamp_mask, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Staged renderer (backward) -- replaces autograd of all of the above (loss.all.backward(),
+ * model/base.py:162; the scatter-adds of grid_sampler_2d_backward).
+ * jt_composite_backward: g_rgb [R][3] -> g_rgb_s [n][3] (= weight * g_rgb masked by clamp).
+ * jt_app_gather_backward: g_prod [n][3*Ca] -> += g_factors.app_*, g_xyz_app [n][3] (overwritten).
+ * jt_march_backward: density + transmittance backward:
+ *   += g_factors.density_*; g_rays_o, g_rays_d [R][3] overwritten (include the app path's
+ *   coordinate gradients read from g_xyz_app).  g_opacity [R] may be NULL. */
+int jt_composite_backward(const JtScene* scene, int n_rays, const int32_t* shade_offset,
+                          const int32_t* entry_ray, const int32_t* entry_smp, const float* weight,
+                          const int32_t* clamp_mask, const float* g_rgb, float* g_rgb_s, int n_entries_max,
+                          void* stream);
+int jt_app_gather_backward(const JtScene* scene, const JtFactors* factors, const float* rays_o,
+                           const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
+                           const int32_t* shade_offset, int n_rays, const int32_t* entry_ray,
+                           const int32_t* entry_smp, const float* g_prod, const JtFactors* g_factors,
+                           float* g_xyz_app, int n_entries_max, void* stream);
+int jt_march_backward(const JtScene* scene, const JtFactors* factors, const float* rays_o, const float* rays_d,
+                      const float* jitter, const float* zvals, int n_rays, const float* sigma_feat,
+                      const float* weight, const float* tmin, const int32_t* shade_offset,
+                      const uint16_t* shade_idx, const float* rgb_s, const int32_t* clamp_mask,
+                      const float* g_rgb, const float* g_opacity, const float* g_xyz_app,
+                      const JtFactors* g_factors, float* g_rays_o, float* g_rays_d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused appearance path on the matrix cores (fp32 MFMA, exact-f32 numerics):
+ * gather(app planes/lines) -> outer product -> basis_mat -> PE -> MLP -> sigmoid, per shaded
+ * sample, without materialising the [n][3*Ca] product matrix.
+ * Replaces compute_appfeature + basis_mat + MLPRender_Fea[_WeakView].forward and their autograd.
+ *   forward : rgb_s [n][3]
+ *   backward: g_rgb_s [n][3] -> += g_factors.app_*, += g_mlp.*, g_xyz_app [n][3] (overwritten)
+ * workspace: jt_shade_workspace_bytes(scene) bytes (packed weights), caller-provided. */
+size_t jt_shade_workspace_bytes(const JtScene* scene);
+int jt_shade_forward(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp, const float* rays_o,
+                     const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
+                     const int32_t* shade_offset, int n_rays, const int32_t* entry_ray,
+                     const int32_t* entry_smp, const float* viewdirs, float* rgb_s, int n_entries_max,
+                     void* workspace, size_t workspace_bytes, void* stream);
+int jt_shade_backward(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp, const float* rays_o,
+                      const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
+                      const int32_t* shade_offset, int n_rays, const int32_t* entry_ray,
+                      const int32_t* entry_smp, const float* viewdirs, const float* g_rgb_s,
+                      const JtFactors* g_factors, const JtMlp* g_mlp, float* g_xyz_app, int n_entries_max,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JT_RENDER_H */

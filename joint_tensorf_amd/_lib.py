@@ -1,0 +1,100 @@
+"""ctypes binding of libjt_render.so (the C ABI declared in include/jt_render.h).
+
+The library is built in-tree by joint_tensorf_amd/build.py (hipcc --offload-arch=gfx950).  There is
+NO fallback: if the shared object is missing or a symbol is absent, importing this module raises.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libjt_render.so")
+
+c_float_p = ctypes.c_void_p  # raw device pointers travel as integers
+c_f = ctypes.c_float
+c_i = ctypes.c_int32
+
+JT_ACT_SOFTPLUS, JT_ACT_RELU = 0, 1
+JT_MLP_FEA, JT_MLP_WEAKVIEW = 0, 1
+
+
+class JtScene(ctypes.Structure):
+    _fields_ = [
+        ("aabb_lo", c_f * 3), ("aabb_hi", c_f * 3),
+        ("plane_h", c_i * 3), ("plane_w", c_i * 3), ("line_len", c_i * 3),
+        ("n_comp_density", c_i), ("n_comp_app", c_i),
+        ("step_size", c_f), ("near_plane", c_f), ("far_plane", c_f),
+        ("distance_scale", c_f), ("density_shift", c_f), ("density_act", c_i),
+        ("weight_thres", c_f), ("n_samples", c_i), ("ndc", c_i), ("white_bg", c_i),
+        ("app_dim", c_i), ("mlp_kind", c_i), ("mlp_hidden", c_i), ("view_pe", c_i), ("fea_pe", c_i),
+        ("view_pe_progress", c_f), ("fea_pe_progress", c_f),
+    ]
+
+
+class JtFactors(ctypes.Structure):
+    _fields_ = [("density_plane", ctypes.c_void_p * 3), ("density_line", ctypes.c_void_p * 3),
+                ("app_plane", ctypes.c_void_p * 3), ("app_line", ctypes.c_void_p * 3)]
+
+
+class JtMlp(ctypes.Structure):
+    _fields_ = [("basis", ctypes.c_void_p), ("w1", ctypes.c_void_p), ("b1", ctypes.c_void_p),
+                ("w2", ctypes.c_void_p), ("b2", ctypes.c_void_p), ("w3", ctypes.c_void_p),
+                ("b3", ctypes.c_void_p)]
+
+
+# every symbol include/jt_render.h declares (tests/test_abi.py checks header <-> this table <-> .so)
+P = ctypes.c_void_p
+I = ctypes.c_int
+F = ctypes.c_float
+SP = ctypes.POINTER(JtScene)
+FP = ctypes.POINTER(JtFactors)
+MP = ctypes.POINTER(JtMlp)
+SIGNATURES = {
+    "jt_version": (ctypes.c_int, []),
+    "jt_raygen_forward": (I, [P, P, P, P, I, I, I, I, F, P, P, P]),
+    "jt_raygen_backward": (I, [P, P, P, P, I, I, I, I, F, P, P, P, P]),
+    "jt_pose_forward": (I, [P, P, P, I, I, P, P]),
+    "jt_pose_backward": (I, [P, P, P, I, I, P, P, P]),
+    "jt_blur_forward": (I, [P, P, P, I, I, I, P, I, P]),
+    "jt_blur_backward": (I, [P, P, P, I, I, I, P, I, P]),
+    "jt_march_forward": (I, [SP, FP, P, P, P, P, I, P, P, P, P, P, P, P, P, P]),
+    "jt_shade_list": (I, [SP, P, I, P, P, P, P, P, I, P]),
+    "jt_app_gather_forward": (I, [SP, FP, P, P, P, P, P, P, I, P, P, P, I, P]),
+    "jt_composite_forward": (I, [SP, I, P, P, P, P, P, P, P, P]),
+    "jt_composite_backward": (I, [SP, I, P, P, P, P, P, P, P, I, P]),
+    "jt_app_gather_backward": (I, [SP, FP, P, P, P, P, P, P, I, P, P, P, FP, P, I, P]),
+    "jt_march_backward": (I, [SP, FP, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, FP, P, P, P]),
+    "jt_shade_workspace_bytes": (ctypes.c_size_t, [SP]),
+    "jt_shade_forward": (I, [SP, FP, MP, P, P, P, P, P, P, I, P, P, P, P, I, P, ctypes.c_size_t, P]),
+    "jt_shade_backward": (I, [SP, FP, MP, P, P, P, P, P, P, I, P, P, P, P, FP, MP, P, I, P, ctypes.c_size_t, P]),
+}
+
+
+class JtError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "joint_tensorf_amd: %s is missing -- build it with `python joint_tensorf_amd/build.py` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = "bad argument" if rc == 1 else "unsupported shape" if rc == 2 else "HIP error %d" % (-rc)
+        raise JtError("%s failed: %s (rc=%d)" % (what, kind, rc))
+
+
+def ptr(t):
+    """device pointer of a tensor (or None)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,195 @@
+// Device-side helpers shared by the gfx950 kernels of the TensoRF-VM renderer.
+// Math follows the reference line by line where the result is DISCRETE (in-box test, sample
+// positions): those expressions use non-contracted __fmul_rn/__fadd_rn so that they round exactly
+// like the torch elementwise ops they replace (tensorBase.py:572-612).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jt_render.h"
+
+namespace jt {
+
+// matMode / vecMode of the reference (tensorBase.py:405-406)
+__device__ __constant__ const int kM0[3] = {0, 0, 1};
+__device__ __constant__ const int kM1[3] = {1, 2, 2};
+__device__ __constant__ const int kV[3] = {2, 1, 0};
+
+struct Dev {
+  float lo[3], hi[3], inv[3];  // inv = 2/(hi-lo)  (tensorBase.py:481)
+  int ph[3], pw[3], ll[3];
+  int Cd, Ca;
+  float step, near_, far_, dist_scale, shift, thres;
+  int act, S, ndc, white_bg;
+  const float* dP[3];
+  const float* dL[3];
+  const float* aP[3];
+  const float* aL[3];
+};
+
+inline int make_dev(const JtScene* s, const JtFactors* f, Dev* d) {
+  if (!s) return JT_ERR_ARG;
+  for (int a = 0; a < 3; ++a) {
+    d->lo[a] = s->aabb_lo[a];
+    d->hi[a] = s->aabb_hi[a];
+    d->inv[a] = 2.0f / (s->aabb_hi[a] - s->aabb_lo[a]);
+    d->ph[a] = s->plane_h[a];
+    d->pw[a] = s->plane_w[a];
+    d->ll[a] = s->line_len[a];
+    if (s->plane_h[a] < 1 || s->plane_w[a] < 1 || s->line_len[a] < 1) return JT_ERR_ARG;
+    d->dP[a] = f ? f->density_plane[a] : nullptr;
+    d->dL[a] = f ? f->density_line[a] : nullptr;
+    d->aP[a] = f ? f->app_plane[a] : nullptr;
+    d->aL[a] = f ? f->app_line[a] : nullptr;
+  }
+  d->Cd = s->n_comp_density;
+  d->Ca = s->n_comp_app;
+  d->step = s->step_size;
+  d->near_ = s->near_plane;
+  d->far_ = s->far_plane;
+  d->dist_scale = s->distance_scale;
+  d->shift = s->density_shift;
+  d->thres = s->weight_thres;
+  d->act = s->density_act;
+  d->S = s->n_samples;
+  d->ndc = s->ndc;
+  d->white_bg = s->white_bg;
+  if (d->S < 1 || d->S > 65535) return JT_ERR_ARG;
+  return JT_OK;
+}
+
+#define JT_LAUNCH_CHECK()                      \
+  do {                                         \
+    hipError_t e__ = hipGetLastError();        \
+    if (e__ != hipSuccess) return -(int)e__;   \
+  } while (0)
+
+// ---- per-ray geometry ------------------------------------------------------------------------
+struct Ray {
+  float o[3], d[3];
+  float tmin;  // AABB entry distance, clamped to [near, far]   (tensorBase.py:587-589)
+  float u;     // per-ray jitter (0 when not training)
+  float norm;  // |d| (NDC only, batBase.py:64)
+};
+
+__device__ inline float ray_tmin(const Dev& D, const float o[3], const float d[3]) {
+  float t = -INFINITY;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float v = (d[a] == 0.f) ? 1e-6f : d[a];
+    float ra = (D.hi[a] - o[a]) / v;
+    float rb = (D.lo[a] - o[a]) / v;
+    t = fmaxf(t, fminf(ra, rb));
+  }
+  return fminf(fmaxf(t, D.near_), D.far_);
+}
+
+// z_i = t_min + stepSize * (i + u)     (tensorBase.py:591-596); NDC: z_i = zvals[i]
+__device__ inline float sample_z(const Dev& D, const Ray& r, const float* zvals, int i) {
+  if (D.ndc) return zvals[i];
+  float rng = __fadd_rn((float)i, r.u);
+  return __fadd_rn(r.tmin, __fmul_rn(D.step, rng));
+}
+
+// pts = o + d*z (un-fused, tensorBase.py:598) and the in-box test (tensorBase.py:610)
+__device__ inline bool sample_point(const Dev& D, const Ray& r, float z, float p[3]) {
+  bool inside = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    p[a] = __fadd_rn(r.o[a], __fmul_rn(r.d[a], z));
+    inside = inside && !(D.lo[a] > p[a]) && !(p[a] > D.hi[a]);
+  }
+  return inside;
+}
+
+// normalize_coord (tensorBase.py:502-503)
+__device__ inline void normalize(const Dev& D, const float p[3], float n[3]) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) n[a] = (p[a] - D.lo[a]) * D.inv[a] - 1.f;
+}
+
+// ---- bilinear / linear taps: grid_sample(bilinear, align_corners=True, zeros) ------------------
+struct Axis {
+  int i0;        // floor cell (clamped copy in c0/c1 for addressing)
+  int c0, c1;    // clamped indices
+  float w0, w1;  // tap weights, zeroed when the tap is out of range
+  float f;       // fractional part
+  float m0, m1;  // 1/0 in-range masks
+  float scale;   // d(ix)/d(normalised coord) = (size-1)/2
+};
+
+__device__ inline Axis axis_taps(float g, int size) {
+  Axis a;
+  float ix = ((g + 1.f) * 0.5f) * (float)(size - 1);
+  float fl = floorf(ix);
+  a.f = ix - fl;
+  a.i0 = (int)fl;
+  bool in0 = (a.i0 >= 0) && (a.i0 < size);
+  bool in1 = (a.i0 + 1 >= 0) && (a.i0 + 1 < size);
+  a.m0 = in0 ? 1.f : 0.f;
+  a.m1 = in1 ? 1.f : 0.f;
+  a.c0 = min(max(a.i0, 0), size - 1);
+  a.c1 = min(max(a.i0 + 1, 0), size - 1);
+  a.w0 = in0 ? (1.f - a.f) : 0.f;
+  a.w1 = in1 ? a.f : 0.f;
+  a.scale = 0.5f * (float)(size - 1);
+  return a;
+}
+
+struct PlaneTaps {
+  int o00, o10, o01, o11;  // element offsets (texel * C) of (x0,y0) (x1,y0) (x0,y1) (x1,y1)
+  float w00, w10, w01, w11;
+  Axis ax, ay;
+};
+
+__device__ inline PlaneTaps plane_taps(float gx, float gy, int H, int W, int C) {
+  PlaneTaps t;
+  t.ax = axis_taps(gx, W);
+  t.ay = axis_taps(gy, H);
+  t.o00 = (t.ay.c0 * W + t.ax.c0) * C;
+  t.o10 = (t.ay.c0 * W + t.ax.c1) * C;
+  t.o01 = (t.ay.c1 * W + t.ax.c0) * C;
+  t.o11 = (t.ay.c1 * W + t.ax.c1) * C;
+  t.w00 = t.ax.w0 * t.ay.w0;
+  t.w10 = t.ax.w1 * t.ay.w0;
+  t.w01 = t.ax.w0 * t.ay.w1;
+  t.w11 = t.ax.w1 * t.ay.w1;
+  return t;
+}
+
+// density activation (tensorBase.py:696-700; F.softplus beta=1 threshold=20)
+__device__ inline float density_act(int act, float x) {
+  if (act == JT_ACT_RELU) return fmaxf(x, 0.f);
+  return (x > 20.f) ? x : log1pf(expf(x));
+}
+__device__ inline float density_act_grad(int act, float x) {
+  if (act == JT_ACT_RELU) return (x > 0.f) ? 1.f : 0.f;
+  return (x > 20.f) ? 1.f : 1.f / (1.f + expf(-x));
+}
+
+__device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ inline void load_ray(const Dev& D, const float* rays_o, const float* rays_d, const float* jitter,
+                                const float* tmin_in, int ray, Ray& r) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    r.o[a] = rays_o[ray * 3 + a];
+    r.d[a] = rays_d[ray * 3 + a];
+  }
+  r.u = (jitter && !D.ndc) ? jitter[ray] : 0.f;
+  r.norm = 1.f;
+  if (D.ndc) {
+    r.norm = sqrtf(r.d[0] * r.d[0] + r.d[1] * r.d[1] + r.d[2] * r.d[2]);
+    r.tmin = 0.f;
+  } else {
+    r.tmin = tmin_in ? tmin_in[ray] : ray_tmin(D, r.o, r.d);
+  }
+}
+
+}  // namespace jt

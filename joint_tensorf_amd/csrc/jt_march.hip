@@ -1,0 +1,573 @@
+// Ray marching kernels (gfx950): sampling, density interpolation, transmittance scan, compositing,
+// and their backward.  One 64-lane wavefront owns one ray; lanes stride over the ray's samples so
+// the transmittance product is a wave prefix scan with a carry between 64-sample chunks.
+#include "jt_common.h"
+
+namespace jt {
+
+// ---------------------------------------------------------------------------------------------
+// density feature of one point: sum_i sum_c bilinear(P_i^c) * linear(L_i^c)   (bateRF.py:41-94)
+// lane-per-sample form: every lane walks its own 16-channel texels with 16-byte loads.
+// ---------------------------------------------------------------------------------------------
+__device__ inline float density_feature(const Dev& D, const float n[3]) {
+  float feat = 0.f;
+  const int C = D.Cd;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    PlaneTaps t = plane_taps(n[kM0[i]], n[kM1[i]], D.ph[i], D.pw[i], C);
+    Axis l = axis_taps(n[kV[i]], D.ll[i]);
+    const float* P = D.dP[i];
+    const float* L = D.dL[i];
+    const int l0 = l.c0 * C, l1 = l.c1 * C;
+    float s = 0.f;
+    for (int q = 0; q < C; q += 4) {
+      float4 a = ld4(P + t.o00 + q), b = ld4(P + t.o10 + q), c = ld4(P + t.o01 + q), d = ld4(P + t.o11 + q);
+      float4 u = ld4(L + l0 + q), v = ld4(L + l1 + q);
+      float px = t.w00 * a.x + t.w10 * b.x + t.w01 * c.x + t.w11 * d.x;
+      float py = t.w00 * a.y + t.w10 * b.y + t.w01 * c.y + t.w11 * d.y;
+      float pz = t.w00 * a.z + t.w10 * b.z + t.w01 * c.z + t.w11 * d.z;
+      float pw = t.w00 * a.w + t.w10 * b.w + t.w01 * c.w + t.w11 * d.w;
+      s += px * (l.w0 * u.x + l.w1 * v.x) + py * (l.w0 * u.y + l.w1 * v.y) + pz * (l.w0 * u.z + l.w1 * v.z) +
+           pw * (l.w0 * u.w + l.w1 * v.w);
+    }
+    feat += s;
+  }
+  return feat;
+}
+
+// alpha_i = 1 - exp(-sigma_i * (delta_i * distance_scale))    (tensorBase.py:59, batBase.py:122)
+__device__ inline float sample_alpha(const Dev& D, float feat, bool valid, float delta, float* sigma_out) {
+  float sigma = valid ? density_act(D.act, feat + D.shift) : 0.f;
+  *sigma_out = sigma;
+  return 1.f - expf(-sigma * (delta * D.dist_scale));
+}
+
+// inclusive wave product scan; returns the exclusive value in *excl and the wave total
+__device__ inline float wave_prod_scan(float f, int lane, float* excl) {
+  float inc = f;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float t = __shfl_up(inc, o);
+    if (lane >= o) inc *= t;
+  }
+  float e = __shfl_up(inc, 1);
+  *excl = (lane == 0) ? 1.f : e;
+  return __shfl(inc, 63);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: march forward
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_march_fwd(Dev D, const float* __restrict__ rays_o,
+                                                   const float* __restrict__ rays_d,
+                                                   const float* __restrict__ jitter,
+                                                   const float* __restrict__ zvals, int R,
+                                                   float* __restrict__ sigma_feat, float* __restrict__ weight,
+                                                   float* __restrict__ tmin_out, int* __restrict__ count,
+                                                   uint16_t* __restrict__ sidx, float* __restrict__ opacity,
+                                                   float* __restrict__ depth) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= R) return;
+  Ray r;
+  load_ray(D, rays_o, rays_d, jitter, nullptr, ray, r);
+  const int S = D.S;
+  float carry = 1.f, acc = 0.f, dep = 0.f;
+  int cnt = 0;
+  const size_t row = (size_t)ray * S;
+  for (int base = 0; base < S; base += 64) {
+    const int i = base + lane;
+    const bool live = i < S;
+    float z0 = 0.f, delta = 0.f, feat = 0.f;
+    bool valid = false;
+    if (live) {
+      z0 = sample_z(D, r, zvals, i);
+      if (i < S - 1) delta = (sample_z(D, r, zvals, i + 1) - z0) * r.norm;
+      float p[3], n[3];
+      valid = sample_point(D, r, z0, p);
+      if (valid) {
+        normalize(D, p, n);
+        feat = density_feature(D, n);
+      }
+    }
+    float sigma;
+    float alpha = sample_alpha(D, feat, valid, delta, &sigma);
+    float f = live ? (1.f - alpha + 1e-10f) : 1.f;
+    float excl;
+    float total = wave_prod_scan(f, lane, &excl);
+    float T = carry * excl;
+    carry *= total;
+    float w = live ? alpha * T : 0.f;
+    if (live) {
+      sigma_feat[row + i] = feat;
+      weight[row + i] = w;
+    }
+    acc += w;
+    dep += w * z0;
+    const bool shade = live && (w > D.thres);
+    unsigned long long bal = __ballot(shade);
+    if (shade) {
+      int rank = __popcll(bal & ((1ull << lane) - 1ull));
+      sidx[row + cnt + rank] = (uint16_t)i;
+    }
+    cnt += __popcll(bal);
+  }
+  acc = wave_sum(acc);
+  dep = wave_sum(dep);
+  if (lane == 0) {
+    tmin_out[ray] = r.tmin;
+    count[ray] = cnt;
+    opacity[ray] = acc;
+    // depth = sum w z + (1-acc) * ray_dir_z - near + 0.05        (batBase.py:147-150)
+    depth[ray] = dep + (1.f - acc) * r.d[2] - D.near_ + 0.05f;
+  }
+}
+
+// exclusive scan of per-ray shade counts (one workgroup; R <= a few 100k)
+__global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ count, int* __restrict__ offset,
+                                                      int R) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int per = (R + 1023) / 1024;
+  const int b = t * per, e = min(b + per, R);
+  int s = 0;
+  for (int i = b; i < e; ++i) s += count[i];
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    int v = (t >= o) ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = (t == 0) ? 0 : part[t - 1];
+  for (int i = b; i < e; ++i) {
+    offset[i] = run;
+    run += count[i];
+  }
+  if (t == 1023) offset[R] = part[1023];
+}
+
+// entry -> (ray, sample) map, one wave per ray
+__global__ __launch_bounds__(256) void k_shade_list(Dev D, const float* __restrict__ rays_d, int R,
+                                                    const int* __restrict__ offset,
+                                                    const uint16_t* __restrict__ sidx, int* __restrict__ eray,
+                                                    int* __restrict__ esmp, float* __restrict__ vdir, int cap) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= R) return;
+  const int off = offset[ray], n = offset[ray + 1] - off;
+  float d0 = rays_d[ray * 3], d1 = rays_d[ray * 3 + 1], d2 = rays_d[ray * 3 + 2];
+  if (D.ndc) {
+    float nr = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+    d0 /= nr;
+    d1 /= nr;
+    d2 /= nr;
+  }
+  for (int k = lane; k < n; k += 64) {
+    int e = off + k;
+    if (e >= cap) break;
+    eray[e] = ray;
+    esmp[e] = sidx[(size_t)ray * D.S + k];
+    vdir[e * 3] = d0;
+    vdir[e * 3 + 1] = d1;
+    vdir[e * 3 + 2] = d2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: composite forward (batBase.py:142-159)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_composite_fwd(Dev D, int R, const int* __restrict__ offset,
+                                                       const uint16_t* __restrict__ sidx,
+                                                       const float* __restrict__ weight,
+                                                       const float* __restrict__ rgb_s,
+                                                       const float* __restrict__ opacity, float* __restrict__ rgb,
+                                                       int* __restrict__ clamp_mask) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= R) return;
+  const int off = offset[ray], n = offset[ray + 1] - off;
+  const size_t row = (size_t)ray * D.S;
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  for (int k = lane; k < n; k += 64) {
+    float w = weight[row + sidx[row + k]];
+    const float* c = rgb_s + (size_t)(off + k) * 3;
+    c0 += w * c[0];
+    c1 += w * c[1];
+    c2 += w * c[2];
+  }
+  c0 = wave_sum(c0);
+  c1 = wave_sum(c1);
+  c2 = wave_sum(c2);
+  if (lane == 0) {
+    float bg = D.white_bg ? (1.f - opacity[ray]) : 0.f;
+    float v[3] = {c0 + bg, c1 + bg, c2 + bg};
+    int m = 0;
+    for (int ch = 0; ch < 3; ++ch) {
+      if (v[ch] >= 0.f && v[ch] <= 1.f) m |= (1 << ch);  // clamp passes gradient on [0,1]
+      rgb[ray * 3 + ch] = fminf(fmaxf(v[ch], 0.f), 1.f);
+    }
+    clamp_mask[ray] = m;
+  }
+}
+
+// g_rgb_s[e] = weight_e * g_rgb[ray] (clamp-masked)
+__global__ __launch_bounds__(256) void k_composite_bwd(Dev D, const int* __restrict__ offset, int R,
+                                                       const int* __restrict__ eray, const int* __restrict__ esmp,
+                                                       const float* __restrict__ weight,
+                                                       const int* __restrict__ clamp_mask,
+                                                       const float* __restrict__ g_rgb, float* __restrict__ g_rgb_s,
+                                                       int cap) {
+  const int total = min(offset[R], cap);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    int ray = eray[e];
+    float w = weight[(size_t)ray * D.S + esmp[e]];
+    int m = clamp_mask[ray];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) g_rgb_s[(size_t)e * 3 + ch] = ((m >> ch) & 1) ? w * g_rgb[ray * 3 + ch] : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// march backward.  Per ray (one wave):
+//   A (forward order)  alpha_i, T_i from the stored sigma_feat; G_i = dL/dw_i
+//   B (reverse order)  suffix sums -> dL/dalpha_i -> dL/dsigma_feat_i ; list of in-box samples
+//   C (channel-parallel, 4 samples x 16 channels per wave instruction) re-gather the density taps,
+//     scatter-add plane/line gradients as 64-byte-contiguous float atomics per texel, reduce the
+//     coordinate gradients over the channel lanes
+//   D  add the appearance path's coordinate gradients of the ray's shaded samples
+// LDS per wave: 3 float arrays + 1 u16 array of S entries.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_march_bwd(Dev D, JtFactors G, const float* __restrict__ rays_o,
+                                                   const float* __restrict__ rays_d,
+                                                   const float* __restrict__ jitter,
+                                                   const float* __restrict__ zvals, int R,
+                                                   const float* __restrict__ sigma_feat,
+                                                   const float* __restrict__ weight,
+                                                   const float* __restrict__ tmin_in,
+                                                   const int* __restrict__ offset,
+                                                   const uint16_t* __restrict__ sidx,
+                                                   const float* __restrict__ rgb_s,
+                                                   const int* __restrict__ clamp_mask,
+                                                   const float* __restrict__ g_rgb,
+                                                   const float* __restrict__ g_opacity,
+                                                   const float* __restrict__ g_xyz_app,
+                                                   float* __restrict__ g_rays_o, float* __restrict__ g_rays_d,
+                                                   int Spad) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int ray = blockIdx.x * 4 + wv;
+  if (ray >= R) return;
+  float* s_alpha = reinterpret_cast<float*>(smem) + (size_t)wv * 3 * Spad;
+  float* s_T = s_alpha + Spad;
+  float* s_G = s_T + Spad;  // G_i, later g_feat_i
+  uint16_t* s_list = reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(smem) + (size_t)4 * 3 * Spad) +
+                     (size_t)wv * Spad;
+
+  Ray r;
+  load_ray(D, rays_o, rays_d, jitter, tmin_in, ray, r);
+  const int S = D.S;
+  const size_t row = (size_t)ray * S;
+  const int off = offset[ray];
+  const int m = clamp_mask[ray];
+  const float gr0 = (m & 1) ? g_rgb[ray * 3] : 0.f;
+  const float gr1 = (m & 2) ? g_rgb[ray * 3 + 1] : 0.f;
+  const float gr2 = (m & 4) ? g_rgb[ray * 3 + 2] : 0.f;
+  const float gacc = g_opacity ? g_opacity[ray] : 0.f;
+  // d(rgb_map)/dw_i = c_i - bg  with bg = 1 when the white background is composited
+  const float bgsum = D.white_bg ? (gr0 + gr1 + gr2) : 0.f;
+
+  // ---- pass A ----
+  float carry = 1.f;
+  int cnt = 0;
+  for (int base = 0; base < S; base += 64) {
+    const int i = base + lane;
+    const bool live = i < S;
+    float delta = 0.f, feat = 0.f, wst = 0.f;
+    bool valid = false;
+    if (live) {
+      float z0 = sample_z(D, r, zvals, i);
+      if (i < S - 1) delta = (sample_z(D, r, zvals, i + 1) - z0) * r.norm;
+      float p[3];
+      valid = sample_point(D, r, z0, p);
+      feat = sigma_feat[row + i];
+      wst = weight[row + i];
+    }
+    float sigma;
+    float alpha = sample_alpha(D, feat, valid, delta, &sigma);
+    float f = live ? (1.f - alpha + 1e-10f) : 1.f;
+    float excl;
+    float total = wave_prod_scan(f, lane, &excl);
+    float T = carry * excl;
+    carry *= total;
+    const bool shade = live && (wst > D.thres);
+    unsigned long long bal = __ballot(shade);
+    float Gw = gacc - bgsum;
+    if (shade) {
+      int e = off + cnt + __popcll(bal & ((1ull << lane) - 1ull));
+      const float* c = rgb_s + (size_t)e * 3;
+      Gw += gr0 * c[0] + gr1 * c[1] + gr2 * c[2];
+    }
+    cnt += __popcll(bal);
+    if (live) {
+      s_alpha[i] = alpha;
+      s_T[i] = T;
+      s_G[i] = Gw;
+    }
+  }
+  // ---- pass B (reverse) ----
+  float suffix = 0.f;  // sum_{j>i} G_j w_j carried from later chunks
+  float gnorm = 0.f;   // NDC: dL/d|d|
+  int nvalid = 0;
+  const int nchunk = (S + 63) / 64;
+  // in-box samples are listed in DEscending chunk order; order is irrelevant for the sums
+  for (int c = nchunk - 1; c >= 0; --c) {
+    const int i = c * 64 + lane;
+    const bool live = i < S;
+    float alpha = 0.f, T = 0.f, Gw = 0.f, delta = 0.f, feat = 0.f;
+    bool valid = false;
+    if (live) {
+      alpha = s_alpha[i];
+      T = s_T[i];
+      Gw = s_G[i];
+      float z0 = sample_z(D, r, zvals, i);
+      if (i < S - 1) delta = (sample_z(D, r, zvals, i + 1) - z0) * r.norm;
+      float p[3];
+      valid = sample_point(D, r, z0, p);
+      feat = sigma_feat[row + i];
+    }
+    float v = live ? Gw * (alpha * T) : 0.f;
+    // inclusive suffix scan over lanes
+    float inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      float t = __shfl_down(inc, o);
+      if (lane + o < 64) inc += t;
+    }
+    float excl_s = __shfl_down(inc, 1);
+    if (lane == 63) excl_s = 0.f;
+    float after = excl_s + suffix;  // sum over j > i
+    suffix += __shfl(inc, 0);
+    float f = 1.f - alpha + 1e-10f;
+    float g_alpha = Gw * T - after / f;
+    // alpha = 1 - exp(-sigma*delta*scale)
+    float one_m = 1.f - alpha;  // = exp(-sigma delta scale)
+    float dsc = delta * D.dist_scale;
+    float g_sigma = g_alpha * dsc * one_m;
+    float x = feat + D.shift;
+    float g_feat = valid ? g_sigma * density_act_grad(D.act, x) : 0.f;
+    if (D.ndc && valid && live) {
+      // delta = dz * |d|  ->  dalpha/d|d| = sigma * dz * scale * (1-alpha)
+      float sigma = density_act(D.act, x);
+      float dz = (r.norm > 0.f) ? delta / r.norm : 0.f;
+      gnorm += g_alpha * sigma * dz * D.dist_scale * one_m;
+    }
+    if (live) s_G[i] = g_feat;
+    const bool keep = live && valid && (g_feat != 0.f);
+    unsigned long long bal = __ballot(keep);
+    if (keep) s_list[nvalid + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
+    nvalid += __popcll(bal);
+  }
+  // ---- pass C: channel-parallel density backward ----
+  const int C = D.Cd;
+  const int sub = lane >> 4, ch = lane & 15;
+  float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < nvalid; k0 += 4) {
+    const int k = k0 + sub;
+    const bool on = k < nvalid;
+    const int i = on ? s_list[k] : 0;
+    const float g = on ? s_G[i] : 0.f;
+    const float z = sample_z(D, r, zvals, i);
+    float p[3], n[3];
+    sample_point(D, r, z, p);
+    normalize(D, p, n);
+    float gn[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      PlaneTaps t = plane_taps(n[kM0[pl]], n[kM1[pl]], D.ph[pl], D.pw[pl], C);
+      Axis l = axis_taps(n[kV[pl]], D.ll[pl]);
+      const float* P = D.dP[pl];
+      const float* L = D.dL[pl];
+      float* gP = G.density_plane[pl];
+      float* gL = G.density_line[pl];
+      float aix = 0.f, aiy = 0.f, ail = 0.f;
+      for (int cq = ch; cq < C; cq += 16) {
+        float a = P[t.o00 + cq], b = P[t.o10 + cq], c = P[t.o01 + cq], d = P[t.o11 + cq];
+        float u = L[l.c0 * C + cq], v = L[l.c1 * C + cq];
+        float pv = t.w00 * a + t.w10 * b + t.w01 * c + t.w11 * d;
+        float lv = l.w0 * u + l.w1 * v;
+        float gpv = g * lv, glv = g * pv;
+        if (on) {
+          if (t.w00 != 0.f) atomicAdd(gP + t.o00 + cq, t.w00 * gpv);
+          if (t.w10 != 0.f) atomicAdd(gP + t.o10 + cq, t.w10 * gpv);
+          if (t.w01 != 0.f) atomicAdd(gP + t.o01 + cq, t.w01 * gpv);
+          if (t.w11 != 0.f) atomicAdd(gP + t.o11 + cq, t.w11 * gpv);
+          if (l.w0 != 0.f) atomicAdd(gL + l.c0 * C + cq, l.w0 * glv);
+          if (l.w1 != 0.f) atomicAdd(gL + l.c1 * C + cq, l.w1 * glv);
+        }
+        // d pv / d ix, d pv / d iy with out-of-range taps treated as zeros (grid_sampler backward)
+        float a_ = a * t.ax.m0 * t.ay.m0, b_ = b * t.ax.m1 * t.ay.m0, c_ = c * t.ax.m0 * t.ay.m1,
+              d_ = d * t.ax.m1 * t.ay.m1;
+        float fy = t.ay.f, fx = t.ax.f;
+        aix += gpv * ((b_ - a_) * (1.f - fy) + (d_ - c_) * fy);
+        aiy += gpv * ((c_ - a_) * (1.f - fx) + (d_ - b_) * fx);
+        ail += glv * (v * l.m1 - u * l.m0);
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        aix += __shfl_xor(aix, o);
+        aiy += __shfl_xor(aiy, o);
+        ail += __shfl_xor(ail, o);
+      }
+      gn[kM0[pl]] += aix * t.ax.scale;
+      gn[kM1[pl]] += aiy * t.ay.scale;
+      gn[kV[pl]] += ail * l.scale;
+    }
+    if (on && ch == 0) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        float gx = gn[a] * D.inv[a];
+        go[a] += gx;
+        gd[a] += gx * z;
+      }
+    }
+  }
+  // ---- pass D: appearance coordinate gradients of this ray's shaded samples ----
+  const int n = offset[ray + 1] - off;
+  if (g_xyz_app) {
+    for (int k = lane; k < n; k += 64) {
+      int i = sidx[row + k];
+      float z = sample_z(D, r, zvals, i);
+      const float* gx = g_xyz_app + (size_t)(off + k) * 3;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        go[a] += gx[a];
+        gd[a] += gx[a] * z;
+      }
+    }
+  }
+  gnorm = wave_sum(gnorm);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    go[a] = wave_sum(go[a]);
+    gd[a] = wave_sum(gd[a]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float g = gd[a];
+      if (D.ndc && r.norm > 0.f) g += gnorm * r.d[a] / r.norm;
+      g_rays_o[ray * 3 + a] = go[a];
+      g_rays_d[ray * 3 + a] = g;
+    }
+  }
+}
+
+}  // namespace jt
+
+using namespace jt;
+
+extern "C" int jt_version(void) { return JT_VERSION; }
+
+static int check_density_shape(const Dev& D) {
+  if (D.Cd < 4 || (D.Cd % 4) != 0) return JT_ERR_UNSUPPORTED;
+  return JT_OK;
+}
+
+extern "C" int jt_march_forward(const JtScene* scene, const JtFactors* factors, const float* rays_o,
+                                const float* rays_d, const float* jitter, const float* zvals, int n_rays,
+                                float* sigma_feat, float* weight, float* tmin, int32_t* shade_count,
+                                int32_t* shade_offset, uint16_t* shade_idx, float* opacity, float* depth,
+                                void* stream) {
+  Dev D;
+  int rc = make_dev(scene, factors, &D);
+  if (rc) return rc;
+  if (!factors || !rays_o || !rays_d || !sigma_feat || !weight || !tmin || !shade_count || !shade_offset ||
+      !shade_idx || !opacity || !depth || n_rays < 1)
+    return JT_ERR_ARG;
+  if (D.ndc && !zvals) return JT_ERR_ARG;
+  if ((rc = check_density_shape(D))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_march_fwd, dim3((n_rays + 3) / 4), dim3(256), 0, st, D, rays_o, rays_d, jitter, zvals,
+                     n_rays, sigma_feat, weight, tmin, shade_count, shade_idx, opacity, depth);
+  JT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, shade_count, shade_offset, n_rays);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
+extern "C" int jt_shade_list(const JtScene* scene, const float* rays_d, int n_rays, const int32_t* shade_offset,
+                             const uint16_t* shade_idx, int32_t* entry_ray, int32_t* entry_smp, float* viewdirs,
+                             int n_entries_max, void* stream) {
+  Dev D;
+  int rc = make_dev(scene, nullptr, &D);
+  if (rc) return rc;
+  if (!rays_d || !shade_offset || !shade_idx || !entry_ray || !entry_smp || !viewdirs || n_rays < 1)
+    return JT_ERR_ARG;
+  if (n_entries_max < 1) return JT_OK;
+  hipLaunchKernelGGL(k_shade_list, dim3((n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, D, rays_d, n_rays,
+                     shade_offset, shade_idx, entry_ray, entry_smp, viewdirs, n_entries_max);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
+extern "C" int jt_composite_forward(const JtScene* scene, int n_rays, const int32_t* shade_offset,
+                                    const uint16_t* shade_idx, const float* weight, const float* rgb_s,
+                                    const float* opacity, float* rgb, int32_t* clamp_mask, void* stream) {
+  Dev D;
+  int rc = make_dev(scene, nullptr, &D);
+  if (rc) return rc;
+  if (!shade_offset || !shade_idx || !weight || !opacity || !rgb || !clamp_mask || n_rays < 1) return JT_ERR_ARG;
+  hipLaunchKernelGGL(k_composite_fwd, dim3((n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, D, n_rays,
+                     shade_offset, shade_idx, weight, rgb_s, opacity, rgb, clamp_mask);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
+extern "C" int jt_composite_backward(const JtScene* scene, int n_rays, const int32_t* shade_offset,
+                                     const int32_t* entry_ray, const int32_t* entry_smp, const float* weight,
+                                     const int32_t* clamp_mask, const float* g_rgb, float* g_rgb_s,
+                                     int n_entries_max, void* stream) {
+  Dev D;
+  int rc = make_dev(scene, nullptr, &D);
+  if (rc) return rc;
+  if (!shade_offset || !entry_ray || !entry_smp || !weight || !clamp_mask || !g_rgb || !g_rgb_s)
+    return JT_ERR_ARG;
+  if (n_entries_max < 1) return JT_OK;
+  int blocks = min((n_entries_max + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_composite_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, D, shade_offset, n_rays,
+                     entry_ray, entry_smp, weight, clamp_mask, g_rgb, g_rgb_s, n_entries_max);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
+extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors, const float* rays_o,
+                                 const float* rays_d, const float* jitter, const float* zvals, int n_rays,
+                                 const float* sigma_feat, const float* weight, const float* tmin,
+                                 const int32_t* shade_offset, const uint16_t* shade_idx, const float* rgb_s,
+                                 const int32_t* clamp_mask, const float* g_rgb, const float* g_opacity,
+                                 const float* g_xyz_app, const JtFactors* g_factors, float* g_rays_o,
+                                 float* g_rays_d, void* stream) {
+  Dev D;
+  int rc = make_dev(scene, factors, &D);
+  if (rc) return rc;
+  if (!factors || !g_factors || !rays_o || !rays_d || !sigma_feat || !weight || !tmin || !shade_offset ||
+      !shade_idx || !clamp_mask || !g_rgb || !g_rays_o || !g_rays_d || n_rays < 1)
+    return JT_ERR_ARG;
+  for (int a = 0; a < 3; ++a)
+    if (!g_factors->density_plane[a] || !g_factors->density_line[a]) return JT_ERR_ARG;
+  if (D.ndc && !zvals) return JT_ERR_ARG;
+  if ((rc = check_density_shape(D))) return rc;
+  const int Spad = (D.S + 63) & ~63;
+  const size_t lds = (size_t)4 * 3 * Spad * sizeof(float) + (size_t)4 * Spad * sizeof(uint16_t);
+  if (lds > 160 * 1024) return JT_ERR_UNSUPPORTED;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)lds);
+  hipLaunchKernelGGL(k_march_bwd, dim3((n_rays + 3) / 4), dim3(256), lds, (hipStream_t)stream, D, *g_factors,
+                     rays_o, rays_d, jitter, zvals, n_rays, sigma_feat, weight, tmin, shade_offset, shade_idx,
+                     rgb_s, clamp_mask, g_rgb, g_opacity, g_xyz_app, g_rays_o, g_rays_d, Spad);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}

@@ -1,0 +1,403 @@
+"""torch.autograd bridges over the C ABI (include/jt_render.h).
+
+PyTorch is plumbing here: it owns device memory, the stream and the autograd tape; every number on
+the hot path is produced by the HIP kernels behind `_lib.lib`.  Tensors cross the boundary as raw
+device pointers.  VM factors cross CHANNEL-LAST ([H][W][C]); `factor_storage` returns that view of
+a logical [1,C,H,W] parameter without a copy when the parameter already lives channel-last
+(which is how joint_tensorf_amd.tensorf_repr allocates them).
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import JtFactors, JtMlp, JtScene, check, lib, ptr
+
+MAT_MODE = ((0, 1), (0, 2), (1, 2))
+VEC_MODE = (2, 1, 0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def factor_storage(p):
+    """logical [1,C,H,W] -> contiguous [H,W,C] tensor (no copy if p is stored channel-last)."""
+    x = p.detach()[0].permute(1, 2, 0)
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def factor_logical(x):
+    """[H,W,C] storage -> logical [1,C,H,W] view."""
+    return x.permute(2, 0, 1)[None]
+
+
+def new_factor(C, H, W, device, dtype=torch.float32):
+    """zero tensor of logical shape [1,C,H,W] stored channel-last."""
+    return factor_logical(torch.zeros(H, W, C, device=device, dtype=dtype))
+
+
+class RenderCfg:
+    """Per-call description of the scene (mirrors JtScene)."""
+
+    def __init__(self, aabb, plane_hw, line_len, n_comp_density, n_comp_app, step_size, near_far,
+                 distance_scale, density_shift, density_act, weight_thres, n_samples, ndc, white_bg,
+                 app_dim, mlp_kind, mlp_hidden, view_pe, fea_pe, view_pe_progress=1.0, fea_pe_progress=1.0,
+                 shade_impl="mfma"):
+        self.aabb = [float(v) for v in aabb]  # lo xyz, hi xyz
+        self.plane_hw = [(int(h), int(w)) for h, w in plane_hw]
+        self.line_len = [int(v) for v in line_len]
+        self.n_comp_density = int(n_comp_density)
+        self.n_comp_app = int(n_comp_app)
+        self.step_size = float(step_size)
+        self.near_far = (float(near_far[0]), float(near_far[1]))
+        self.distance_scale = float(distance_scale)
+        self.density_shift = float(density_shift)
+        self.density_act = int(density_act)
+        self.weight_thres = float(weight_thres)
+        self.n_samples = int(n_samples)
+        self.ndc = int(bool(ndc))
+        self.white_bg = int(bool(white_bg))
+        self.app_dim = int(app_dim)
+        self.mlp_kind = int(mlp_kind)
+        self.mlp_hidden = int(mlp_hidden)
+        self.view_pe = int(view_pe)
+        self.fea_pe = int(fea_pe)
+        self.view_pe_progress = float(view_pe_progress)
+        self.fea_pe_progress = float(fea_pe_progress)
+        self.shade_impl = shade_impl
+
+    def scene(self):
+        s = JtScene()
+        for a in range(3):
+            s.aabb_lo[a] = self.aabb[a]
+            s.aabb_hi[a] = self.aabb[3 + a]
+            s.plane_h[a], s.plane_w[a] = self.plane_hw[a]
+            s.line_len[a] = self.line_len[a]
+        s.n_comp_density = self.n_comp_density
+        s.n_comp_app = self.n_comp_app
+        s.step_size = self.step_size
+        s.near_plane, s.far_plane = self.near_far
+        s.distance_scale = self.distance_scale
+        s.density_shift = self.density_shift
+        s.density_act = self.density_act
+        s.weight_thres = self.weight_thres
+        s.n_samples = self.n_samples
+        s.ndc = self.ndc
+        s.white_bg = self.white_bg
+        s.app_dim = self.app_dim
+        s.mlp_kind = self.mlp_kind
+        s.mlp_hidden = self.mlp_hidden
+        s.view_pe = self.view_pe
+        s.fea_pe = self.fea_pe
+        s.view_pe_progress = self.view_pe_progress
+        s.fea_pe_progress = self.fea_pe_progress
+        return s
+
+
+def _factors_struct(dp, dl, ap, al):
+    f = JtFactors()
+    for i in range(3):
+        f.density_plane[i] = ptr(dp[i]) if dp is not None else None
+        f.density_line[i] = ptr(dl[i]) if dl is not None else None
+        f.app_plane[i] = ptr(ap[i]) if ap is not None else None
+        f.app_line[i] = ptr(al[i]) if al is not None else None
+    return f
+
+
+def _mlp_struct(basis, w1, b1, w2, b2, w3, b3):
+    m = JtMlp()
+    m.basis, m.w1, m.b1, m.w2, m.b2, m.w3, m.b3 = (ptr(t) for t in (basis, w1, b1, w2, b2, w3, b3))
+    return m
+
+
+# ----------------------------------------------------------------------------------------------
+# MLP in stock torch ops -- only used by shade_impl="torch" (staged cross-check path)
+# ----------------------------------------------------------------------------------------------
+def _pe(x, freqs, progress):
+    levels = torch.arange(freqs, device=x.device)
+    bands = (2 ** levels).to(x.dtype)
+    mask = (progress * freqs - levels).clamp(0.0, 1.0).to(x.dtype)
+    pts = x[..., None] * bands
+    pts = torch.cat([torch.sin(pts) * mask, torch.cos(pts) * mask], -1)
+    return pts.reshape(x.shape[:-1] + (freqs * 2 * x.shape[-1],))
+
+
+def _torch_shade(cfg, prod, vdir, basis, w1, b1, w2, b2, w3, b3):
+    feat = prod @ basis.t()
+    F = torch.nn.functional
+    if cfg.mlp_kind == _lib.JT_MLP_WEAKVIEW:
+        x = torch.cat([feat, _pe(feat, cfg.fea_pe, cfg.fea_pe_progress)], -1) if cfg.fea_pe > 0 else feat
+        h = F.relu(F.linear(x, w1, b1))
+        h = F.relu(F.linear(h, w2, b2))
+        mid = torch.cat([_pe(vdir, cfg.view_pe, cfg.view_pe_progress), h], -1) if cfg.view_pe > 0 else h
+        return torch.sigmoid(F.linear(mid, w3, b3))
+    x = [feat, vdir]
+    if cfg.fea_pe > 0:
+        x.append(_pe(feat, cfg.fea_pe, cfg.fea_pe_progress))
+    if cfg.view_pe > 0:
+        x.append(_pe(vdir, cfg.view_pe, cfg.view_pe_progress))
+    h = F.relu(F.linear(torch.cat(x, -1), w1, b1))
+    h = F.relu(F.linear(h, w2, b2))
+    return torch.sigmoid(F.linear(h, w3, b3))
+
+
+# ----------------------------------------------------------------------------------------------
+# the renderer
+# ----------------------------------------------------------------------------------------------
+class RenderRays(torch.autograd.Function):
+    """(rays, VM factors, basis, MLP) -> rgb [R,3], depth [R], opacity [R].
+
+    Drop-in for the tensor program of BatBase.forward (model/tensorf_repr/batBase.py:44-165)."""
+
+    @staticmethod
+    def forward(ctx, cfg, rays_o, rays_d, jitter, zvals, *params):
+        dp, dl, ap, al = params[0:3], params[3:6], params[6:9], params[9:12]
+        basis, w1, b1, w2, b2, w3, b3 = params[12:19]
+        dev = rays_o.device
+        assert dev.type == "cuda", "joint_tensorf_amd renders on the GPU only (no CPU fallback)"
+        R, S = rays_o.shape[0], cfg.n_samples
+        rays_o = rays_o.detach().contiguous().float()
+        rays_d = rays_d.detach().contiguous().float()
+        jitter = None if jitter is None else jitter.detach().contiguous().float().view(-1)
+        zvals = None if zvals is None else zvals.detach().contiguous().float().view(-1)
+        sdp = [factor_storage(p) for p in dp]
+        sdl = [factor_storage(p) for p in dl]
+        sap = [factor_storage(p) for p in ap]
+        sal = [factor_storage(p) for p in al]
+        mlp_t = [t.detach().contiguous() for t in (basis, w1, b1, w2, b2, w3, b3)]
+        scene = cfg.scene()
+        fac = _factors_struct(sdp, sdl, sap, sal)
+        st = _stream()
+
+        f32 = dict(device=dev, dtype=torch.float32)
+        sigma_feat = torch.empty(R, S, **f32)
+        weight = torch.empty(R, S, **f32)
+        tmin = torch.empty(R, **f32)
+        count = torch.empty(R, device=dev, dtype=torch.int32)
+        offset = torch.empty(R + 1, device=dev, dtype=torch.int32)
+        sidx = torch.empty(R, S, device=dev, dtype=torch.int16)
+        opacity = torch.empty(R, **f32)
+        depth = torch.empty(R, **f32)
+        check(lib.jt_march_forward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals), R,
+                                   ptr(sigma_feat), ptr(weight), ptr(tmin), ptr(count), ptr(offset), ptr(sidx),
+                                   ptr(opacity), ptr(depth), st), "jt_march_forward")
+        if cfg.shade_impl == "torch":
+            n = int(offset[R].item())  # host sync: staged cross-check path only
+            cap = n
+        else:
+            n = cap = R * S  # worst case; kernels bound themselves by shade_offset[R] on the device
+        cap_alloc = max(cap, 1)
+        eray = torch.empty(cap_alloc, device=dev, dtype=torch.int32)
+        esmp = torch.empty(cap_alloc, device=dev, dtype=torch.int32)
+        vdir = torch.empty(cap_alloc, 3, **f32)
+        check(lib.jt_shade_list(scene, ptr(rays_d), R, ptr(offset), ptr(sidx), ptr(eray), ptr(esmp), ptr(vdir),
+                                cap, st), "jt_shade_list")
+        rgb_s = torch.empty(cap_alloc, 3, **f32)
+        ws = None
+        if cfg.shade_impl == "torch":
+            prod = torch.empty(cap_alloc, 3 * cfg.n_comp_app, **f32)
+            check(lib.jt_app_gather_forward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
+                                            ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(prod), cap, st),
+                  "jt_app_gather_forward")
+            if n > 0:
+                with torch.no_grad():
+                    rgb_s[:n] = _torch_shade(cfg, prod[:n], vdir[:n], *mlp_t)
+            ctx.prod = prod
+        else:
+            nbytes = lib.jt_shade_workspace_bytes(scene)
+            ws = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8)
+            mlp = _mlp_struct(*mlp_t)
+            check(lib.jt_shade_forward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
+                                       ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(rgb_s),
+                                       cap, ptr(ws), nbytes, st), "jt_shade_forward")
+        rgb = torch.empty(R, 3, **f32)
+        cmask = torch.empty(R, device=dev, dtype=torch.int32)
+        check(lib.jt_composite_forward(scene, R, ptr(offset), ptr(sidx), ptr(weight), ptr(rgb_s), ptr(opacity),
+                                       ptr(rgb), ptr(cmask), st), "jt_composite_forward")
+        ctx.cfg, ctx.n, ctx.cap = cfg, n, cap
+        ctx.ws = ws
+        ctx.saved = (rays_o, rays_d, jitter, zvals, sdp, sdl, sap, sal, mlp_t, sigma_feat, weight, tmin, offset,
+                     sidx, eray, esmp, vdir, rgb_s, cmask)
+        ctx.param_shapes = [tuple(p.shape) for p in params]
+        ctx.mark_non_differentiable(depth)
+        ctx.stats = dict(offset=offset)
+        return rgb, depth, opacity
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_opacity):
+        cfg = ctx.cfg
+        (rays_o, rays_d, jitter, zvals, sdp, sdl, sap, sal, mlp_t, sigma_feat, weight, tmin, offset, sidx, eray,
+         esmp, vdir, rgb_s, cmask) = ctx.saved
+        dev = rays_o.device
+        R = rays_o.shape[0]
+        scene = cfg.scene()
+        fac = _factors_struct(sdp, sdl, sap, sal)
+        st = _stream()
+        f32 = dict(device=dev, dtype=torch.float32)
+        g_rgb = g_rgb.contiguous().float()
+        g_op = None if g_opacity is None else g_opacity.contiguous().float()
+        cap, n = ctx.cap, ctx.n
+        cap_alloc = max(cap, 1)
+        g_rgb_s = torch.empty(cap_alloc, 3, **f32)
+        check(lib.jt_composite_backward(scene, R, ptr(offset), ptr(eray), ptr(esmp), ptr(weight), ptr(cmask),
+                                        ptr(g_rgb), ptr(g_rgb_s), cap, st), "jt_composite_backward")
+        # gradient buffers (channel-last storage, zero-initialised: the kernels accumulate with atomics)
+        gdp = [torch.zeros_like(t) for t in sdp]
+        gdl = [torch.zeros_like(t) for t in sdl]
+        gap = [torch.zeros_like(t) for t in sap]
+        gal = [torch.zeros_like(t) for t in sal]
+        gfac = _factors_struct(gdp, gdl, gap, gal)
+        g_xyz = torch.empty(cap_alloc, 3, **f32)
+        if cfg.shade_impl == "torch":
+            g_mlp = [torch.zeros_like(t) for t in mlp_t]
+            if n > 0:
+                prod = ctx.prod[:n].detach().requires_grad_(True)
+                leaves = [t.detach().requires_grad_(True) for t in mlp_t]
+                with torch.enable_grad():
+                    out = _torch_shade(cfg, prod, vdir[:n], *leaves)
+                grads = torch.autograd.grad(out, [prod] + leaves, g_rgb_s[:n])
+                g_prod = grads[0].contiguous()
+                g_mlp = list(grads[1:])
+            else:
+                g_prod = torch.zeros(1, 3 * cfg.n_comp_app, **f32)
+            check(lib.jt_app_gather_backward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
+                                             ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(g_prod), gfac,
+                                             ptr(g_xyz), cap, st), "jt_app_gather_backward")
+        else:
+            g_mlp = [torch.zeros_like(t) for t in mlp_t]
+            mlp = _mlp_struct(*mlp_t)
+            gm = _mlp_struct(*g_mlp)
+            nbytes = ctx.ws.numel()
+            check(lib.jt_shade_backward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
+                                        ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(g_rgb_s),
+                                        gfac, gm, ptr(g_xyz), cap, ptr(ctx.ws), nbytes, st), "jt_shade_backward")
+        g_o = torch.empty(R, 3, **f32)
+        g_d = torch.empty(R, 3, **f32)
+        check(lib.jt_march_backward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals), R,
+                                    ptr(sigma_feat), ptr(weight), ptr(tmin), ptr(offset), ptr(sidx), ptr(rgb_s),
+                                    ptr(cmask), ptr(g_rgb), ptr(g_op), ptr(g_xyz), gfac, ptr(g_o), ptr(g_d), st),
+              "jt_march_backward")
+        g_factors = [factor_logical(t) for t in gdp + gdl + gap + gal]
+        out = [None, g_o, g_d, None, None] + g_factors + list(g_mlp)
+        return tuple(out)
+
+
+def render_rays(cfg, rays_o, rays_d, jitter, zvals, density_plane, density_line, app_plane, app_line, basis,
+                mlp_params):
+    """mlp_params = (w1, b1, w2, b2, w3, b3)."""
+    return RenderRays.apply(cfg, rays_o, rays_d, jitter, zvals, *density_plane, *density_line, *app_plane,
+                            *app_line, basis, *mlp_params)
+
+
+# ----------------------------------------------------------------------------------------------
+# separable blur of a factor
+# ----------------------------------------------------------------------------------------------
+class BlurFactor(torch.autograd.Function):
+    """Replicate-padded separable blur of a logical [1,C,H,W] factor (plane, or line with W == 1).
+
+    Replaces BAT_VMSplit.convolute_plane / convolute_line (bateRF.py:8-39) for cubic planes."""
+
+    @staticmethod
+    def forward(ctx, x, taps):
+        xs = factor_storage(x)
+        H, W, C = xs.shape
+        taps = taps.detach().contiguous().float()
+        out = torch.empty_like(xs)
+        tmp = torch.empty_like(xs) if (H > 1 and W > 1) else None
+        check(lib.jt_blur_forward(ptr(xs), ptr(out), ptr(tmp), H, W, C, ptr(taps), taps.numel(), _stream()),
+              "jt_blur_forward")
+        ctx.save_for_backward(taps)
+        return factor_logical(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        (taps,) = ctx.saved_tensors
+        gs = factor_storage(g)
+        H, W, C = gs.shape
+        gin = torch.empty_like(gs)
+        tmp = torch.empty_like(gs) if (H > 1 and W > 1) else None
+        check(lib.jt_blur_backward(ptr(gs), ptr(gin), ptr(tmp), H, W, C, ptr(taps), taps.numel(), _stream()),
+              "jt_blur_backward")
+        return factor_logical(gin), None
+
+
+def blur_factor(x, taps):
+    return BlurFactor.apply(x, taps)
+
+
+# ----------------------------------------------------------------------------------------------
+# camera
+# ----------------------------------------------------------------------------------------------
+class TrainPose(torch.autograd.Function):
+    """pose = exp(se3) o noise o gt   (model/bat.py:341-353, camera.py:81-99)."""
+
+    @staticmethod
+    def forward(ctx, se3, noise, gt):
+        se3c = se3.detach().contiguous().float()
+        B = se3c.shape[0]
+        noise_c = None if noise is None else noise.detach().contiguous().float()
+        gt_c = gt.detach().contiguous().float()
+        stride = 12 if gt_c.dim() == 3 else 0
+        pose = torch.empty(B, 3, 4, device=se3c.device, dtype=torch.float32)
+        check(lib.jt_pose_forward(ptr(se3c), ptr(noise_c), ptr(gt_c), stride, B, ptr(pose), _stream()),
+              "jt_pose_forward")
+        ctx.saved = (se3c, noise_c, gt_c, stride)
+        return pose
+
+    @staticmethod
+    def backward(ctx, g_pose):
+        se3c, noise_c, gt_c, stride = ctx.saved
+        B = se3c.shape[0]
+        g = g_pose.contiguous().float()
+        g_se3 = torch.empty_like(se3c)
+        check(lib.jt_pose_backward(ptr(se3c), ptr(noise_c), ptr(gt_c), stride, B, ptr(g), ptr(g_se3), _stream()),
+              "jt_pose_backward")
+        return g_se3, None, None
+
+
+def train_pose(se3, noise, gt):
+    return TrainPose.apply(se3, noise, gt)
+
+
+class RayGen(torch.autograd.Function):
+    """rays for the sampled pixel lattice only (camera.py:231-261 + 303-340)."""
+
+    @staticmethod
+    def forward(ctx, pose, intr_inv, intr, ray_idx, image_w, ndc, ndc_near):
+        pose_c = pose.detach().contiguous().float()
+        B = pose_c.shape[0]
+        ki = intr_inv.detach().contiguous().float()
+        k = None if intr is None else intr.detach().contiguous().float()
+        idx = ray_idx.detach().contiguous().to(torch.int64)
+        r = idx.numel()
+        o = torch.empty(B, r, 3, device=pose_c.device, dtype=torch.float32)
+        d = torch.empty_like(o)
+        check(lib.jt_raygen_forward(ptr(pose_c), ptr(ki), ptr(k), ptr(idx), B, r, int(image_w), int(bool(ndc)),
+                                    float(ndc_near), ptr(o), ptr(d), _stream()), "jt_raygen_forward")
+        ctx.saved = (pose_c, ki, k, idx, int(image_w), int(bool(ndc)), float(ndc_near))
+        return o, d
+
+    @staticmethod
+    def backward(ctx, g_o, g_d):
+        pose_c, ki, k, idx, W, ndc, near = ctx.saved
+        B, r = pose_c.shape[0], idx.numel()
+        g_o = g_o.contiguous().float()
+        g_d = g_d.contiguous().float()
+        g_pose = torch.empty(B, 3, 4, device=pose_c.device, dtype=torch.float32)
+        check(lib.jt_raygen_backward(ptr(pose_c), ptr(ki), ptr(k), ptr(idx), B, r, W, ndc, near, ptr(g_o),
+                                     ptr(g_d), ptr(g_pose), _stream()), "jt_raygen_backward")
+        return g_pose, None, None, None, None, None, None
+
+
+def ray_gen(pose, intr_inv, intr, ray_idx, image_w, ndc=False, ndc_near=1.0):
+    return RayGen.apply(pose, intr_inv, intr, ray_idx, image_w, ndc, ndc_near)
+
+
+def gaussian_taps(sigma_vox, kernel_size, device):
+    """kernels.get_gaussian_kernel (kernels.py:16-22): un-normalised taps clamped at 1, K even -> K+1 taps."""
+    s = max(float(sigma_vox), 0.0001)
+    ns = torch.arange(-(kernel_size // 2), kernel_size // 2 + 1, dtype=torch.float32)
+    k = 1 / (s * math.sqrt(2 * math.pi)) * torch.exp(-0.5 * (ns / s) * (ns / s))
+    return torch.clamp(k, max=1.0).to(device)

@@ -1,0 +1,359 @@
+"""Drop-in scene representation: `BAT_VMSplit` with the reference's constructor / forward signature
+(model/tensorf.py:375-397 constructs it, model/tensorf.py:246-261 calls it) and the same
+state_dict key names, rendered by the HIP kernels behind include/jt_render.h.
+
+What stays host-side torch here is orchestration the reference also does on the host (kernel taps
+from a schedule scalar, regularisers over the parameters, grid upsampling); everything per-ray /
+per-sample runs in joint_tensorf_amd/csrc.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib, ops
+
+MAT_MODE = ops.MAT_MODE
+VEC_MODE = ops.VEC_MODE
+
+
+def _channel_last_param(t):
+    """logical [1,C,H,W] values -> Parameter with the same logical shape stored [H][W][C]."""
+    store = t.detach().permute(0, 2, 3, 1).contiguous()
+    return torch.nn.Parameter(store.permute(0, 3, 1, 2))
+
+
+class _RenderMLP(torch.nn.Module):
+    """Parameter container with the reference's key names (`mlp.0/2/4.*`, tensorBase.py:101-114).
+    The arithmetic of MLPRender_Fea.forward runs in the fused shade kernel."""
+
+    kind = _lib.JT_MLP_FEA
+
+    def __init__(self, inChanel, viewpe, feape, featureC):
+        super().__init__()
+        self.in_mlpC = 2 * viewpe * 3 + 2 * feape * inChanel + 3 + inChanel
+        self.viewpe, self.feape = viewpe, feape
+        l1 = torch.nn.Linear(self.in_mlpC, featureC)
+        l2 = torch.nn.Linear(featureC, featureC)
+        l3 = torch.nn.Linear(featureC, 3)
+        self.mlp = torch.nn.Sequential(l1, torch.nn.ReLU(inplace=True), l2, torch.nn.ReLU(inplace=True), l3)
+        torch.nn.init.constant_(self.mlp[-1].bias, 0)
+
+    def weights(self):
+        m = self.mlp
+        return (m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias)
+
+
+class _RenderMLPWeakView(torch.nn.Module):
+    """`layer1/2/3.*` container of MLPRender_Fea_WeakView (tensorBase.py:180-196)."""
+
+    kind = _lib.JT_MLP_WEAKVIEW
+
+    def __init__(self, inChanel, viewpe, feape, featureC):
+        super().__init__()
+        self.in_mlpC = (2 * feape + 1) * inChanel
+        self.mid_mlpC = 2 * viewpe * 3
+        self.viewpe, self.feape = viewpe, feape
+        self.layer1 = torch.nn.Linear(self.in_mlpC, featureC)
+        self.layer2 = torch.nn.Linear(featureC, featureC)
+        self.layer3 = torch.nn.Linear(featureC + self.mid_mlpC, 3)
+        torch.nn.init.constant_(self.layer3.bias, 0)
+
+    def weights(self):
+        return (self.layer1.weight, self.layer1.bias, self.layer2.weight, self.layer2.bias, self.layer3.weight,
+                self.layer3.bias)
+
+
+class TVLoss(torch.nn.Module):
+    """tensorBase.py:16-41 (regulariser over the parameters, host-level torch)."""
+
+    def __init__(self, TVLoss_weight=1):
+        super().__init__()
+        self.TVLoss_weight = TVLoss_weight
+
+    def forward(self, x):
+        b, c, h, w = x.shape
+        count_h, count_w = c * (h - 1) * w, c * h * (w - 1)
+        total = 0
+        if count_h > 0:
+            total = total + torch.pow(x[:, :, 1:, :] - x[:, :, :h - 1, :], 2).sum() / count_h
+        if count_w > 0:
+            total = total + torch.pow(x[:, :, :, 1:] - x[:, :, :, :w - 1], 2).sum() / count_w
+        return self.TVLoss_weight * 2 * total / b
+
+
+class BAT_VMSplit(torch.nn.Module):
+    """TensoRF vector-matrix scene with coarse-to-fine blurred factors, rendered by HIP kernels."""
+
+    def __init__(self, aabb, gridSize, device, density_n_comp=8, appearance_n_comp=24, app_dim=27,
+                 shadingMode="MLP_Fea", alphaMask=None, near_far=(2.0, 6.0), density_shift=-10,
+                 alphaMask_thres=0.001, distance_scale=25, rayMarch_weight_thres=0.0001, pos_pe=6, view_pe=6,
+                 fea_pe=6, featureC=128, step_ratio=2.0, fea2denseAct="softplus", dtype=torch.float32,
+                 volume_init_scale=0.1, volume_init_bias=0.1, shade_impl="mfma"):
+        super().__init__()
+        if dtype != torch.float32:
+            raise NotImplementedError("the HIP path computes in fp32 (the reference yamls never set half_tensor)")
+        self.device = device
+        self.dtype = dtype
+        self.alphaMask = alphaMask
+        self.matMode = [list(m) for m in MAT_MODE]
+        self.vecMode = list(VEC_MODE)
+        self.shade_impl = shade_impl
+        self.kernel_density = None
+        self.kernel_color = None
+        self.c2f_mode = None
+        # test hooks: inject the random draws the reference takes from torch's generators
+        self.jitter_override = None
+        self.coin_override = None
+        self.reset(aabb, gridSize, density_n_comp, appearance_n_comp, app_dim, density_shift, alphaMask_thres,
+                   distance_scale, rayMarch_weight_thres, fea2denseAct, near_far, step_ratio, shadingMode, pos_pe,
+                   view_pe, fea_pe, featureC, volume_init_scale, volume_init_bias)
+
+    # ---- construction (tensorBase.py:430-488, tensoRF.py:150-169) --------------------------------
+    def reset(self, aabb, gridSize, density_n_comp, appearance_n_comp, app_dim, density_shift, alphaMask_thres,
+              distance_scale, rayMarch_weight_thres, fea2denseAct, near_far, step_ratio, shadingMode, pos_pe,
+              view_pe, fea_pe, featureC, volume_init_scale, volume_init_bias):
+        self.density_n_comp = [int(c) for c in density_n_comp]
+        self.app_n_comp = [int(c) for c in appearance_n_comp]
+        self.app_dim = app_dim
+        self.aabb = torch.as_tensor(aabb, dtype=torch.float32).view(2, 3).cpu()
+        self.density_shift = density_shift
+        self.alphaMask_thres = alphaMask_thres
+        self.distance_scale = distance_scale
+        self.rayMarch_weight_thres = rayMarch_weight_thres
+        self.fea2denseAct = fea2denseAct
+        self.near_far = near_far  # same list object as opt.nerf.depth.range (model/tensorf.py:382)
+        self.step_ratio = step_ratio
+        self.update_stepSize(gridSize)
+        self.volume_init_scale = volume_init_scale
+        self.volume_init_bias = volume_init_bias
+        self.init_svd_volume(gridSize[0], self.device, init_scale=volume_init_scale, init_bias=volume_init_bias)
+        self.shadingMode, self.pos_pe, self.view_pe, self.fea_pe, self.featureC = shadingMode, pos_pe, view_pe, fea_pe, featureC
+        self.init_render_func(shadingMode, pos_pe, view_pe, fea_pe, featureC, self.device)
+
+    def init_render_func(self, shadingMode, pos_pe, view_pe, fea_pe, featureC, device):
+        if shadingMode == "MLP_Fea":
+            self.renderModule = _RenderMLP(self.app_dim, view_pe, fea_pe, featureC).to(device)
+        elif shadingMode == "MLP_Fea_WeakView":
+            self.renderModule = _RenderMLPWeakView(self.app_dim, view_pe, fea_pe, featureC).to(device)
+        else:
+            raise NotImplementedError("shadingMode %r is not used by the BAT configs (SURVEY.md §2 row 3)" % shadingMode)
+
+    def update_stepSize(self, gridSize):
+        g = [int(v) for v in gridSize]
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invaabbSize = 2.0 / self.aabbSize
+        self.gridSize = torch.LongTensor(g)
+        self.units = self.aabbSize / (self.gridSize - 1)
+        self.stepSize = torch.mean(self.units) * self.step_ratio
+        self.aabbDiag = torch.sqrt(torch.sum(torch.square(self.aabbSize)))
+        self.nSamples = int((self.aabbDiag / self.stepSize).item()) + 1
+
+    def init_svd_volume(self, res, device, init_density=True, init_app=True, init_basis=True, init_scale=0.1,
+                        init_bias=0.1):
+        if init_density:
+            self.density_plane, self.density_line = self.init_one_svd(self.density_n_comp, self.gridSize, init_scale,
+                                                                     init_bias, device)
+        if init_app:
+            self.app_plane, self.app_line = self.init_one_svd(self.app_n_comp, self.gridSize, init_scale, init_bias,
+                                                             device)
+        if init_basis:
+            self.basis_mat = torch.nn.Linear(sum(self.app_n_comp), self.app_dim, bias=False).to(device)
+
+    def init_one_svd(self, n_component, gridSize, scale, bias, device):
+        g = [int(v) for v in gridSize]
+        planes, lines = [], []
+        for i in range(3):
+            m0, m1 = MAT_MODE[i]
+            # same draw order / shapes as tensoRF.py:159-169 (generated on the CPU generator, then moved)
+            p = torch.abs(bias + scale * torch.randn((1, n_component[i], g[m1], g[m0]), dtype=torch.float32))
+            l = torch.abs(bias + scale * torch.randn((1, n_component[i], g[VEC_MODE[i]], 1), dtype=torch.float32))
+            planes.append(_channel_last_param(p.to(device)))
+            lines.append(_channel_last_param(l.to(device)))
+        return torch.nn.ParameterList(planes), torch.nn.ParameterList(lines)
+
+    # ---- optimisation helpers (tensoRF.py:170-228) ------------------------------------------------
+    def freeze_scene(self, opt=None):
+        self.basis_mat.weight.requires_grad = False
+        self.renderModule.requires_grad_(False)
+        for i in range(3):
+            for lst in (self.density_plane, self.density_line, self.app_plane, self.app_line):
+                lst[i].requires_grad = False
+
+    def unfreeze_scene(self, opt=None):
+        self.basis_mat.weight.requires_grad = True
+        self.renderModule.requires_grad_(True)
+        for i in range(3):
+            for lst in (self.density_plane, self.density_line, self.app_plane, self.app_line):
+                lst[i].requires_grad = True
+
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):
+        return [{"params": self.density_line, "lr": lr_init_spatialxyz},
+                {"params": self.density_plane, "lr": lr_init_spatialxyz},
+                {"params": self.app_line, "lr": lr_init_spatialxyz},
+                {"params": self.app_plane, "lr": lr_init_spatialxyz},
+                {"params": self.basis_mat.parameters(), "lr": lr_init_network},
+                {"params": self.renderModule.parameters(), "lr": lr_init_network}]
+
+    def density_L1(self):
+        total = 0
+        for i in range(3):
+            total = total + torch.mean(torch.abs(self.density_plane[i])) + torch.mean(torch.abs(self.density_line[i]))
+        return total
+
+    def TV_loss_density(self, reg):
+        total = 0
+        for i in range(3):
+            total = total + reg(self.density_plane[i]) * 1e-2
+        return total
+
+    def TV_loss_app(self, reg):
+        total = 0
+        for i in range(3):
+            total = total + reg(self.app_plane[i]) * 1e-2
+        return total
+
+    # ---- resolution changes (tensoRF.py:274-295) --------------------------------------------------
+    @torch.no_grad()
+    def up_sampling_VM(self, plane_coef, line_coef, res_target):
+        for i in range(3):
+            m0, m1 = MAT_MODE[i]
+            p = F.interpolate(plane_coef[i].data.contiguous(), size=(res_target[m1], res_target[m0]), mode="bilinear",
+                              align_corners=True)
+            l = F.interpolate(line_coef[i].data.contiguous(), size=(res_target[VEC_MODE[i]], 1), mode="bilinear",
+                              align_corners=True)
+            plane_coef[i] = _channel_last_param(p)
+            line_coef[i] = _channel_last_param(l)
+        return plane_coef, line_coef
+
+    @torch.no_grad()
+    def upsample_volume_grid(self, res_target):
+        self.app_plane, self.app_line = self.up_sampling_VM(self.app_plane, self.app_line, res_target)
+        self.density_plane, self.density_line = self.up_sampling_VM(self.density_plane, self.density_line, res_target)
+        self.update_stepSize(res_target)
+
+    def updateAlphaMask(self, gridSize=(200, 200, 200)):
+        raise NotImplementedError("alpha-mask volume is SURVEY.md §8(f) N4 (never active in the BAT yamls)")
+
+    def shrink(self, new_aabb):
+        raise NotImplementedError("AABB shrink is SURVEY.md §8(f) N4 (never active in the BAT yamls)")
+
+    # ---- checkpoint extras (tensorBase.py:508-552) ------------------------------------------------
+    def get_reset_kwargs(self):
+        return {"aabb": self.aabb, "gridSize": self.gridSize.tolist(), "density_n_comp": self.density_n_comp,
+                "appearance_n_comp": self.app_n_comp, "app_dim": self.app_dim, "density_shift": self.density_shift,
+                "alphaMask_thres": self.alphaMask_thres, "distance_scale": self.distance_scale,
+                "rayMarch_weight_thres": self.rayMarch_weight_thres, "fea2denseAct": self.fea2denseAct,
+                "near_far": self.near_far, "step_ratio": self.step_ratio, "shadingMode": self.shadingMode,
+                "pos_pe": self.pos_pe, "view_pe": self.view_pe, "fea_pe": self.fea_pe, "featureC": self.featureC,
+                "volume_init_scale": self.volume_init_scale, "volume_init_bias": self.volume_init_bias}
+
+    def save_param_state(self):
+        return {"tensorf_reset_kwargs": self.get_reset_kwargs()}
+
+    def load_param_state(self, ckpt):
+        self.reset(**ckpt["tensorf_reset_kwargs"])
+
+    # ---- small pure helpers kept for API parity ---------------------------------------------------
+    def normalize_coord(self, xyz_sampled):
+        return (xyz_sampled - self.aabb[0].to(xyz_sampled.device)) * self.invaabbSize.to(xyz_sampled.device) - 1
+
+    def feature2density(self, density_features):
+        if self.fea2denseAct == "softplus":
+            return F.softplus(density_features + self.density_shift)
+        return F.relu(density_features + self.density_shift)
+
+    def get_kernel(self, opt, c2f_mode, c2f_parameter, c2f_kernel_size=25):
+        """batBase.py:13-25: sigma in voxels = mean(gridSize/aabbSize) * parameter (fp32)."""
+        scale = torch.mean(self.gridSize.to(torch.float32) / (self.aabb[1] - self.aabb[0]))
+        sig = (scale * c2f_parameter).to(torch.float32)
+        if c2f_mode == "uniform-gaussian":
+            return ops.gaussian_taps(sig, c2f_kernel_size, self.device)
+        if c2f_mode == "uniform-average":
+            return _average_kernel(float(sig), c2f_kernel_size).to(self.device)
+        raise RuntimeError(f"invalid c2f_mode {c2f_mode}")
+
+    def _check_flags(self, opt):
+        arch = getattr(opt, "arch", None)
+        if arch is None:
+            return
+        for k in ("abs_components", "component_wise_feature2density", "plane_feature2density", "convolve_plane_only",
+                  "convolve_positive_only", "ignore_negative_split"):
+            if bool(getattr(arch, k, False) if not isinstance(arch, dict) else arch.get(k, False)):
+                raise NotImplementedError("arch.%s=true is outside the hot path (false in every BAT yaml)" % k)
+
+    # ---- the renderer (batBase.py:44-165) -----------------------------------------------------------
+    def forward(self, opt, center, ray_dir, white_bg=True, is_train=False, ndc_ray=False, N_samples=-1,
+                c2f_parameter_density=None, c2f_parameter_color=None, c2f_mode=None, c2f_kernel_size=None,
+                is_test_optim=False, view_pe_progress=1.0, fea_pe_progress=1.0):
+        self._check_flags(opt)
+        self.opt = opt
+        dev = center.device
+        S = N_samples if N_samples > 0 else self.nSamples
+        near, far = float(self.near_far[0]), float(self.near_far[1])
+        R = center.shape[0]
+        jitter = zvals = None
+        if ndc_ray:
+            zvals = torch.linspace(near, far, S, device=dev, dtype=torch.float32).unsqueeze(0)
+            if is_train:
+                u = self.jitter_override if self.jitter_override is not None else torch.rand_like(zvals)
+                zvals = zvals + u.to(dev).view(1, -1) * ((far - near) / S)
+        elif is_train:
+            jitter = self.jitter_override if self.jitter_override is not None else torch.rand(R, 1, device=dev)
+            jitter = jitter.to(dev)
+        # blur kernels (batBase.py:91-101)
+        self.c2f_mode = c2f_mode
+        if c2f_mode is not None:
+            kd_mode = "uniform-gaussian" if is_test_optim else c2f_mode
+            self.kernel_density = self.get_kernel(opt, kd_mode, c2f_parameter_density, c2f_kernel_size)
+            self.kernel_color = self.get_kernel(opt, c2f_mode, c2f_parameter_color, c2f_kernel_size)
+        else:
+            self.kernel_density = self.kernel_color = None
+        dP, dL, aP, aL = list(self.density_plane), list(self.density_line), list(self.app_plane), list(self.app_line)
+        g = self.gridSize.tolist()
+        plane_hw = [(g[MAT_MODE[i][1]], g[MAT_MODE[i][0]]) for i in range(3)]
+        if c2f_mode is not None:
+            for i in range(3):
+                if g[MAT_MODE[i][0]] != g[MAT_MODE[i][1]]:
+                    raise NotImplementedError(
+                        "blur of non-square planes reproduces a reshape quirk of the reference "
+                        "(SURVEY.md App. B-10); not built yet")
+            dP = [ops.blur_factor(p, self.kernel_density) for p in dP]
+            dL = [ops.blur_factor(p, self.kernel_density) for p in dL]
+            aP = [ops.blur_factor(p, self.kernel_color) for p in aP]
+            aL = [ops.blur_factor(p, self.kernel_color) for p in aL]
+        # white background: static flag or the reference's CPU coin (batBase.py:154)
+        if white_bg:
+            wb = True
+        elif is_train:
+            coin = self.coin_override if self.coin_override is not None else float(torch.rand((1,)))
+            wb = coin < 0.5
+        else:
+            wb = False
+        if len(set(self.density_n_comp)) != 1 or len(set(self.app_n_comp)) != 1:
+            raise NotImplementedError("per-plane component counts must be equal (they are in both BAT yamls)")
+        cfg = ops.RenderCfg(
+            aabb=self.aabb.view(-1).tolist(), plane_hw=plane_hw, line_len=[g[VEC_MODE[i]] for i in range(3)],
+            n_comp_density=self.density_n_comp[0], n_comp_app=self.app_n_comp[0], step_size=float(self.stepSize),
+            near_far=(near, far), distance_scale=self.distance_scale, density_shift=self.density_shift,
+            density_act=_lib.JT_ACT_SOFTPLUS if self.fea2denseAct == "softplus" else _lib.JT_ACT_RELU,
+            weight_thres=self.rayMarch_weight_thres, n_samples=S, ndc=ndc_ray, white_bg=wb, app_dim=self.app_dim,
+            mlp_kind=self.renderModule.kind, mlp_hidden=self.featureC, view_pe=self.view_pe, fea_pe=self.fea_pe,
+            view_pe_progress=view_pe_progress, fea_pe_progress=fea_pe_progress, shade_impl=self.shade_impl)
+        rgb, depth, opacity = ops.render_rays(cfg, center, ray_dir, jitter, zvals, dP, dL, aP, aL,
+                                              self.basis_mat.weight, self.renderModule.weights())
+        return rgb, depth, opacity
+
+
+def _average_kernel(t, kernel_size):
+    """kernels.get_average_kernel (kernels.py:25-41)."""
+    if kernel_size % 2 == 0:
+        kernel_size += 1
+    t0 = min(math.floor(t), kernel_size // 2)
+    k0 = torch.zeros(kernel_size)
+    k0[kernel_size // 2 - t0:kernel_size // 2 + t0 + 1] = 1 / (t0 * 2 + 1)
+    t1 = min(math.ceil(t), kernel_size // 2)
+    k1 = torch.zeros(kernel_size)
+    k1[kernel_size // 2 - t1:kernel_size // 2 + t1 + 1] = 1 / (t1 * 2 + 1)
+    return (t % 1.0) * k1 + (1 - t % 1.0) * k0

@@ -1,0 +1,129 @@
+"""GPU parity: the HIP path (through the drop-in scene class and the C ABI) against
+  (a) the golden vectors captured from the reference, and
+  (b) the CPU oracle on the same inputs.
+Tolerances (fp32, different reduction order, float atomics): values 2e-5 abs, gradients 2e-3 of the
+tensor's max-abs (5e-2 for the saturated `dense` fixtures whose render gradient is a cancellation
+residue)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import CASES, Fixture, replay_oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL_VAL = 2e-5
+TOL_GRAD = 2e-3
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def build_scene(fx, device, shade_impl):
+    import joint_tensorf_amd as jt
+    m = fx.meta
+    torch.manual_seed(0)
+    tf = jt.BAT_VMSplit(m["aabb"], m["gridSize"], device, density_n_comp=m["density_n_comp"],
+                        appearance_n_comp=m["app_n_comp"], app_dim=m["app_dim"], near_far=list(m["near_far"]),
+                        shadingMode=m["shadingMode"], density_shift=m["density_shift"],
+                        distance_scale=m["distance_scale"], view_pe=m["view_pe"], fea_pe=m["fea_pe"],
+                        featureC=m["featureC"], step_ratio=m["step_ratio"], fea2denseAct=m["fea2denseAct"],
+                        rayMarch_weight_thres=m["rayMarch_weight_thres"], shade_impl=shade_impl)
+    sd = {k[len("param.nerf.tensorf."):]: fx.t(k) for k in fx.arrays if k.startswith("param.nerf.tensorf.")}
+    missing, unexpected = tf.load_state_dict(sd, strict=True)
+    return tf.to(device)
+
+
+def replay_hip(fx, shade_impl, pin_rays=True, device="cuda"):
+    from joint_tensorf_amd import ops
+    m = fx.meta
+    tf = build_scene(fx, device, shade_impl)
+    se3 = fx.t("param.se3_refine.weight", device).clone().requires_grad_(True)
+    idx = fx.t("in.idx", device).long()
+    if m["llff"]:
+        pose = ops.train_pose(se3[idx], None, torch.eye(3, 4, device=device))
+    else:
+        pose = ops.train_pose(se3[idx], fx.t("param.pose_noise", device)[idx], fx.t("in.pose_gt", device))
+    ray_idx = fx.t("in.ray_idx", device).long()
+    center, ray = ops.ray_gen(pose, fx.t("in.intr_inv", device), fx.t("in.intr", device), ray_idx, m["W"],
+                              ndc=m["ndc_ray"], ndc_near=m["ndc_near_plane"])
+    B, r = center.shape[:2]
+    center_own, ray_own = center, ray
+    if pin_rays:
+        center = center + (fx.t("mid.center", device).view(B, r, 3) - center).detach()
+        ray = ray + (fx.t("mid.ray_dir", device).view(B, r, 3) - ray).detach()
+    if m["is_train"] and fx.has("in.jitter"):
+        tf.jitter_override = fx.t("in.jitter", device)
+    tf.coin_override = m["coin"][0] if m["coin"] else None
+    rgb, depth, acc = tf(None, center.reshape(-1, 3), ray.reshape(-1, 3), white_bg=m["white_bg"],
+                         is_train=m["is_train"], ndc_ray=m["ndc_ray"], N_samples=m["N_samples"],
+                         c2f_parameter_density=m["c2f_parameter_density"], c2f_parameter_color=m["c2f_parameter_color"],
+                         c2f_mode=m["c2f_mode"], c2f_kernel_size=m["c2f_kernel_size"],
+                         view_pe_progress=m["view_pe_progress"], fea_pe_progress=m["fea_pe_progress"])
+    rgb = rgb.view(B, r, 3)
+    from oracle import tensorf_oracle as O  # checker only
+    if m["mode"] == "vis":
+        total = ((rgb - 0.3) ** 2).mean()
+    else:
+        image = fx.t("in.image", device).view(B, 3, -1).permute(0, 2, 1)[:, ray_idx]
+        e = m["edge_loss"]
+        edge_on = e["on"] and ((m["it"] % 2 == 0) if e["alternate"] else True)
+        if edge_on and m["mode"] == "train" and m["it"] < e["before_iter"]:
+            mask = fx.t("in.train_edge_masks", device)[:, ray_idx]
+            render = O.render_loss(rgb, image, mask, e["edge_factor"], e["non_edge_factor"])
+        else:
+            render = O.render_loss(rgb, image)
+        total = render + m["L1_weight"] * tf.density_L1()
+    total.backward()
+    grads = {}
+    for grp in ("density_plane", "density_line", "app_plane", "app_line"):
+        for i in range(3):
+            grads["%s.%d" % (grp, i)] = getattr(tf, grp)[i].grad
+    grads["basis_mat.weight"] = tf.basis_mat.weight.grad
+    w = tf.renderModule.weights()
+    for k, t in zip(("w1", "b1", "w2", "b2", "w3", "b3"), w):
+        grads["mlp." + k] = t.grad
+    return dict(pose=pose, center=center_own, ray=ray_own, rgb=rgb, depth=depth.view(B, r, 1),
+                opacity=acc.view(B, r, 1), total=total, grads=grads, grad_se3=se3.grad)
+
+
+def _supported(fx):
+    m = fx.meta
+    g = m["gridSize"]
+    if m["c2f_mode"] is not None and len(set(g)) != 1:
+        return False  # non-cubic blur quirk not built yet
+    return True
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("shade_impl", ["torch"])
+def test_hip_vs_golden_and_oracle(name, shade_impl):
+    fx = Fixture(name)
+    if not _supported(fx):
+        pytest.skip("non-cubic blur quirk not built yet")
+    out = replay_hip(fx, shade_impl)
+    ref = replay_oracle(fx)
+    tol_g = 5e-2 if "dense" in name else TOL_GRAD
+    np.testing.assert_allclose(out["pose"].detach().cpu().numpy(), fx.arrays["mid.current_pose"], atol=2e-6)
+    np.testing.assert_allclose(out["center"].detach().cpu().reshape(-1, 3).numpy(), fx.arrays["mid.center"], atol=5e-6)
+    np.testing.assert_allclose(out["ray"].detach().cpu().reshape(-1, 3).numpy(), fx.arrays["mid.ray_dir"], atol=5e-6)
+    for key, gold in (("rgb", "out.rgb"), ("opacity", "out.opacity")):
+        np.testing.assert_allclose(out[key].detach().cpu().numpy(), fx.arrays[gold], atol=TOL_VAL, err_msg=key)
+        np.testing.assert_allclose(out[key].detach().cpu().numpy(), ref[key].detach().numpy(), atol=TOL_VAL, err_msg=key)
+    np.testing.assert_allclose(out["depth"].detach().cpu().numpy(), fx.arrays["out.depth"], atol=1e-4)
+    if fx.meta["mode"] != "vis":
+        np.testing.assert_allclose(float(out["total"].detach()), float(fx.arrays["loss.all"]), rtol=1e-4)
+    bad = []
+    for n, g in out["grads"].items():
+        key = fx.grad_key(n)
+        assert g is not None, n
+        e1 = _rel(g.detach().cpu().numpy(), fx.arrays[key])
+        e2 = _rel(g.detach().cpu().numpy(), ref["grads"][n].numpy())
+        if max(e1, e2) > tol_g:
+            bad.append((n, e1, e2))
+    e = _rel(out["grad_se3"].cpu().numpy(), fx.arrays["grad.se3_refine.weight"])
+    if e > tol_g:
+        bad.append(("se3", e, _rel(out["grad_se3"].cpu().numpy(), ref["grad_se3"].numpy())))
+    assert not bad, bad
