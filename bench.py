@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""bench.py -- train rays/s of the joint pose + TensoRF-VM training step on MI355X.
+
+A "step" is one full optimisation iteration of the reference's hot loop on a synthetic
+Blender-lego-shaped scene: pose composition from se(3) parameters -> rays for the
+lattice pixels -> sampling / VM interpolation / MLP / compositing -> edge-weighted MSE + L1 (+TV)
+-> backward to the VM factors, basis, MLP and se(3) -> Adam steps (scene + pose) -> LR schedule.
+Inputs (images, cameras, parameters) are resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config bat_blender_VM] [--stage 4]
+
+N > 1: launched by torch.distributed.run, one rank per GPU; every rank renders its own ray batch
+(weak scaling) and the VM-factor / basis / MLP / pose gradients are summed with one RCCL
+all-reduce per iteration.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="bat_blender_VM")
+    ap.add_argument("--stage", type=int, default=-1,
+                    help="grid stage of the yaml's upsampling schedule (0 = initial grid, -1 = final grid)")
+    ap.add_argument("--n-rays", type=int, default=0, help="override opt.nerf.n_rays (0 = yaml schedule value)")
+    ap.add_argument("--shade-impl", default="mfma", choices=["mfma", "torch"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def setup_dist(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    return world, rank, local
+
+
+def stage_setup(opt, stage):
+    """Put `opt` at the start of grid stage `stage` of its own schedule (model/tensorf.py:304,449-461)."""
+    ups = list(opt.train_schedule.upsample_iters)
+    n_stage = len(ups) + 1
+    if stage < 0:
+        stage += n_stage
+    stage = max(0, min(stage, n_stage - 1))
+    n_list = torch.round(torch.exp(torch.linspace(np.log(opt.train_schedule.n_voxel_init),
+                                                  np.log(opt.train_schedule.n_voxel_final), n_stage))).long().tolist()
+    it0 = 0 if stage == 0 else ups[stage - 1]
+    # the final stage of bat_blender_VM runs 9000..40000; blur is active until progress 0.3 (it 12000).
+    # Bench the sharp part of the last stage (77 % of all iterations of the run are sharp last-stage ones).
+    if stage == n_stage - 1:
+        it0 = max(it0, int(0.3 * opt.max_iter) + 1)
+    opt.train_schedule.n_voxel_init = n_list[stage]
+    opt.train_schedule.upsample_iters = [u for u in ups if u > it0] or [10 ** 9]
+    return stage, it0
+
+
+def build_model(opt, it0, n_views):
+    from joint_tensorf_amd.model import bat_hip
+    model = bat_hip.Model(opt)
+    model.build_networks(opt, n_views=n_views)
+    model.setup_optimizer(opt)
+    model.it = it0
+    model.graph.nerf.set_progress(it0 / opt.max_iter)
+    return model
+
+
+def allreduce_grads(model, world):
+    if world == 1:
+        return
+    from joint_tensorf_amd import dist as jdist
+    jdist.allreduce_gradients(list(model.graph.parameters()), world)
+
+
+def cpu_baseline(opt_name, seconds_budget=20.0):
+    """The reference algorithm (torch-CPU oracle port, parity-pinned) on config C1 of SURVEY §8(d):
+    grid 64^3, 512 rays (4 views x 128), S = 221, fwd + loss + bwd, blur off."""
+    from oracle import tensorf_oracle as O
+    torch.set_num_threads(os.cpu_count())
+    g = torch.Generator().manual_seed(0)
+    grid = [64, 64, 64]
+    cfg = O.SceneCfg([-1.5] * 3 + [1.5] * 3, grid, [2.0, 6.0])
+    params = O.init_params(grid, scale=0.1, bias=0.0, generator=g)
+    for _, v in O.flat_params(params):
+        v.requires_grad_(True)
+    B, r, S, H, W = 4, 128, 221, 400, 400
+    from joint_tensorf_amd.synthetic import look_at
+    poses = []
+    for i in range(B):
+        th = 2 * np.pi * i / B
+        poses.append(look_at(4.0 * np.array([np.cos(th) * 0.8, np.sin(th) * 0.8, 0.6])))
+    pose_gt = torch.tensor(np.stack(poses))
+    f = 0.5 * W / np.tan(0.5 * 0.69)
+    intr = torch.tensor([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]], dtype=torch.float32)[None].repeat(B, 1, 1)
+    se3 = (torch.randn(B, 6, generator=g) * 0.01).requires_grad_(True)
+    noise = O.se3_to_SE3(torch.randn(B, 6, generator=g) * 0.15)
+    target = torch.rand(B, r, 3, generator=g)
+
+    def step():
+        ray_idx = torch.randperm(H * W, generator=g)[:r]
+        pose = O.train_pose(se3, noise, pose_gt)
+        c, d = O.rays_for_pixels(pose, intr.inverse(), ray_idx, W)
+        jit = torch.rand(B * r, 1, generator=g)
+        rgb, _, _ = O.render(cfg, params, c.reshape(-1, 3), d.reshape(-1, 3), S, white_bg=True, jitter=jit)
+        loss = O.render_loss(rgb.view(B, r, 3), target) + 8e-5 * O.density_L1(params)
+        loss.backward()
+
+    step()  # warm-up
+    times = []
+    t_end = time.time() + seconds_budget
+    while time.time() < t_end or len(times) < 3:
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
+        if len(times) >= 25:
+            break
+    med = float(np.median(times))
+    return dict(value=B * r / med, unit="rays/s", cores=os.cpu_count(), kind="port",
+                sample="C1: grid 64^3, 512 rays x 221 samples, fwd+loss+bwd, blur off, %d reps, median %.0f ms "
+                       "(min %.0f / max %.0f), torch %d threads" % (len(times), med * 1e3, min(times) * 1e3,
+                                                                   max(times) * 1e3, torch.get_num_threads()))
+
+
+def measure_roofline(model, opt, var, reps=20):
+    """Average duration of the dominant kernel launch (fused appearance forward: VM gather + basis +
+    MLP), measured with HIP events on the launch stream, against its algorithmic gather bytes."""
+    from joint_tensorf_amd import ops
+    g = model.graph
+    tf = g.nerf.tensorf
+    with torch.no_grad():
+        pose = g.get_pose(opt, var, mode="train")
+        ray_idx = torch.arange(0, opt.H * opt.W, max(1, (opt.H * opt.W) // max(1, opt.nerf.n_rays // len(var.idx))),
+                               device=opt.device)[:max(1, opt.nerf.n_rays // len(var.idx))]
+        center, ray = ops.ray_gen(pose, var.intr_inv, var.intr, ray_idx, opt.W, ndc=bool(opt.camera.ndc))
+    probe = ops.KernelProbe(tf, center.reshape(-1, 3), ray.reshape(-1, 3), g.nerf.n_samples,
+                            white_bg=bool(opt.nerf.setbg_opaque), ndc=bool(opt.camera.ndc))
+    return probe.run(reps)
+
+
+def main():
+    args = parse()
+    world, rank, local = setup_dist(args)
+    dev = "cuda:%d" % local
+    import joint_tensorf_amd  # noqa: F401  (fails loudly without the HIP library)
+    from joint_tensorf_amd.options import make_options
+    from joint_tensorf_amd.synthetic import make_views
+
+    torch.manual_seed(0)
+    np.random.seed(1234)  # host draws (blur scale) identical on every rank
+    opt = make_options(args.config, device=dev, shade_impl=args.shade_impl)
+    stage, it0 = stage_setup(opt, args.stage)
+    if it0 < opt.train_schedule.change_n_rays_after_n_iters:
+        opt.nerf.n_rays = opt.train_schedule.n_rays_init
+    else:
+        opt.nerf.n_rays = opt.train_schedule.n_rays_rest
+    if args.n_rays:
+        opt.nerf.n_rays = args.n_rays
+    n_views = int(opt.data.num_views)
+    model = build_model(opt, it0, n_views)
+    var_all = make_views(opt, n_views, seed=0, device=dev)
+    nerf = model.graph.nerf
+    res, S = nerf.resolution, nerf.n_samples
+    # per-rank lattice offsets differ (different pixels per GPU); everything else is shared
+    lattice_rng = np.random.RandomState(1000 + rank)
+
+    rays_total = 0
+
+    def one_step():
+        nonlocal rays_total
+        from joint_tensorf_amd.options import Opt
+        var = Opt(dict(var_all))
+        state = np.random.get_state()
+        np.random.set_state(lattice_rng.get_state())
+        g = model.graph
+        g.it = model.it
+        model.optim.zero_grad()
+        var = g.forward(opt, var, mode="train")
+        lattice_rng.set_state(np.random.get_state())
+        np.random.set_state(state)
+        loss = g.compute_loss(opt, var, mode="train")
+        loss = model.summarize_loss(opt, var, loss)
+        (loss.all / world).backward()
+        allreduce_grads(model, world)
+        model.optim.step()
+        model.optim.zero_grad()
+        it = model.it
+        model.it += 1
+        model.optim_pose.step()
+        model.optim_pose.zero_grad()
+        if model.sched_pose is not None:
+            model.sched_pose.step()
+        nerf.set_progress(model.it / opt.max_iter)
+        model.after_iteration(opt, it)
+        rays_total += var.rgb.shape[0] * var.rgb.shape[1]
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    rays_total = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, float(rays_total)], device=dev, dtype=torch.float64)
+    if world > 1:
+        import torch.distributed as dist
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, rays_all = float(tmax[0]), float(tsum[1])
+    else:
+        rays_all = float(rays_total)
+
+    if rank == 0:
+        out = {
+            "metric": "train rays/sec & Msamples/sec composited, lego VM-48, 1/2/4/8 MI355X",
+            "value": rays_all / dt,
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (random-init VM factors / MLP, random images, 100 cameras on a radius-4 sphere)",
+            "config": {
+                "workload": "%s stage %d: grid %s, S=%d samples/ray, %d rays/iter/GPU (%s lattice over %d views), "
+                            "blur %s, full train step (fwd+loss+bwd+Adam+pose Adam)"
+                            % (args.config, stage, "x".join(str(r) for r in res), S, int(rays_all / args.steps / world),
+                               opt.nerf.ray_sampling_strategy, n_views,
+                               "on" if model.graph.resolve_blur(opt, "vis")[2] else "off"),
+                "rays_per_iter_per_gpu": rays_all / args.steps / world,
+                "samples_per_ray": S,
+                "Msamples_per_s": rays_all * S / dt / 1e6,
+                "shade_impl": args.shade_impl,
+            },
+        }
+        if world == 1 and not args.no_roofline:
+            try:
+                from joint_tensorf_amd.options import Opt
+                out["roofline"] = measure_roofline(model, opt, Opt(dict(var_all)))
+            except Exception as e:  # keep the bench line even if the probe is unavailable
+                out["roofline"] = {"error": repr(e)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.config)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

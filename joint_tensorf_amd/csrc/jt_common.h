@@ -1,6 +1,6 @@
 // Device-side helpers shared by the gfx950 kernels of the TensoRF-VM renderer.
 // Math follows the reference line by line where the result is DISCRETE (in-box test, sample
-// positions): those expressions use non-contracted __fmul_rn/__fadd_rn so that they round exactly
+// positions): those expressions use non-contracted mul_rn/add_rn so that they round exactly
 // like the torch elementwise ops they replace (tensorBase.py:572-612).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -84,11 +84,22 @@ __device__ inline float ray_tmin(const Dev& D, const float o[3], const float d[3
   return fminf(fmaxf(t, D.near_), D.far_);
 }
 
+// separately rounded multiply / add.  HIP's __fmul_rn/__fadd_rn are plain `*`/`+` and get contracted
+// into an FMA under the default -ffp-contract=fast; the pragma keeps these two un-fused.
+__device__ inline float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ inline float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+
 // z_i = t_min + stepSize * (i + u)     (tensorBase.py:591-596); NDC: z_i = zvals[i]
 __device__ inline float sample_z(const Dev& D, const Ray& r, const float* zvals, int i) {
   if (D.ndc) return zvals[i];
-  float rng = __fadd_rn((float)i, r.u);
-  return __fadd_rn(r.tmin, __fmul_rn(D.step, rng));
+  float rng = add_rn((float)i, r.u);
+  return add_rn(r.tmin, mul_rn(D.step, rng));
 }
 
 // pts = o + d*z (un-fused, tensorBase.py:598) and the in-box test (tensorBase.py:610)
@@ -96,7 +107,7 @@ __device__ inline bool sample_point(const Dev& D, const Ray& r, float z, float p
   bool inside = true;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    p[a] = __fadd_rn(r.o[a], __fmul_rn(r.d[a], z));
+    p[a] = add_rn(r.o[a], mul_rn(r.d[a], z));
     inside = inside && !(D.lo[a] > p[a]) && !(p[a] > D.hi[a]);
   }
   return inside;

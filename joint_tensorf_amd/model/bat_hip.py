@@ -1,0 +1,393 @@
+"""`bat_hip`: drop-in for the reference's `model/bat.py` (+ the parts of model/tensorf.py,
+model/nerf.py and model/base.py it inherits) on the training hot path.
+
+Same classes and call contract as the reference:
+    Graph.forward(opt, var, mode) -> var with rgb [B,r,3], depth/opacity [B,r,1], ray_idx, current_pose
+    Graph.compute_loss(opt, var, mode) -> dict of 0-dim tensors
+    Graph.get_pose / render / render_rays / render_by_slices
+    NeRF: resolution / sample-count / learning-rate schedule owner (model/tensorf.py:278-524)
+    Model: build_networks / setup_optimizer / train_iteration (model/bat.py:30-116, base.py:154-172)
+What differs is *how* a forward is executed: pose composition, ray generation for the sampled pixels
+only, sampling, interpolation, MLP, compositing and their backward are HIP kernels
+(joint_tensorf_amd/csrc), and the schedule scalars stay on the host (no `.cpu()` reads of Parameters).
+Logging / visualisation / dataset loading of the reference engine are out of scope.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import ops
+from .. import tensorf_repr
+from ..options import Opt
+
+
+def interp_schedule(x, schedule, left=0.0, right=1.0):
+    """util.interp_schedule (util.py:217-225) on host floats."""
+    x = float(x)
+    assert left <= x <= right
+    xs = np.linspace(left, right, len(schedule))
+    return float(np.interp(x, xs, schedule))
+
+
+def _has(o, k):
+    return (k in o) if isinstance(o, dict) else hasattr(o, k)
+
+
+class NeRF(torch.nn.Module):
+    """tensorf.NeRF + bat.NeRF: owns the scene tensors and every schedule that resizes them."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.device = opt.device
+        self.register_new_optimizer = None
+        self.get_current_optimizer = None
+        self.lr_decay_duration = opt.max_iter if opt.optim.lr_decay_iters < 0 else opt.optim.lr_decay_iters
+        self.lr_decay_factor = opt.optim.lr_decay_target_ratio ** (1 / self.lr_decay_duration)
+        self.update_alphamask_iters = opt.train_schedule.update_alphamask_iters
+        self.upsample_list = opt.train_schedule.upsample_iters
+        self.bbox = torch.tensor(opt.data.scene_bbox).to(torch.float).view(2, 3)
+        n_list = torch.round(torch.exp(torch.linspace(np.log(opt.train_schedule.n_voxel_init),
+                                                      np.log(opt.train_schedule.n_voxel_final),
+                                                      len(self.upsample_list) + 1))).long().tolist()[1:]
+        self.reset(opt, bbox=opt.data.scene_bbox, n_voxel_list=n_list, n_voxels=opt.train_schedule.n_voxel_init,
+                   alphamask_resolution=self._find_resolution(opt, opt.train_schedule.n_voxel_init),
+                   lr_basis=opt.optim.lr_basis, lr_index=opt.optim.lr_index,
+                   TV_weight_color=opt.loss_weight.TV_color, TV_weight_density=opt.loss_weight.TV_density)
+        self.define_network(opt)
+        # Parameters so that they are checkpointed like the reference's (model/bat.py:373-374);
+        # the host mirrors are what the schedule code reads (no device->host sync per iteration).
+        self.progress = torch.nn.Parameter(torch.tensor(0.0))
+        self.test_time_progress = torch.nn.Parameter(torch.tensor(0.0))
+        self.progress_host = 0.0
+        self.test_time_progress_host = 0.0
+
+    def set_progress(self, value):
+        self.progress_host = float(value)
+        self.progress.data.fill_(float(value))
+
+    def reset(self, opt, bbox, n_voxel_list, n_voxels, alphamask_resolution, lr_basis, lr_index, TV_weight_color,
+              TV_weight_density):
+        self.bbox = torch.as_tensor(bbox).to(torch.float).view(2, 3)
+        self.n_voxel_list = list(n_voxel_list)
+        self.n_voxels = n_voxels
+        self.resolution = self._find_resolution(opt, self.n_voxels)
+        self.n_samples = self._find_n_samples(opt, self.resolution)
+        self.alphamask_resolution = alphamask_resolution
+        self.lr_basis, self.lr_index = lr_basis, lr_index
+        self.TV_weight_color, self.TV_weight_density = TV_weight_color, TV_weight_density
+        opt.loss_weight.TV_color = TV_weight_color
+        opt.loss_weight.TV_density = TV_weight_density
+
+    def define_network(self, opt):
+        arch = opt.arch
+        dens = [int(c) for c in arch.tensorf.density_components]
+        app = [int(c) for c in arch.tensorf.color_components]
+        cls = getattr(tensorf_repr, arch.tensorf.model)
+        self.tensorf = cls(self.bbox, self.resolution, opt.device, density_n_comp=dens, appearance_n_comp=app,
+                           app_dim=arch.shading.app_dim, near_far=opt.nerf.depth.range,
+                           shadingMode=arch.shading.model, alphaMask_thres=opt.train_schedule.alpha_mask_threshold,
+                           density_shift=arch.density_shift, distance_scale=arch.distance_scale,
+                           pos_pe=arch.shading.pose_pe, view_pe=arch.shading.view_pe, fea_pe=arch.shading.fea_pe,
+                           featureC=arch.shading.mlp_hidden_dim, step_ratio=opt.nerf.step_ratio,
+                           fea2denseAct=arch.feature_to_density_activation, dtype=torch.float32,
+                           volume_init_scale=arch.tensorf.volume_init_scale,
+                           rayMarch_weight_thres=arch.tensorf.rayMarch_weight_thres,
+                           volume_init_bias=arch.tensorf.volume_init_bias,
+                           shade_impl=opt.get("shade_impl", "mfma"))
+
+    def _find_resolution(self, opt, n_voxels):
+        lo, hi = self.bbox[0], self.bbox[1]
+        voxel = ((hi - lo).prod() / n_voxels).pow(1 / 3)
+        scale = torch.tensor(opt.train_schedule.resolution_scale_init)
+        return ((hi - lo) / voxel * scale).long().tolist()
+
+    def _find_n_samples(self, opt, resolution):
+        return min(int(opt.nerf.sample_intvs), int(np.linalg.norm(resolution) / opt.nerf.step_ratio))
+
+    def _get_optimizer(self, opt, it=0, lr_basis=None, lr_index=None):
+        if lr_basis is None and lr_index is None:
+            reset = opt.optim.lr_upsample_reset and it in self.upsample_list
+            scale = 1.0 if reset else opt.optim.lr_decay_target_ratio ** (it / opt.max_iter)
+            self.lr_basis, self.lr_index = opt.optim.lr_basis * scale, opt.optim.lr_index * scale
+        else:
+            self.lr_basis, self.lr_index = lr_basis, lr_index
+        groups = self.tensorf.get_optparam_groups(self.lr_index, self.lr_basis)
+        if opt.optim.algo == "Adam":
+            return torch.optim.Adam(groups, betas=(0.9, 0.99))
+        return getattr(torch.optim, opt.optim.algo)(groups)
+
+    def update_schedule(self, opt, it):
+        """model/tensorf.py:399-447."""
+        assert self.register_new_optimizer is not None and self.get_current_optimizer is not None
+        if it in self.upsample_list:
+            if it == self.upsample_list[0]:
+                opt.train_schedule.resolution_scale_init = [1.0, 1.0, 1.0]
+            self.n_voxels = self.n_voxel_list.pop(0)
+            self.resolution = self._find_resolution(opt, self.n_voxels)
+            self.tensorf.upsample_volume_grid(self.resolution)
+            self.n_samples = self._find_n_samples(opt, self.resolution)
+            self.register_new_optimizer(self._get_optimizer(opt, it))
+        else:
+            for g in self.get_current_optimizer().param_groups:
+                g["lr"] = g["lr"] * self.lr_decay_factor
+            self.lr_basis *= self.lr_decay_factor
+            self.lr_index *= self.lr_decay_factor
+        if it in self.update_alphamask_iters:
+            r = self.resolution
+            if r[0] * r[1] * r[2] < 256 ** 3:
+                raise NotImplementedError("alpha-mask update (SURVEY.md §8(f) N4) -- never reached by the BAT yamls")
+        if opt.loss_weight.TV_density > 0:
+            opt.loss_weight.TV_density *= self.lr_decay_factor
+            self.TV_weight_density = opt.loss_weight.TV_density
+        if opt.loss_weight.TV_color > 0:
+            opt.loss_weight.TV_color *= self.lr_decay_factor
+            self.TV_weight_color = opt.loss_weight.TV_color
+
+    def freeze_scene(self, opt):
+        self.tensorf.freeze_scene(opt)
+
+    def unfreeze_scene(self, opt):
+        self.tensorf.unfreeze_scene(opt)
+
+
+class Graph(torch.nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.it = 0
+        self.nerf = NeRF(opt)
+        self.nerf.get_parent = lambda: self
+        self.pose_eye = torch.eye(3, 4, device=opt.device)
+        self.tvloss = tensorf_repr.TVLoss()
+        self.sim3 = None
+
+    # ---- pose (model/bat.py:341-367) -------------------------------------------------------------
+    def get_pose(self, opt, var, mode=None):
+        if mode == "train":
+            var.se3_refine = self.se3_refine.weight[var.idx]
+            if opt.data.dataset == "blender":
+                noise = self.pose_noise[var.idx] if opt.camera.noise else None
+                if noise is not None:
+                    var.pose_noise = noise
+                return ops.train_pose(var.se3_refine, noise, var.pose)
+            return ops.train_pose(var.se3_refine, None, self.pose_eye)
+        if mode in ("val", "eval", "test-optim"):
+            sim3 = self.sim3
+            R, t = var.pose[..., :3], var.pose[..., 3:]
+            center = (-R.transpose(-1, -2) @ t)[..., 0]  # camera centres in world coordinates
+            center_aligned = (center - sim3.t0) / sim3.s0 @ sim3.R * sim3.s1 + sim3.t1
+            R_aligned = R @ sim3.R
+            t_aligned = (-R_aligned @ center_aligned[..., None])[..., 0]
+            pose = torch.cat([R_aligned, t_aligned[..., None]], -1)
+            if opt.optim.test_photo and mode != "val":
+                pr = var.pose_refine_test
+                pose = torch.cat([pose[..., :3] @ pr[..., :3], pose[..., :3] @ pr[..., 3:] + pose[..., 3:]], -1)
+            return pose
+        return var.pose
+
+    # ---- forward (model/nerf.py:650-679) ---------------------------------------------------------
+    def forward(self, opt, var, mode=None):
+        batch_size = len(var.idx)
+        pose = self.get_pose(opt, var, mode=mode)
+        var.current_pose = pose
+        if mode in ("train", "test-optim"):
+            strat = opt.nerf.ray_sampling_strategy
+            if strat == "all_view_rand_rays":
+                var.ray_idx = torch.randperm(opt.H * opt.W, device=opt.device)[:opt.nerf.n_rays // batch_size]
+            elif strat == "all_view_rand_grid":
+                rays_per_view = opt.nerf.n_rays // batch_size
+                step = math.ceil((opt.H * opt.W // rays_per_view) ** 0.5)
+                ox, oy = np.random.randint(step), np.random.randint(step)
+                sx = torch.arange(ox, opt.W, step, device=opt.device)
+                sy = torch.arange(oy, opt.H, step, device=opt.device)
+                gY, gX = torch.meshgrid(sy, sx, indexing="ij")
+                var.ray_idx = (gX + gY * opt.W).view(-1)
+                var.ray_grid_step, var.grid_H, var.grid_W = step, len(sy), len(sx)
+            else:
+                assert strat == "single_view_rand_rays"
+                var.ray_idx = torch.randperm(opt.H * opt.W, device=opt.device)[:opt.nerf.n_rays]
+            ret = self.render(opt, pose, intr_inv=var.intr_inv, ray_idx=var.ray_idx, mode=mode, intr=var.intr)
+        else:
+            ret = self.render_by_slices(opt, pose, intr_inv=var.intr_inv, mode=mode, intr=var.intr)
+        var.update(ret)
+        return var
+
+    # ---- render (model/tensorf.py:144-167) -------------------------------------------------------
+    def render(self, opt, pose, intr_inv=None, ray_idx=None, mode=None, intr=None):
+        if ray_idx is None:
+            ray_idx = torch.arange(opt.H * opt.W, device=pose.device)
+        ndc_near = float(opt.arch.ndc_near_plane) if _has(opt.arch, "ndc_near_plane") else 1.0
+        # rays for the sampled pixels only, NDC folded in (camera.py:231-261, 303-340)
+        center, ray = ops.ray_gen(pose, intr_inv, intr, ray_idx, opt.W, ndc=bool(opt.camera.ndc), ndc_near=ndc_near)
+        return self.render_rays(opt, center, ray, mode, n_views=len(pose), n_pixels_per_view=center.shape[1])
+
+    def render_by_slices(self, opt, pose, intr_inv=None, mode=None, intr=None):
+        """model/nerf.py:728-740."""
+        acc = dict(rgb=[], depth=[], opacity=[])
+        for c in range(0, opt.H * opt.W, opt.nerf.n_rays):
+            ray_idx = torch.arange(c, min(c + opt.nerf.n_rays, opt.H * opt.W), device=opt.device)
+            ret = self.render(opt, pose, intr_inv=intr_inv, ray_idx=ray_idx, mode="vis", intr=intr)
+            for k in acc:
+                acc[k].append(ret[k])
+        return Opt({k: torch.cat(v, dim=1) for k, v in acc.items()})
+
+    # ---- schedule glue (model/tensorf.py:169-267) -------------------------------------------------
+    def resolve_blur(self, opt, mode):
+        if not (opt.model in ("bat", "bat_hip") and opt.c2f_mode != "None"):
+            return None, None, None, None
+        c2f_mode = opt.c2f_mode
+        if c2f_mode not in ("uniform-gaussian", "uniform-average"):
+            raise Exception("unknown c2f_mode")
+        pd = interp_schedule(self.nerf.progress_host, opt.c2f_schedule_density)
+        pc = interp_schedule(self.nerf.progress_host, opt.c2f_schedule_color)
+        if mode != "vis" and _has(opt, "c2f_random_density_blur") and opt.c2f_random_density_blur:
+            if mode == "train" and _has(opt, "sync_2d_3d_scales") and opt.sync_2d_3d_scales:
+                scale = self.scale
+            else:
+                scale = np.random.choice(opt.c2f_random_density_scale_pool)
+            pd = pd * scale
+        if mode == "test-optim" and opt.data.dataset == "llff":
+            pd = interp_schedule(self.nerf.test_time_progress_host, opt.optim.test_kernel_schedule)
+        if max(pd, pc) < 0.001:
+            return None, None, None, None
+        return pd, pc, c2f_mode, opt.c2f_kernel_size
+
+    def render_rays(self, opt, center, ray, mode=None, n_views=None, n_pixels_per_view=None):
+        batch_size = n_views if n_views else center.shape[0]
+        dim1 = n_pixels_per_view if n_pixels_per_view else center.shape[1]
+        pd, pc, c2f_mode, ksize = self.resolve_blur(opt, mode)
+        tf = self.nerf.tensorf
+        if opt.data.dataset != "blender":
+            tf.near_far[0] = interp_schedule(self.nerf.progress_host, opt.tensorf_near_plane_schedule)
+            opt.nerf.depth.range[0] = tf.near_far[0]
+        view_pe = interp_schedule(self.nerf.progress_host, opt.c2f_view_pe_schedule) if _has(opt, "c2f_view_pe_schedule") else 1.0
+        fea_pe = interp_schedule(self.nerf.progress_host, opt.c2f_fea_pe_schedule) if _has(opt, "c2f_fea_pe_schedule") else 1.0
+        rgb, depth, opacity = tf.forward(
+            opt, center=center.reshape(-1, 3), ray_dir=ray.reshape(-1, 3), white_bg=opt.nerf.setbg_opaque,
+            is_train=(mode == "train" and opt.nerf.sample_stratified),
+            is_test_optim=(mode == "test-optim") and (opt.data.dataset == "llff"), ndc_ray=opt.camera.ndc,
+            N_samples=self.nerf.n_samples, c2f_parameter_density=pd, c2f_parameter_color=pc, c2f_mode=c2f_mode,
+            c2f_kernel_size=ksize, fea_pe_progress=fea_pe, view_pe_progress=view_pe)
+        return Opt(rgb=rgb.view(batch_size, dim1, 3), depth=depth.view(batch_size, dim1, 1),
+                   opacity=opacity.view(batch_size, dim1, 1))
+
+    # ---- losses (model/tensorf.py:96-142, base.py:259-261) ----------------------------------------
+    @staticmethod
+    def MSE_loss(pred, label=0):
+        return ((pred.contiguous() - label) ** 2).nanmean()
+
+    def compute_loss(self, opt, var, mode=None):
+        loss = Opt()
+        batch_size = len(var.idx)
+        image = var.image.view(batch_size, 3, opt.H * opt.W).permute(0, 2, 1)
+        if mode in ("train", "test-optim"):
+            image = image[:, var.ray_idx]
+        if opt.loss_weight.render is not None:
+            edge_on = False
+            if _has(opt, "edge_mask_on_render_loss") and opt.edge_mask_on_render_loss:
+                edge_on = (self.it % 2 == 0) if (_has(opt, "alternate_edge_loss") and opt.alternate_edge_loss) else True
+            if edge_on and mode == "train" and self.it < opt.edge_mask_before_iter:
+                m = var.train_edge_masks[:, var.ray_idx].view(batch_size, len(var.ray_idx), 1).expand(-1, -1, 3)
+                if _has(opt, "soft_edge_loss") and opt.soft_edge_loss:
+                    m = m * opt.edge_loss_factor + opt.non_edge_loss_factor
+                    loss.render = self.MSE_loss(var.rgb * m, image * m)
+                else:
+                    edge = self.MSE_loss(var.rgb * m, image * m)
+                    non_edge = self.MSE_loss(var.rgb * (1 - m), image * (1 - m))
+                    loss.render = opt.edge_loss_factor * edge + opt.non_edge_loss_factor * non_edge
+            else:
+                loss.render = self.MSE_loss(var.rgb, image)
+        tf = self.nerf.tensorf
+        loss.L1 = tf.density_L1()
+        loss.TV_density = tf.TV_loss_density(self.tvloss)
+        loss.TV_color = tf.TV_loss_app(self.tvloss)
+        if mode == "train" and opt.nerf.ray_sampling_strategy == "all_view_rand_grid" and "TV_depth" in opt.loss_weight:
+            d = var.depth.reshape(batch_size, var.grid_H, var.grid_W)
+            loss.TV_depth = torch.pow(d[:, 1:, :] - d[:, :-1, :], 2).sum() / var.grid_H + \
+                torch.pow(d[:, :, 1:] - d[:, :, :-1], 2).sum() / var.grid_W
+            if self.it > opt.loss_weight.TV_depth_until_iters:
+                opt.loss_weight.TV_depth = 0.0
+        return loss
+
+
+class Model(torch.nn.Module):
+    """Training driver on the hot path: bat.Model / tensorf.Model / base.Model.train_iteration."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.it = 0
+
+    def build_networks(self, opt, n_views):
+        self.graph = Graph(opt).to(opt.device)
+        if opt.camera.noise:
+            se3_noise = torch.randn(n_views, 6, device=opt.device) * opt.camera.noise
+            # pose_noise = se3_to_SE3(noise) (model/bat.py:32-36): the exp kernel with identity base
+            eye = torch.eye(3, 4, device=opt.device)
+            noise = ops.train_pose(se3_noise.float(), None, eye)
+            self.graph.pose_noise = torch.nn.Parameter(noise.detach(), requires_grad=False)
+        self.graph.se3_refine = torch.nn.Embedding(n_views, 6).to(opt.device)
+        torch.nn.init.zeros_(self.graph.se3_refine.weight)
+
+    def setup_optimizer(self, opt):
+        nerf = self.graph.nerf
+        self.optim = nerf._get_optimizer(opt)
+        nerf.get_current_optimizer = lambda: self.optim
+
+        def register(o):
+            self.optim = o
+        nerf.register_new_optimizer = register
+        algo = getattr(torch.optim, opt.optim.pose_algo)
+        self.optim_pose = algo([dict(params=self.graph.se3_refine.parameters(), lr=opt.optim.lr_pose)])
+        self.sched_pose = None
+        if opt.optim.sched_pose:
+            assert opt.optim.sched_pose.type == "ExponentialLR"
+            gamma = (opt.optim.lr_pose_end / opt.optim.lr_pose) ** (1.0 / opt.max_iter)
+            self.sched_pose = torch.optim.lr_scheduler.ExponentialLR(self.optim_pose, gamma=gamma)
+
+    def summarize_loss(self, opt, var, loss):
+        """model/tensorf.py:31-47 (linear weights; the finiteness asserts would force a host sync per
+        iteration and are left to the caller)."""
+        total = 0.0
+        for key in loss:
+            assert key in opt.loss_weight, f"loss {key} not in opt.loss_weight"
+            if key == "L1":
+                first = opt.train_schedule.update_alphamask_iters[0]
+                w = float(opt.loss_weight.L1.rest if self.it > first else opt.loss_weight.L1.init)
+                total = total + w * loss["L1"]
+            elif opt.loss_weight[key] is not None:
+                w = float(opt.loss_weight[key])
+                if w != 0.0:
+                    total = total + w * loss[key]
+        loss.update(all=total)
+        return loss
+
+    def train_iteration(self, opt, var):
+        """One optimisation step (model/bat.py:96-116 around model/base.py:154-172)."""
+        g = self.graph
+        g.it = self.it
+        if opt.optim.warmup_pose:
+            pg = self.optim_pose.param_groups[0]
+            pg["lr_orig"] = pg["lr"]
+            pg["lr"] *= min(1, self.it / opt.optim.warmup_pose)
+        self.optim.zero_grad()
+        var = g.forward(opt, var, mode="train")
+        loss = g.compute_loss(opt, var, mode="train")
+        loss = self.summarize_loss(opt, var, loss)
+        loss.all.backward()
+        if (not _has(opt.optim, "grad_accum_iter")) or (self.it % opt.optim.grad_accum_iter) == 0:
+            self.optim.step()
+            self.optim.zero_grad()
+        self.it += 1
+        if (not _has(opt.optim, "pose_grad_accum_iter")) or (self.it % opt.optim.pose_grad_accum_iter) == 0:
+            self.optim_pose.step()
+            self.optim_pose.zero_grad()
+        if opt.optim.warmup_pose:
+            self.optim_pose.param_groups[0]["lr"] = self.optim_pose.param_groups[0]["lr_orig"]
+        if self.sched_pose is not None:
+            self.sched_pose.step()
+        g.nerf.set_progress(self.it / opt.max_iter)
+        return loss
+
+    def after_iteration(self, opt, it):
+        """the part of nerf.Model.train's loop body that follows train_iteration (model/nerf.py:258-260)."""
+        self.graph.nerf.update_schedule(opt, it)

@@ -75,7 +75,10 @@ def replay_hip(fx, shade_impl, pin_rays=True, device="cuda"):
             render = O.render_loss(rgb, image, mask, e["edge_factor"], e["non_edge_factor"])
         else:
             render = O.render_loss(rgb, image)
-        total = render + m["L1_weight"] * tf.density_L1()
+        import joint_tensorf_amd as jt
+        tv = jt.TVLoss()
+        total = render + m["L1_weight"] * tf.density_L1() + m["TV_density_weight"] * tf.TV_loss_density(tv) \
+            + m["TV_color_weight"] * tf.TV_loss_app(tv)
     total.backward()
     grads = {}
     for grp in ("density_plane", "density_line", "app_plane", "app_line"):

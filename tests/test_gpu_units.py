@@ -1,0 +1,171 @@
+"""GPU unit parity of the individual C-ABI entry points against the CPU oracle / known answers."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tensorf_oracle as O
+from tests.golden_util import GOLDEN, Fixture
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def test_pose_known_answers():
+    from joint_tensorf_amd import ops
+    d = np.load(GOLDEN + "/known_answers.npz")
+    wu = torch.tensor(d["se3.wu"], device=DEV, requires_grad=True)
+    eye = torch.eye(3, 4, device=DEV)
+    Rt = ops.train_pose(wu, None, eye)  # exp(se3) o identity
+    np.testing.assert_allclose(Rt.detach().cpu().numpy(), d["se3.Rt"], atol=2e-6)
+    (Rt * torch.tensor(d["se3.cot"], device=DEV)).sum().backward()
+    np.testing.assert_allclose(wu.grad.cpu().numpy(), d["se3.grad_wu"], atol=5e-5, rtol=2e-4)
+
+
+def test_pose_compose_vs_oracle():
+    from joint_tensorf_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B = 37
+    se3 = (torch.randn(B, 6, generator=g) * 0.2)
+    noise = O.se3_to_SE3(torch.randn(B, 6, generator=g) * 0.15)
+    gt = O.se3_to_SE3(torch.randn(B, 6, generator=g))
+    cot = torch.randn(B, 3, 4, generator=g)
+    a = se3.clone().requires_grad_(True)
+    ref = O.train_pose(a, noise, gt)
+    (ref * cot).sum().backward()
+    b = se3.clone().to(DEV).requires_grad_(True)
+    out = ops.train_pose(b, noise.to(DEV), gt.to(DEV))
+    (out * cot.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-6)
+    assert _rel(b.grad.cpu().numpy(), a.grad.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("ndc", [False, True])
+def test_raygen_vs_oracle(ndc):
+    from joint_tensorf_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 5, 30, 40
+    if ndc:
+        pose = torch.eye(3, 4)[None].repeat(B, 1, 1) + 0.02 * torch.randn(B, 3, 4, generator=g)
+    else:
+        pose = O.se3_to_SE3(torch.randn(B, 6, generator=g))
+        pose[..., 3] += torch.tensor([0.0, 0.0, 4.0])
+    f = 0.8 * W
+    intr = torch.tensor([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]])[None].repeat(B, 1, 1)
+    ray_idx = torch.randperm(H * W, generator=g)[:77]
+    co, cd = torch.randn(B, 77, 3, generator=g), torch.randn(B, 77, 3, generator=g)
+    p1 = pose.clone().requires_grad_(True)
+    c, r = O.rays_for_pixels(p1, intr.inverse(), ray_idx, W)
+    if ndc:
+        c, r = O.convert_ndc(c, r, intr, near=1.0)
+    ((c * co).sum() + (r * cd).sum()).backward()
+    p2 = pose.clone().to(DEV).requires_grad_(True)
+    c2, r2 = ops.ray_gen(p2, intr.inverse().to(DEV), intr.to(DEV), ray_idx.to(DEV), W, ndc=ndc, ndc_near=1.0)
+    ((c2 * co.to(DEV)).sum() + (r2 * cd.to(DEV)).sum()).backward()
+    np.testing.assert_allclose(c2.detach().cpu().numpy(), c.detach().numpy(), atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(r2.detach().cpu().numpy(), r.detach().numpy(), atol=1e-5, rtol=1e-5)
+    assert _rel(p2.grad.cpu().numpy(), p1.grad.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(16, 14, 14), (48, 21, 21), (4, 9, 9), (16, 70, 70)])
+@pytest.mark.parametrize("sigma", [0.7, 2.3, 6.4])
+def test_blur_plane_vs_oracle(shape, sigma):
+    from joint_tensorf_amd import ops
+    C, H, W = shape
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(1, C, H, W, generator=g)
+    cot = torch.randn(1, C, H, W, generator=g)
+    k = O.gaussian_kernel(sigma, 64)
+    a = x.clone().requires_grad_(True)
+    ref = O.blur_plane(k, a, W, H)  # cubic: (gm0, gm1) = (W, H)
+    (ref * cot).sum().backward()
+    b = ops.factor_logical(ops.factor_storage(x).to(DEV)).requires_grad_(True)
+    out = ops.blur_factor(b, k.to(DEV))
+    (out * cot.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-5, rtol=1e-5)
+    assert _rel(b.grad.cpu().numpy(), a.grad.numpy()) < 1e-5
+
+
+def test_blur_line_vs_oracle():
+    from joint_tensorf_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 16, 33, 1, generator=g)
+    cot = torch.randn(1, 16, 33, 1, generator=g)
+    k = O.gaussian_kernel(3.1, 64)
+    a = x.clone().requires_grad_(True)
+    ref = O.blur_line(k, a)
+    (ref * cot).sum().backward()
+    b = ops.factor_logical(ops.factor_storage(x).to(DEV)).requires_grad_(True)
+    out = ops.blur_factor(b, k.to(DEV))
+    (out * cot.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-5, rtol=1e-5)
+    assert _rel(b.grad.cpu().numpy(), a.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["blender_train_mid", "blender_train_sharp", "llff_train_thin_whitebg"])
+def test_march_stage_vs_oracle(name):
+    """sigma_feat / weight / shade list of jt_march_forward against the oracle's intermediates."""
+    from joint_tensorf_amd import ops
+    from joint_tensorf_amd._lib import lib, ptr, check
+    from tests.test_gpu_parity import build_scene
+    fx = Fixture(name)
+    m = fx.meta
+    if m["c2f_mode"] is not None:
+        pytest.skip("sharp fixtures only")
+    cfg = fx.cfg()
+    params = fx.params(requires_grad=False)
+    center, ray = fx.t("mid.center"), fx.t("mid.ray_dir")
+    jitter = fx.t("in.jitter") if m["is_train"] else None
+    _, _, _, aux = O.render(cfg, params, center, ray, m["N_samples"], white_bg=fx.white_bg(), jitter=jitter,
+                            ndc_ray=m["ndc_ray"], return_aux=True)
+    tf = build_scene(fx, DEV, "torch")
+    R, S = center.shape[0], m["N_samples"]
+    g = m["gridSize"]
+    rc = ops.RenderCfg(aabb=m["aabb"], plane_hw=[(g[ops.MAT_MODE[i][1]], g[ops.MAT_MODE[i][0]]) for i in range(3)],
+                       line_len=[g[ops.VEC_MODE[i]] for i in range(3)], n_comp_density=m["density_n_comp"][0],
+                       n_comp_app=m["app_n_comp"][0], step_size=m["stepSize"], near_far=m["near_far"],
+                       distance_scale=m["distance_scale"], density_shift=m["density_shift"],
+                       density_act=0 if m["fea2denseAct"] == "softplus" else 1,
+                       weight_thres=m["rayMarch_weight_thres"], n_samples=S, ndc=m["ndc_ray"], white_bg=fx.white_bg(),
+                       app_dim=m["app_dim"], mlp_kind=tf.renderModule.kind, mlp_hidden=m["featureC"],
+                       view_pe=m["view_pe"], fea_pe=m["fea_pe"])
+    scene = rc.scene()
+    fac = ops._factors_struct([ops.factor_storage(p) for p in tf.density_plane],
+                              [ops.factor_storage(p) for p in tf.density_line],
+                              [ops.factor_storage(p) for p in tf.app_plane],
+                              [ops.factor_storage(p) for p in tf.app_line])
+    f32 = dict(device=DEV, dtype=torch.float32)
+    o, d = center.to(DEV).contiguous(), ray.to(DEV).contiguous()
+    zvals = jit = None
+    if m["ndc_ray"]:
+        zvals = torch.linspace(m["near_far"][0], m["near_far"][1], S)[None]
+        if jitter is not None:
+            zvals = zvals + jitter.view(1, -1) * ((m["near_far"][1] - m["near_far"][0]) / S)
+        zvals = zvals.to(DEV).contiguous()
+    elif jitter is not None:
+        jit = jitter.to(DEV).contiguous().view(-1)
+    sf, w, tmin = torch.empty(R, S, **f32), torch.empty(R, S, **f32), torch.empty(R, **f32)
+    cnt = torch.empty(R, device=DEV, dtype=torch.int32)
+    off = torch.empty(R + 1, device=DEV, dtype=torch.int32)
+    sidx = torch.empty(R, S, device=DEV, dtype=torch.int16)
+    op, dep = torch.empty(R, **f32), torch.empty(R, **f32)
+    check(lib.jt_march_forward(scene, fac, ptr(o), ptr(d), ptr(jit), ptr(zvals), R, ptr(sf), ptr(w), ptr(tmin),
+                               ptr(cnt), ptr(off), ptr(sidx), ptr(op), ptr(dep), None), "march")
+    torch.cuda.synchronize()
+    valid = aux["valid"]
+    ref_feat = torch.zeros(R, S)
+    ref_feat[valid] = aux["sigma_feat"]
+    np.testing.assert_allclose(sf.cpu().numpy()[valid.numpy()], ref_feat.numpy()[valid.numpy()], atol=2e-5, rtol=2e-5)
+    assert np.all(sf.cpu().numpy()[~valid.numpy()] == 0.0)
+    np.testing.assert_allclose(w.cpu().numpy(), aux["weight"].numpy(), atol=2e-6, rtol=2e-5)
+    ref_cnt = aux["app_mask"].sum(-1).to(torch.int32)
+    assert torch.equal(cnt.cpu(), ref_cnt)
+    assert int(off[R]) == int(ref_cnt.sum())
+    sidx_np = sidx.cpu().numpy().view(np.uint16)
+    for r_ in range(R):
+        want = np.nonzero(aux["app_mask"][r_].numpy())[0]
+        assert np.array_equal(sidx_np[r_, :len(want)], want)
