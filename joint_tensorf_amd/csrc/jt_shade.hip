@@ -1,14 +1,1052 @@
-// Fused appearance path on the matrix cores -- placeholder until the MFMA kernels land.
+// Fused appearance path on the CDNA4 matrix cores (fp32-input MFMA, exact f32 numerics):
+//   gather(app planes/lines) -> plane*line products -> basis_mat -> positional encoding -> MLP -> sigmoid
+// for every shaded sample, without materialising the [n][3*Ca] product matrix.
+// Replaces compute_appfeature (bateRF.py:97-130), basis_mat (tensoRF.py:156),
+// MLPRender_Fea.forward (tensorBase.py:116-126) / MLPRender_Fea_WeakView.forward (:198-214).
+//
+// Tiling.  One wavefront owns a tile of 32 consecutive shaded samples.  Every product of the chain is
+// computed TRANSPOSED, D[unit][sample] = W[unit][k] * X[k][sample], with v_mfma_f32_32x32x2_f32:
+// the sample index sits on the lane (lane & 31) for the B operand and for the accumulator, so the
+// accumulator of one layer (16 registers = 16 units of the lane's sample) is directly the B operand
+// of the next layer -- no LDS round trip between layers.  The two lane halves (lane >> 5) supply the
+// two k-slices of each MFMA step; which unit a half supplies in a step is fixed by the accumulator
+// map  row(r, h) = (r & 3) + 8 (r >> 2) + 4 h, and the A operand (weights, read from LDS with an odd
+// row stride => conflict-free) simply reads the matching column.  The gather is split the same way:
+// half h loads the channel quads q with q % 2 == h as 16-byte vectors.
 #include "jt_common.h"
 
-extern "C" size_t jt_shade_workspace_bytes(const JtScene* scene) { return 0; }
+namespace jt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__host__ __device__ constexpr int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct MlpDev {
+  const float* basis;
+  const float* w1;
+  const float* b1;
+  const float* w2;
+  const float* b2;
+  const float* w3;
+  const float* b3;
+};
+
+template <int CA_, int APP_, int HID_, int KIND_>
+struct ShadeCfg {
+  static constexpr int CA = CA_, APP = APP_, HID = HID_, KIND = KIND_;
+  static constexpr int NC = 3 * CA;                                  // basis_mat input width
+  static constexpr int LDB = NC | 1;                                 // odd LDS row stride
+  static constexpr int IN1 = (KIND == JT_MLP_FEA) ? APP * 5 + 15 : APP * 5;  // 150 / 100
+  static constexpr int LD1 = (IN1 + 1) | 1;                          // >= IN1+1: column IN1 is a zero pad
+  static constexpr int MT = HID / 32;                                // M tiles of the hidden layers
+  static constexpr int LD2 = HID | 1;
+  static constexpr int IN3 = (KIND == JT_MLP_FEA) ? HID : HID + 12;  // 64 / 44
+  static constexpr int NSLOT = (CA + 7) / 8;                         // channel-quad slots per half per plane
+  // LDS carve (floats)
+  static constexpr int O_BASIS = 0;
+  static constexpr int O_W1 = O_BASIS + 32 * LDB;
+  static constexpr int O_W2 = O_W1 + HID * LD1;
+  static constexpr int O_W3 = O_W2 + HID * LD2;   // stored [k][4] (c = 0..2, pad)
+  static constexpr int O_B1 = O_W3 + IN3 * 4;
+  static constexpr int O_B2 = O_B1 + HID;
+  static constexpr int O_B3 = O_B2 + HID;
+  static constexpr int LDS_FLOATS = O_B3 + 4;
+  static_assert(HID % 32 == 0 && APP <= 32 && CA % 4 == 0, "shape");
+};
+
+// Column of W1 (torch layout [HID][IN1]) that lane-half h consumes in k-step (r, t), t = 0..4:
+//   t = 0: the raw feature, t = 1..4: its positional encoding [sin x, sin 2x, cos x, cos 2x]
+// (tensorBase.py:43-55: per channel [sin 2^0, sin 2^1, cos 2^0, cos 2^1]).  Feature a = rowmap(r,h) of
+// basis_mat's output lives at column a, its encoding at APP+3 + 4a (MLP_Fea: [f, d, PE(f), PE(d)],
+// tensorBase.py:117-122) or APP + 4a (WeakView: [f, PE(f)], :199-205).  For MLP_Fea the three view
+// direction components ride in the slots of half 1 whose feature row is padding (rows 28..30).
+template <class C>
+__host__ __device__ constexpr int w1_col(int h, int r, int t) {
+  const int a = rowmap(r, h);
+  if (a < C::APP) {
+    if (C::KIND == JT_MLP_FEA) return t == 0 ? a : C::APP + 3 + 4 * a + (t - 1);
+    return t == 0 ? a : C::APP + 4 * a + (t - 1);
+  }
+  if (C::KIND == JT_MLP_FEA && h == 1 && a >= 28 && a <= 30) {
+    const int v = a - 28;
+    return t == 0 ? C::APP + v : C::APP + 3 + 4 * C::APP + 4 * v + (t - 1);
+  }
+  return C::IN1;  // zero pad column
+}
+
+// number of r-steps of layer 1 that carry at least one live half
+template <class C>
+__host__ __device__ constexpr int l1_rsteps() {
+  int n = 0;
+  for (int r = 0; r < 16; ++r)
+    if (w1_col<C>(0, r, 0) != C::IN1 || w1_col<C>(1, r, 0) != C::IN1) n = r + 1;
+  return n;
+}
+
+template <class C>
+__device__ inline void load_weights_lds(float* s, const MlpDev& M) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < 32 * C::LDB; i += nt) {
+    int a = i / C::LDB, c = i - a * C::LDB;
+    s[C::O_BASIS + i] = (a < C::APP && c < C::NC) ? M.basis[a * C::NC + c] : 0.f;
+  }
+  for (int i = tid; i < C::HID * C::LD1; i += nt) {
+    int u = i / C::LD1, c = i - u * C::LD1;
+    s[C::O_W1 + i] = (c < C::IN1) ? M.w1[u * C::IN1 + c] : 0.f;
+  }
+  for (int i = tid; i < C::HID * C::LD2; i += nt) {
+    int u = i / C::LD2, c = i - u * C::LD2;
+    s[C::O_W2 + i] = (c < C::HID) ? M.w2[u * C::HID + c] : 0.f;
+  }
+  for (int i = tid; i < C::IN3 * 4; i += nt) {
+    int k = i >> 2, c = i & 3;
+    s[C::O_W3 + i] = (c < 3) ? M.w3[c * C::IN3 + k] : 0.f;
+  }
+  for (int i = tid; i < C::HID; i += nt) {
+    s[C::O_B1 + i] = M.b1[i];
+    s[C::O_B2 + i] = M.b2[i];
+  }
+  if (tid < 4) s[C::O_B3 + tid] = (tid < 3) ? M.b3[tid] : 0.f;
+}
+
+struct PeMask {
+  float f0, f1, v0, v1;  // (progress*freqs - level) clamped to [0,1], freqs = 2 (tensorBase.py:48)
+};
+
+// Position of entry e: normalised coordinates + taps are recomputed from the ray, exactly as the
+// march kernel did (same expressions => same sample).
+struct EntryGeom {
+  float n[3];
+  float z;
+  int ray;
+};
+
+__device__ inline EntryGeom entry_geom(const Dev& D, const float* rays_o, const float* rays_d, const float* jitter,
+                                       const float* zvals, const float* tmin, const int* eray, const int* esmp,
+                                       int e) {
+  EntryGeom g;
+  g.ray = eray[e];
+  Ray r;
+  load_ray(D, rays_o, rays_d, jitter, tmin, g.ray, r);
+  g.z = sample_z(D, r, zvals, esmp[e]);
+  float p[3];
+  sample_point(D, r, g.z, p);
+  normalize(D, p, g.n);
+  return g;
+}
+
+// ---- stage 1: gather + products + basis_mat  -> feature accumulator (16 regs: rows rowmap(r,h)) -----
+template <class C>
+__device__ inline f32x16 gather_basis(const Dev& D, const float* s, const float n[3], int j, int h) {
+  f32x16 facc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) facc[r] = 0.f;
+  const float* sb = s + C::O_BASIS + j * C::LDB;  // this lane's basis row (A operand: unit a = j)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    PlaneTaps t = plane_taps(n[kM0[i]], n[kM1[i]], D.ph[i], D.pw[i], C::CA);
+    Axis l = axis_taps(n[kV[i]], D.ll[i]);
+    const float* P = D.aP[i];
+    const float* L = D.aL[i];
+#pragma unroll
+    for (int m = 0; m < C::NSLOT; ++m) {
+      const int q = 2 * m + h;
+      const bool live = q * 4 < C::CA;
+      const int c0 = live ? q * 4 : 0;
+      float4 a = ld4(P + t.o00 + c0), b = ld4(P + t.o10 + c0), c = ld4(P + t.o01 + c0), d = ld4(P + t.o11 + c0);
+      float4 u = ld4(L + l.c0 * C::CA + c0), v = ld4(L + l.c1 * C::CA + c0);
+      float pr[4];
+      pr[0] = (t.w00 * a.x + t.w10 * b.x + t.w01 * c.x + t.w11 * d.x) * (l.w0 * u.x + l.w1 * v.x);
+      pr[1] = (t.w00 * a.y + t.w10 * b.y + t.w01 * c.y + t.w11 * d.y) * (l.w0 * u.y + l.w1 * v.y);
+      pr[2] = (t.w00 * a.z + t.w10 * b.z + t.w01 * c.z + t.w11 * d.z) * (l.w0 * u.z + l.w1 * v.z);
+      pr[3] = (t.w00 * a.w + t.w10 * b.w + t.w01 * c.w + t.w11 * d.w) * (l.w0 * u.w + l.w1 * v.w);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float bv = live ? pr[k] : 0.f;
+        float av = sb[i * C::CA + c0 + k];
+        facc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, facc, 0, 0, 0);
+      }
+      if (m & 1) __builtin_amdgcn_sched_barrier(0);  // at most two quad slots of taps in flight
+    }
+  }
+  return facc;
+}
+
+// sin and cos of x in one go: 3-term Cody-Waite reduction by pi/2 and the cephes single-precision minimax
+// kernels on [-pi/4, pi/4] (abs error ~1e-7 for |x| < 1e4; the MLP inputs are O(1) features).
+__device__ inline void sincos_f(float x, float* sn, float* cs) {
+  const float k = rintf(x * 0.636619772367581343f);  // x * 2/pi
+  const int q = (int)k;
+  float y = fmaf(k, -1.5703125f, x);
+  y = fmaf(k, -4.837512969970703125e-4f, y);
+  y = fmaf(k, -7.54978995489188216e-8f, y);
+  const float z = y * y;
+  float s = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, y, y);
+  float c = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                 fmaf(-0.5f, z, 1.f));
+  const float ss = (q & 1) ? c : s;
+  const float cc = (q & 1) ? s : c;
+  *sn = (q & 2) ? -ss : ss;
+  *cs = ((q + 1) & 2) ? -cc : cc;
+}
+
+// the five values (x, PE(x)) lane-half h feeds into layer 1 for accumulator row r:
+//   [x, sin x * m0, sin 2x * m1, cos x * m0, cos 2x * m1]     (tensorBase.py:43-55)
+template <class C>
+__device__ inline void l1_inputs(const f32x16& facc, const float vd[3], const PeMask& pm, int h, int r,
+                                 float out[5]) {
+  const int a0 = rowmap(r, 0), a1 = rowmap(r, 1);
+  const bool feat0 = a0 < C::APP, feat1 = a1 < C::APP;
+  const bool dir1 = (C::KIND == JT_MLP_FEA) && a1 >= 28 && a1 <= 30;
+  float x = facc[r], m0 = pm.f0, m1 = pm.f1;
+  bool live = h ? (feat1 || dir1) : feat0;
+  if (dir1 && h) {
+    x = vd[a1 >= 28 ? a1 - 28 : 0];
+    m0 = pm.v0;
+    m1 = pm.v1;
+  }
+  float sn, cs;
+  sincos_f(x, &sn, &cs);
+  out[0] = live ? x : 0.f;
+  out[1] = live ? sn * m0 : 0.f;
+  out[2] = live ? 2.f * sn * cs * m1 : 0.f;
+  out[3] = live ? cs * m0 : 0.f;
+  out[4] = live ? (1.f - 2.f * sn * sn) * m1 : 0.f;
+}
+
+template <class C>
+struct Hidden {
+  f32x16 v[C::MT];
+};
+
+// ---- layer 1: IN1 -> HID, + bias, ReLU -----------------------------------------------------------------
+template <class C>
+__device__ inline Hidden<C> layer1(const float* s, const f32x16& facc, const float vd[3], const PeMask& pm, int j,
+                                   int h) {
+  Hidden<C> acc;
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc.v[mt][r] = s[C::O_B1 + mt * 32 + rowmap(r, h)];
+  constexpr int RS = l1_rsteps<C>();
+#pragma unroll
+  for (int r = 0; r < RS; ++r) {
+    float in[5];
+    l1_inputs<C>(facc, vd, pm, h, r, in);
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int col = h ? w1_col<C>(1, r, t) : w1_col<C>(0, r, t);
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) {
+        float av = s[C::O_W1 + (mt * 32 + j) * C::LD1 + col];
+        acc.v[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, in[t], acc.v[mt], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the encodings of later rows from being hoisted (VGPR pressure)
+  }
+  return acc;
+}
+
+// ---- layer 2: HID -> HID, + bias (ReLU applied by the caller on input and output) ------------------------
+template <class C>
+__device__ inline Hidden<C> layer2(const float* s, const Hidden<C>& h1, int j, int h) {
+  Hidden<C> acc;
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc.v[mt][r] = s[C::O_B2 + mt * 32 + rowmap(r, h)];
+#pragma unroll
+  for (int mk = 0; mk < C::MT; ++mk) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int col = mk * 32 + rowmap(r, 0) + 4 * h;
+      const float bv = h1.v[mk][r];
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) {
+        float av = s[C::O_W2 + (mt * 32 + j) * C::LD2 + col];
+        acc.v[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc.v[mt], 0, 0, 0);
+      }
+    }
+  }
+  return acc;
+}
+
+template <class C>
+__device__ inline void relu_(Hidden<C>& x) {
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x.v[mt][r] = fmaxf(x.v[mt][r], 0.f);
+}
+
+// view-direction encoding used by the WeakView last layer: [sin d (3x2) , cos d (3x2)] per channel
+__device__ inline void view_pe(const float vd[3], const PeMask& pm, float out[12]) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float sn, cs;
+    sincos_f(vd[a], &sn, &cs);
+    out[4 * a + 0] = sn * pm.v0;
+    out[4 * a + 1] = 2.f * sn * cs * pm.v1;
+    out[4 * a + 2] = cs * pm.v0;
+    out[4 * a + 3] = (1.f - 2.f * sn * sn) * pm.v1;
+  }
+}
+
+// ---- layer 3 (3 outputs): VALU dot over the lane's own units, halves combined with one swap -------------
+template <class C>
+__device__ inline void layer3(const float* s, const Hidden<C>& h2, const float vd[3], const PeMask& pm, int h,
+                              float out[3]) {
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+  constexpr int HOFF = (C::KIND == JT_MLP_FEA) ? 0 : 12;  // WeakView: [PE(d) (12), h (HID)]
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = HOFF + mt * 32 + rowmap(r, 0) + 4 * h;
+      const float4 w = *reinterpret_cast<const float4*>(s + C::O_W3 + k * 4);
+      const float x = h2.v[mt][r];
+      o0 += x * w.x;
+      o1 += x * w.y;
+      o2 += x * w.z;
+    }
+  if (C::KIND != JT_MLP_FEA) {
+    float pe[12];
+    view_pe(vd, pm, pe);
+    if (h == 0) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        const float4 w = *reinterpret_cast<const float4*>(s + C::O_W3 + k * 4);
+        o0 += pe[k] * w.x;
+        o1 += pe[k] * w.y;
+        o2 += pe[k] * w.z;
+      }
+    }
+  }
+  o0 += __shfl_xor(o0, 32);
+  o1 += __shfl_xor(o1, 32);
+  o2 += __shfl_xor(o2, 32);
+  out[0] = o0 + s[C::O_B3 + 0];
+  out[1] = o1 + s[C::O_B3 + 1];
+  out[2] = o2 + s[C::O_B3 + 2];
+}
+
+static inline PeMask pe_masks(float fea_progress, float view_progress, int fea_pe, int view_pe) {
+  PeMask pm;
+  pm.f0 = fminf(fmaxf(fea_progress * fea_pe - 0.f, 0.f), 1.f);
+  pm.f1 = fminf(fmaxf(fea_progress * fea_pe - 1.f, 0.f), 1.f);
+  pm.v0 = fminf(fmaxf(view_progress * view_pe - 0.f, 0.f), 1.f);
+  pm.v1 = fminf(fmaxf(view_progress * view_pe - 1.f, 0.f), 1.f);
+  return pm;
+}
+
+template <class C>
+__global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm, const float* __restrict__ rays_o,
+                                                      const float* __restrict__ rays_d,
+                                                      const float* __restrict__ jitter,
+                                                      const float* __restrict__ zvals,
+                                                      const float* __restrict__ tmin,
+                                                      const int* __restrict__ offset, int R,
+                                                      const int* __restrict__ eray, const int* __restrict__ esmp,
+                                                      const float* __restrict__ vdir, float* __restrict__ rgb_s,
+                                                      int cap) {
+  extern __shared__ __align__(16) float smem[];
+  load_weights_lds<C>(smem, M);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j_ = lane & 31, h_ = lane >> 5;
+  const int total = min(offset[R], cap);
+  const int ntiles = (total + 31) >> 5;
+  for (int tile = blockIdx.x * 4 + wv; tile < ntiles; tile += gridDim.x * 4) {
+    int j = j_, h = h_;  // see k_shade_bwd: keeps per-lane address math from being hoisted out of the loop
+    asm volatile("" : "+v"(j), "+v"(h));
+    const int e = tile * 32 + j;
+    const bool on = e < total;
+    const int ee = on ? e : total - 1;
+    EntryGeom g = entry_geom(D, rays_o, rays_d, jitter, zvals, tmin, eray, esmp, ee);
+    float vd[3] = {vdir[(size_t)ee * 3], vdir[(size_t)ee * 3 + 1], vdir[(size_t)ee * 3 + 2]};
+    f32x16 facc = gather_basis<C>(D, smem, g.n, j, h);
+    Hidden<C> h1 = layer1<C>(smem, facc, vd, pm, j, h);
+    relu_<C>(h1);
+    Hidden<C> h2 = layer2<C>(smem, h1, j, h);
+    relu_<C>(h2);
+    float o[3];
+    layer3<C>(smem, h2, vd, pm, h, o);
+    if (on && h == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rgb_s[(size_t)e * 3 + c] = 1.f / (1.f + expf(-o[c]));
+    }
+  }
+}
+
+
+// =================================================================================================
+// backward
+// =================================================================================================
+// Per tile of 32 samples a wave (1) recomputes the forward, (2) walks the MLP backwards with the same
+// transposed MFMA chain (the gradient w.r.t. a layer's input comes out in exactly the register layout the
+// forward consumed, so the chain rule through ReLU / positional encoding is lane-local), (3) turns the
+// feature gradient into per-channel product gradients (basis_mat^T), hands them through a small LDS tile
+// to a channel-parallel scatter that walks the samples of the tile in ray order and accumulates the four
+// plane corners / two line taps in registers, flushing a texel with ONE float atomic per channel only
+// when the walk leaves it (samples are half a voxel apart, so consecutive samples share texels), and
+// (4) leaves sample-major records (layer inputs / pre-activation gradients) for the weight-gradient
+// kernel k_wgrad, which is a skinny GEMM over the sample axis on the same MFMA instruction.
+
+__device__ inline void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <class C>
+struct BwdCfg {
+  static constexpr int TP_ROWS = (C::HID > 32 || C::CA > 32) ? 64 : 32;
+  static constexpr int TP_LD = 33;
+  static constexpr int WAVE_FLOATS = TP_ROWS * TP_LD + 32 * 4 + 32 * 4;
+  static constexpr int NWAVE = 8;
+  static constexpr int LDS_FLOATS = C::LDS_FLOATS + NWAVE * WAVE_FLOATS;
+  static constexpr int PT = (C::CA + 31) / 32;  // M tiles of one plane's channels in the basis backward
+  // sample-major records handed to k_wgrad (floats per entry)
+  static constexpr int R_G1 = 0;
+  static constexpr int R_G2 = R_G1 + C::HID;
+  static constexpr int R_H1 = R_G2 + C::HID;
+  static constexpr int R_MID = R_H1 + C::HID;
+  static constexpr int R_F = R_MID + C::IN3;
+  static constexpr int R_GF = R_F + 32;
+  static constexpr int R_GO = R_GF + 32;
+  static constexpr int R_PROD = R_GO + 4;
+  static constexpr int REC_FLOATS = R_PROD + C::NC;
+};
+
+// rows = tile*32 + rowmap(r,h), column = sample j  ->  tp[row][j]
+template <int NT>
+__device__ inline void tp_write(float* tp, const f32x16* v, int j, int h) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tp[(t * 32 + rowmap(r, h)) * 33 + j] = v[t][r];
+}
+
+// rec[(e0+s)*ld + col] = tp[col][s] for the tile's live samples; 256-byte contiguous row pieces
+__device__ inline void tp_store_rows(const float* tp, float* rec, size_t ld, int ncols, int e0, int nlive, int lane) {
+  for (int sidx = 0; sidx < nlive; ++sidx)
+    for (int col = lane; col < ncols; col += 64) rec[(size_t)(e0 + sidx) * ld + col] = tp[col * 33 + sidx];
+}
+
+// ---- channel-parallel scatter of one plane's product gradients ------------------------------------------
+// lanes: group = lane >> 4 (4 groups), cl = lane & 15.  Group g walks samples g*8 .. g*8+7 of the tile.
+template <class C>
+__device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, const float* tp, const float* geo,
+                                     float* gxyz, int nlive, int lane) {
+  constexpr int NCH = (C::CA + 15) / 16;
+  const int grp = lane >> 4, cl = lane & 15;
+  const int H = D.ph[pl], W = D.pw[pl], L = D.ll[pl];
+  const float* P = D.aP[pl];
+  const float* Ln = D.aL[pl];
+  float* gP = G.app_plane[pl];
+  float* gL = G.app_line[pl];
+  float acc[4][NCH], accl[2][NCH];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    acc[0][k] = acc[1][k] = acc[2][k] = acc[3][k] = 0.f;
+    accl[0][k] = accl[1][k] = 0.f;
+  }
+  int cx = -1000000, cy = -1000000, cz = -1000000;  // current cell (un-clamped floor indices)
+  auto flush_corner = [&](int i, int jj, float* a) {
+    const int x = cx + i, y = cy + jj;
+    const bool ok = (x >= 0) && (x < W) && (y >= 0) && (y < H);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int c = cl + 16 * k;
+      if (ok && c < C::CA && a[k] != 0.f) atomicAdd(gP + ((size_t)y * W + x) * C::CA + c, a[k]);
+      a[k] = 0.f;
+    }
+  };
+  auto flush_line = [&](int i, float* a) {
+    const int z = cz + i;
+    const bool ok = (z >= 0) && (z < L);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int c = cl + 16 * k;
+      if (ok && c < C::CA && a[k] != 0.f) atomicAdd(gL + (size_t)z * C::CA + c, a[k]);
+      a[k] = 0.f;
+    }
+  };
+  for (int q = 0; q < 8; ++q) {
+    const int sidx = grp * 8 + q;
+    const bool on = sidx < nlive;
+    float n[3] = {geo[sidx * 4], geo[sidx * 4 + 1], geo[sidx * 4 + 2]};
+    PlaneTaps t = plane_taps(n[kM0[pl]], n[kM1[pl]], H, W, C::CA);
+    Axis l = axis_taps(n[kV[pl]], L);
+    if (on) {
+      const int nx = t.ax.i0, ny = t.ay.i0, nz = l.i0;
+      if (nx != cx || ny != cy) {
+        if (ny == cy && nx == cx + 1) {  // step +x: corners (1,*) become (0,*)
+          flush_corner(0, 0, acc[0]);
+          flush_corner(0, 1, acc[2]);
+#pragma unroll
+          for (int k = 0; k < NCH; ++k) {
+            acc[0][k] = acc[1][k];
+            acc[2][k] = acc[3][k];
+            acc[1][k] = acc[3][k] = 0.f;
+          }
+        } else if (ny == cy && nx == cx - 1) {
+          flush_corner(1, 0, acc[1]);
+          flush_corner(1, 1, acc[3]);
+#pragma unroll
+          for (int k = 0; k < NCH; ++k) {
+            acc[1][k] = acc[0][k];
+            acc[3][k] = acc[2][k];
+            acc[0][k] = acc[2][k] = 0.f;
+          }
+        } else if (nx == cx && ny == cy + 1) {
+          flush_corner(0, 0, acc[0]);
+          flush_corner(1, 0, acc[1]);
+#pragma unroll
+          for (int k = 0; k < NCH; ++k) {
+            acc[0][k] = acc[2][k];
+            acc[1][k] = acc[3][k];
+            acc[2][k] = acc[3][k] = 0.f;
+          }
+        } else if (nx == cx && ny == cy - 1) {
+          flush_corner(0, 1, acc[2]);
+          flush_corner(1, 1, acc[3]);
+#pragma unroll
+          for (int k = 0; k < NCH; ++k) {
+            acc[2][k] = acc[0][k];
+            acc[3][k] = acc[1][k];
+            acc[0][k] = acc[1][k] = 0.f;
+          }
+        } else {
+          flush_corner(0, 0, acc[0]);
+          flush_corner(1, 0, acc[1]);
+          flush_corner(0, 1, acc[2]);
+          flush_corner(1, 1, acc[3]);
+        }
+        cx = nx;
+        cy = ny;
+      }
+      if (nz != cz) {
+        if (nz == cz + 1) {
+          flush_line(0, accl[0]);
+#pragma unroll
+          for (int k = 0; k < NCH; ++k) {
+            accl[0][k] = accl[1][k];
+            accl[1][k] = 0.f;
+          }
+        } else if (nz == cz - 1) {
+          flush_line(1, accl[1]);
+#pragma unroll
+          for (int k = 0; k < NCH; ++k) {
+            accl[1][k] = accl[0][k];
+            accl[0][k] = 0.f;
+          }
+        } else {
+          flush_line(0, accl[0]);
+          flush_line(1, accl[1]);
+        }
+        cz = nz;
+      }
+    }
+    float aix = 0.f, aiy = 0.f, ail = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int c = cl + 16 * k;
+      const bool cv = c < C::CA;
+      const int cc = cv ? c : 0;
+      float a = P[t.o00 + cc], b = P[t.o10 + cc], cq = P[t.o01 + cc], d = P[t.o11 + cc];
+      float u = Ln[l.c0 * C::CA + cc], v = Ln[l.c1 * C::CA + cc];
+      float pv = t.w00 * a + t.w10 * b + t.w01 * cq + t.w11 * d;
+      float lv = l.w0 * u + l.w1 * v;
+      float g = (on && cv) ? tp[cc * 33 + sidx] : 0.f;
+      float gpv = g * lv, glv = g * pv;
+      acc[0][k] += t.w00 * gpv;
+      acc[1][k] += t.w10 * gpv;
+      acc[2][k] += t.w01 * gpv;
+      acc[3][k] += t.w11 * gpv;
+      accl[0][k] += l.w0 * glv;
+      accl[1][k] += l.w1 * glv;
+      float a_ = a * t.ax.m0 * t.ay.m0, b_ = b * t.ax.m1 * t.ay.m0, c_ = cq * t.ax.m0 * t.ay.m1,
+            d_ = d * t.ax.m1 * t.ay.m1;
+      aix += gpv * ((b_ - a_) * (1.f - t.ay.f) + (d_ - c_) * t.ay.f);
+      aiy += gpv * ((c_ - a_) * (1.f - t.ax.f) + (d_ - b_) * t.ax.f);
+      ail += glv * (v * l.m1 - u * l.m0);
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      aix += __shfl_xor(aix, o);
+      aiy += __shfl_xor(aiy, o);
+      ail += __shfl_xor(ail, o);
+    }
+    if (on && cl == 0) {
+      gxyz[sidx * 4 + kM0[pl]] += aix * t.ax.scale * D.inv[kM0[pl]];
+      gxyz[sidx * 4 + kM1[pl]] += aiy * t.ay.scale * D.inv[kM1[pl]];
+      gxyz[sidx * 4 + kV[pl]] += ail * l.scale * D.inv[kV[pl]];
+    }
+  }
+  flush_corner(0, 0, acc[0]);
+  flush_corner(1, 0, acc[1]);
+  flush_corner(0, 1, acc[2]);
+  flush_corner(1, 1, acc[3]);
+  flush_line(0, accl[0]);
+  flush_line(1, accl[1]);
+}
+
+template <class C>
+__global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm, JtFactors G,
+                                                      const float* __restrict__ rays_o,
+                                                      const float* __restrict__ rays_d,
+                                                      const float* __restrict__ jitter,
+                                                      const float* __restrict__ zvals,
+                                                      const float* __restrict__ tmin,
+                                                      const int* __restrict__ offset, int R,
+                                                      const int* __restrict__ eray, const int* __restrict__ esmp,
+                                                      const float* __restrict__ vdir,
+                                                      const float* __restrict__ g_rgb_s, float* __restrict__ g_xyz,
+                                                      float* __restrict__ rec, int chunk_start, int chunk_cap,
+                                                      int cap) {
+  typedef BwdCfg<C> B;
+  extern __shared__ __align__(16) float smem[];
+  load_weights_lds<C>(smem, M);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j_ = lane & 31, h_ = lane >> 5;
+  float* tp = smem + C::LDS_FLOATS + wv * B::WAVE_FLOATS;
+  float* geo = tp + B::TP_ROWS * B::TP_LD;
+  float* gxyz = geo + 32 * 4;
+  const int total = min(offset[R], cap);
+  const int n_chunk = min(total - chunk_start, chunk_cap);
+  const int ntiles = (n_chunk + 31) >> 5;
+  const size_t RC = B::REC_FLOATS;
+  for (int tile = blockIdx.x * B::NWAVE + wv; tile < ntiles; tile += gridDim.x * B::NWAVE) {
+    // re-materialise the lane indices per tile: otherwise every per-lane LDS address / select that depends
+    // on them is hoisted out of the tile loop as a loop invariant and the kernel spills hundreds of VGPRs
+    int j = j_, h = h_;
+    asm volatile("" : "+v"(j), "+v"(h));
+    const int l0 = tile * 32;                // first record row of the tile (chunk-local)
+    const int e = chunk_start + l0 + j;      // global entry of this lane's sample
+    const int nlive = min(32, n_chunk - l0);
+    const bool on = j < nlive;
+    const int ee = on ? e : chunk_start + l0 + nlive - 1;
+    EntryGeom g = entry_geom(D, rays_o, rays_d, jitter, zvals, tmin, eray, esmp, ee);
+    float vd[3] = {vdir[(size_t)ee * 3], vdir[(size_t)ee * 3 + 1], vdir[(size_t)ee * 3 + 2]};
+    if (h == 0) {
+      geo[j * 4 + 0] = g.n[0];
+      geo[j * 4 + 1] = g.n[1];
+      geo[j * 4 + 2] = g.n[2];
+      gxyz[j * 4 + 0] = gxyz[j * 4 + 1] = gxyz[j * 4 + 2] = 0.f;
+    }
+    // ---- forward recompute; the plane*line products go out as the PROD record, plane by plane ----
+    f32x16 facc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) facc[r] = 0.f;
+    {
+      const float* sb = smem + C::O_BASIS + j * C::LDB;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        PlaneTaps t = plane_taps(g.n[kM0[i]], g.n[kM1[i]], D.ph[i], D.pw[i], C::CA);
+        Axis l = axis_taps(g.n[kV[i]], D.ll[i]);
+        const float* P = D.aP[i];
+        const float* L = D.aL[i];
+#pragma unroll
+        for (int m = 0; m < C::NSLOT; ++m) {
+          const int q = 2 * m + h;
+          const bool live = q * 4 < C::CA;
+          const int c0 = live ? q * 4 : 0;
+          float4 a = ld4(P + t.o00 + c0), b = ld4(P + t.o10 + c0), c = ld4(P + t.o01 + c0), d = ld4(P + t.o11 + c0);
+          float4 u = ld4(L + l.c0 * C::CA + c0), v = ld4(L + l.c1 * C::CA + c0);
+          float pr[4];
+          pr[0] = (t.w00 * a.x + t.w10 * b.x + t.w01 * c.x + t.w11 * d.x) * (l.w0 * u.x + l.w1 * v.x);
+          pr[1] = (t.w00 * a.y + t.w10 * b.y + t.w01 * c.y + t.w11 * d.y) * (l.w0 * u.y + l.w1 * v.y);
+          pr[2] = (t.w00 * a.z + t.w10 * b.z + t.w01 * c.z + t.w11 * d.z) * (l.w0 * u.z + l.w1 * v.z);
+          pr[3] = (t.w00 * a.w + t.w10 * b.w + t.w01 * c.w + t.w11 * d.w) * (l.w0 * u.w + l.w1 * v.w);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float bv = live ? pr[k] : 0.f;
+            if (live) tp[(c0 + k) * 33 + j] = pr[k];
+            float av = sb[i * C::CA + c0 + k];
+            facc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, facc, 0, 0, 0);
+          }
+          if (m & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        wave_lds_sync();
+        tp_store_rows(tp, rec + B::R_PROD + i * C::CA, RC, C::CA, l0, nlive, lane);
+        wave_lds_sync();
+      }
+    }
+    Hidden<C> h1 = layer1<C>(smem, facc, vd, pm, j, h);
+    relu_<C>(h1);
+    Hidden<C> h2 = layer2<C>(smem, h1, j, h);
+    relu_<C>(h2);
+    float o[3];
+    layer3<C>(smem, h2, vd, pm, h, o);
+    // ---- output layer backward (VALU) ----
+    float go[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float rgb = 1.f / (1.f + expf(-o[c]));
+      go[c] = on ? g_rgb_s[(size_t)e * 3 + c] * rgb * (1.f - rgb) : 0.f;
+    }
+    if (on && h == 0) {
+      float4 gq = make_float4(go[0], go[1], go[2], 0.f);
+      *reinterpret_cast<float4*>(rec + (size_t)(l0 + j) * RC + B::R_GO) = gq;
+    }
+    constexpr int HOFF = (C::KIND == JT_MLP_FEA) ? 0 : 12;
+    Hidden<C> G2;
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = HOFF + mt * 32 + rowmap(r, 0) + 4 * h;
+        const float4 w = *reinterpret_cast<const float4*>(smem + C::O_W3 + k * 4);
+        float gsum = go[0] * w.x + go[1] * w.y + go[2] * w.z;
+        G2.v[mt][r] = (h2.v[mt][r] > 0.f) ? gsum : 0.f;
+      }
+    // records: MID = [PE(d)] + relu(h2), G2
+    tp_write<C::MT>(tp, h2.v, j, h);
+    wave_lds_sync();
+    tp_store_rows(tp, rec + B::R_MID + HOFF, RC, C::HID, l0, nlive, lane);
+    wave_lds_sync();
+    if (C::KIND != JT_MLP_FEA) {
+      float pe[12];
+      view_pe(vd, pm, pe);
+      if (on && h == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) rec[(size_t)(l0 + j) * RC + B::R_MID + k] = pe[k];
+      }
+    }
+    tp_write<C::MT>(tp, G2.v, j, h);
+    wave_lds_sync();
+    tp_store_rows(tp, rec + B::R_G2, RC, C::HID, l0, nlive, lane);
+    wave_lds_sync();
+    // ---- layer 2 backward: g_h1[k] = sum_i W2[i][k] G2[i] ; masked by relu(h1) ----
+    Hidden<C> G1;
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) G1.v[mt][r] = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < C::MT; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int irow = mi * 32 + rowmap(r, 0) + 4 * h;  // unit i this half supplies
+        const float bv = G2.v[mi][r];
+#pragma unroll
+        for (int mk = 0; mk < C::MT; ++mk) {
+          float av = smem[C::O_W2 + irow * C::LD2 + mk * 32 + j];
+          G1.v[mk] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, G1.v[mk], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) G1.v[mt][r] = (h1.v[mt][r] > 0.f) ? G1.v[mt][r] : 0.f;
+    tp_write<C::MT>(tp, h1.v, j, h);
+    wave_lds_sync();
+    tp_store_rows(tp, rec + B::R_H1, RC, C::HID, l0, nlive, lane);
+    wave_lds_sync();
+    tp_write<C::MT>(tp, G1.v, j, h);
+    wave_lds_sync();
+    tp_store_rows(tp, rec + B::R_G1, RC, C::HID, l0, nlive, lane);
+    wave_lds_sync();
+    // ---- layer 1 backward, one M tile per encoding slot t: row rowmap(r,h) of tile t is the gradient of the
+    //      very value this lane fed forward in k-step (r, t)  =>  chain rule through the encoding is lane-local
+    f32x16 gf;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gf[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      // column of W1 for output row m = j of tile t (feature rows only; view-direction inputs are detached)
+      int col;
+      if (j < C::APP) {
+        if (C::KIND == JT_MLP_FEA) col = (t == 0) ? j : C::APP + 3 + 4 * j + (t - 1);
+        else col = (t == 0) ? j : C::APP + 4 * j + (t - 1);
+      } else {
+        col = C::IN1;
+      }
+      f32x16 gin;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gin[r] = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < C::MT; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int irow = mi * 32 + rowmap(r, 0) + 4 * h;
+          float av = smem[C::O_W1 + irow * C::LD1 + col];
+          gin = __builtin_amdgcn_mfma_f32_32x32x2f32(av, G1.v[mi][r], gin, 0, 0, 0);
+        }
+      }
+      // d/dx of [x, sin x m0, sin 2x m1, cos x m0, cos 2x m1]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (rowmap(r, 0) >= C::APP && rowmap(r, 1) >= C::APP) continue;
+        float x = facc[r];
+        float sn, cs;
+        sincos_f(x, &sn, &cs);
+        float dv;
+        if (t == 0) dv = 1.f;
+        else if (t == 1) dv = cs * pm.f0;
+        else if (t == 2) dv = 2.f * (1.f - 2.f * sn * sn) * pm.f1;
+        else if (t == 3) dv = -sn * pm.f0;
+        else dv = -4.f * sn * cs * pm.f1;
+        gf[r] += gin[r] * dv;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (rowmap(r, 0) + 4 * h >= C::APP) gf[r] = 0.f;
+    // records: F (basis_mat output) and GF
+    tp_write<1>(tp, &facc, j, h);
+    wave_lds_sync();
+    tp_store_rows(tp, rec + B::R_F, RC, 32, l0, nlive, lane);
+    wave_lds_sync();
+    tp_write<1>(tp, &gf, j, h);
+    wave_lds_sync();
+    tp_store_rows(tp, rec + B::R_GF, RC, 32, l0, nlive, lane);
+    wave_lds_sync();
+    // ---- basis_mat^T and the scatter, plane by plane ----
+#pragma unroll 1
+    for (int pl = 0; pl < 3; ++pl) {
+      f32x16 gp[B::PT];
+#pragma unroll
+      for (int T = 0; T < B::PT; ++T) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gp[T][r] = 0.f;
+        const int ch = T * 32 + j;
+        const int col = (ch < C::CA) ? pl * C::CA + ch : C::NC;  // NC = zero pad column
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int arow = rowmap(r, 0) + 4 * h;
+          float av = smem[C::O_BASIS + arow * C::LDB + col];
+          gp[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, gf[r], gp[T], 0, 0, 0);
+        }
+      }
+      // tp[channel][sample]
+#pragma unroll
+      for (int T = 0; T < B::PT; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ch = T * 32 + rowmap(r, 0) + 4 * h;
+          if (ch < C::CA) tp[ch * 33 + j] = gp[T][r];
+        }
+      wave_lds_sync();
+      scatter_plane<C>(D, G, pl, tp, geo, gxyz, nlive, lane);
+      wave_lds_sync();
+    }
+    if (on && h == 0) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) g_xyz[(size_t)e * 3 + a] = gxyz[j * 4 + a];
+    }
+    wave_lds_sync();
+  }
+}
+
+// ---- weight gradients: dW[m][n] += sum_p A[p][m] * B[p][n],  db[m] += sum_p A[p][m] ------------------------
+// A skinny GEMM over the sample axis with v_mfma_f32_32x32x2_f32: the two lane halves take two consecutive
+// samples per step, lane & 31 is the unit index for both operands (coalesced 128-byte row reads).
+// XF = 1 / 2 builds the layer-1 input row [f, d, PE(f), PE(d)] / [f, PE(f)] on the fly from the F record.
+template <int MT, int NT, int XF>
+__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int M, const float* __restrict__ Bm,
+                                               int N, size_t ld, const float* __restrict__ vdir, PeMask pm, int APP,
+                                               const int* __restrict__ offset, int R, int cap, int chunk_start,
+                                               int chunk_cap, float* __restrict__ dW, int ldw,
+                                               float* __restrict__ db) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int m = lane & 31, h = lane >> 5;
+  const int total = min(offset[R], cap);
+  const int n = min(total - chunk_start, chunk_cap);
+  if (n <= 0) return;
+  const int nwaves = gridDim.x * 4;
+  const int per = (((n + nwaves - 1) / nwaves) + 1) & ~1;  // even number of samples per wave
+  const int w = blockIdx.x * 4 + wv;
+  const int p_begin = w * per, p_end = min(p_begin + per, n);
+  f32x16 acc[MT][NT];
+  float asum[MT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+    asum[a] = 0.f;
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  }
+  // per-lane description of the layer-1 input column n = nt*32 + m
+  for (int p0 = p_begin; p0 < p_end; p0 += 2) {
+    const int p = p0 + h;
+    const bool ok = p < p_end;
+    const size_t row = (size_t)(ok ? p : p_begin) * ld;
+    float av[MT], bv[NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+      const int c = a * 32 + m;
+      av[a] = (ok && c < M) ? A[row + c] : 0.f;
+      asum[a] += av[a];
+    }
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      const int c = b * 32 + m;
+      float v = 0.f;
+      if (XF == 0) {
+        v = (ok && c < N) ? Bm[row + c] : 0.f;
+      } else {
+        // source scalar x and which function of it this column holds
+        int src = -1, fn = 0;
+        bool view = false;
+        const int npe = 4 * APP;
+        if (c < APP) { src = c; fn = 0; }
+        else if (XF == 1 && c < APP + 3) { src = c - APP; fn = 0; view = true; }
+        else {
+          const int base = (XF == 1) ? APP + 3 : APP;
+          if (c < base + npe) { src = (c - base) >> 2; fn = 1 + ((c - base) & 3); }
+          else if (XF == 1 && c < base + npe + 12) { src = (c - base - npe) >> 2; fn = 1 + ((c - base - npe) & 3); view = true; }
+        }
+        if (ok && src >= 0 && c < N) {
+          const size_t e = (size_t)(chunk_start + p);
+          float x = view ? vdir[e * 3 + src] : Bm[row + src];
+          float sn, cs;
+          sincos_f(x, &sn, &cs);
+          const float m0 = view ? pm.v0 : pm.f0, m1 = view ? pm.v1 : pm.f1;
+          v = (fn == 0) ? x : (fn == 1) ? sn * m0 : (fn == 2) ? 2.f * sn * cs * m1 : (fn == 3) ? cs * m0
+                                                                                               : (1.f - 2.f * sn * sn) * m1;
+        }
+      }
+      bv[b] = v;
+    }
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+  }
+  // epilogue: D[i][k], i = a*32 + rowmap(r,h), k = b*32 + m  (128-byte contiguous atomics per half)
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = a * 32 + rowmap(r, 0) + 4 * h, k = b * 32 + m;
+        if (i < M && k < N && acc[a][b][r] != 0.f) atomicAdd(dW + (size_t)i * ldw + k, acc[a][b][r]);
+      }
+    if (db) {
+      float sacc = asum[a] + __shfl_xor(asum[a], 32);
+      const int i = a * 32 + m;
+      if (h == 0 && i < M && sacc != 0.f) atomicAdd(db + i, sacc);
+    }
+  }
+}
+
+}  // namespace jt
+
+using namespace jt;
+
+typedef ShadeCfg<48, 27, 64, JT_MLP_FEA> CfgBlender;     // bat_blender_VM: VM-48, MLP_Fea 150->64->64->3
+typedef ShadeCfg<20, 20, 32, JT_MLP_WEAKVIEW> CfgLlff;   // bat_llff_VM_MLP: VM-20, WeakView 100->32->32, 44->3
+
+static int shade_kind(const JtScene* s) {
+  if (!s) return -1;
+  if (s->view_pe != 2 || s->fea_pe != 2) return -1;
+  if (s->n_comp_app == 48 && s->app_dim == 27 && s->mlp_hidden == 64 && s->mlp_kind == JT_MLP_FEA) return 0;
+  if (s->n_comp_app == 20 && s->app_dim == 20 && s->mlp_hidden == 32 && s->mlp_kind == JT_MLP_WEAKVIEW) return 1;
+  return -1;
+}
+
+// workspace = sample-major records of one chunk of shaded samples (consumed by k_wgrad right after the
+// chunk's backward kernel, so with the default chunk they never leave the 256 MiB Infinity Cache)
+static const int kChunkEntries = 96 * 1024;
+
+extern "C" size_t jt_shade_workspace_bytes(const JtScene* scene) {
+  const int kind = shade_kind(scene);
+  if (kind < 0) return 0;
+  const size_t rec = (kind == 0) ? BwdCfg<CfgBlender>::REC_FLOATS : BwdCfg<CfgLlff>::REC_FLOATS;
+  return rec * sizeof(float) * kChunkEntries;
+}
+
+template <class C>
+static int launch_shade_fwd(const Dev& D, const MlpDev& M, const PeMask& pm, const float* rays_o,
+                            const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
+                            const int32_t* offset, int R, const int32_t* eray, const int32_t* esmp,
+                            const float* vdir, float* rgb_s, int cap, hipStream_t st) {
+  const size_t lds = C::LDS_FLOATS * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_fwd<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  long tiles = ((long)cap + 31) / 32;
+  int blocks = (int)std::min<long>((tiles + 3) / 4, 512);
+  hipLaunchKernelGGL(k_shade_fwd<C>, dim3(blocks), dim3(256), lds, st, D, M, pm, rays_o, rays_d, jitter, zvals, tmin,
+                     offset, R, eray, esmp, vdir, rgb_s, cap);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
 
 extern "C" int jt_shade_forward(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp, const float* rays_o,
                                 const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
                                 const int32_t* shade_offset, int n_rays, const int32_t* entry_ray,
                                 const int32_t* entry_smp, const float* viewdirs, float* rgb_s, int n_entries_max,
                                 void* workspace, size_t workspace_bytes, void* stream) {
-  return JT_ERR_UNSUPPORTED;
+  Dev D;
+  int rc = make_dev(scene, factors, &D);
+  if (rc) return rc;
+  if (!factors || !mlp || !rays_o || !rays_d || !tmin || !shade_offset || !entry_ray || !entry_smp || !viewdirs ||
+      !rgb_s)
+    return JT_ERR_ARG;
+  if (!mlp->basis || !mlp->w1 || !mlp->b1 || !mlp->w2 || !mlp->b2 || !mlp->w3 || !mlp->b3) return JT_ERR_ARG;
+  if (D.ndc && !zvals) return JT_ERR_ARG;
+  const int kind = shade_kind(scene);
+  if (kind < 0) return JT_ERR_UNSUPPORTED;
+  if (n_entries_max < 1) return JT_OK;
+  MlpDev M = {mlp->basis, mlp->w1, mlp->b1, mlp->w2, mlp->b2, mlp->w3, mlp->b3};
+  PeMask pm = pe_masks(scene->fea_pe_progress, scene->view_pe_progress, scene->fea_pe, scene->view_pe);
+  hipStream_t st = (hipStream_t)stream;
+  if (kind == 0)
+    return launch_shade_fwd<CfgBlender>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, shade_offset, n_rays,
+                                        entry_ray, entry_smp, viewdirs, rgb_s, n_entries_max, st);
+  return launch_shade_fwd<CfgLlff>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, shade_offset, n_rays, entry_ray,
+                                   entry_smp, viewdirs, rgb_s, n_entries_max, st);
+}
+
+template <class C>
+static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, const JtFactors& G, const JtMlp& GM,
+                            const float* rays_o, const float* rays_d, const float* jitter, const float* zvals,
+                            const float* tmin, const int32_t* offset, int R, const int32_t* eray,
+                            const int32_t* esmp, const float* vdir, const float* g_rgb_s, float* g_xyz, int cap,
+                            float* rec, size_t rec_bytes, hipStream_t st) {
+  typedef BwdCfg<C> B;
+  const size_t lds = B::LDS_FLOATS * sizeof(float);
+  if (lds > 160 * 1024) return JT_ERR_UNSUPPORTED;
+  int chunk = (int)std::min<size_t>(rec_bytes / (B::REC_FLOATS * sizeof(float)), (size_t)cap);
+  chunk &= ~31;
+  if (chunk < 32) return JT_ERR_ARG;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_bwd<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  const size_t RC = B::REC_FLOATS;
+  const int wg_blocks = 256;
+  for (int start = 0; start < cap; start += chunk) {
+    const int ccap = std::min(chunk, cap - start);
+    long tiles = ((long)ccap + 31) / 32;
+    int blocks = (int)std::min<long>((tiles + B::NWAVE - 1) / B::NWAVE, 256);
+    hipLaunchKernelGGL(k_shade_bwd<C>, dim3(blocks), dim3(512), lds, st, D, M, pm, G, rays_o, rays_d, jitter, zvals,
+                       tmin, offset, R, eray, esmp, vdir, g_rgb_s, g_xyz, rec, start, ccap, cap);
+    JT_LAUNCH_CHECK();
+    // dW3/db3 = GO^T MID ; dW2/db2 = G2^T H1 ; dW1/db1 = G1^T X(F, d) ; dBasis = GF^T PROD
+    constexpr int NT3 = (C::IN3 + 31) / 32, NT1 = (C::IN1 + 31) / 32, NTB = (C::NC + 31) / 32;
+    hipLaunchKernelGGL((k_wgrad<1, NT3, 0>), dim3(wg_blocks), dim3(256), 0, st, rec + B::R_GO, 3, rec + B::R_MID,
+                       C::IN3, RC, vdir, pm, C::APP, offset, R, cap, start, ccap, GM.w3, C::IN3, GM.b3);
+    JT_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_wgrad<C::MT, C::MT, 0>), dim3(wg_blocks), dim3(256), 0, st, rec + B::R_G2, C::HID,
+                       rec + B::R_H1, C::HID, RC, vdir, pm, C::APP, offset, R, cap, start, ccap, GM.w2, C::HID,
+                       GM.b2);
+    JT_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_wgrad<C::MT, NT1, (C::KIND == JT_MLP_FEA ? 1 : 2)>), dim3(wg_blocks), dim3(256), 0, st,
+                       rec + B::R_G1, C::HID, rec + B::R_F, C::IN1, RC, vdir, pm, C::APP, offset, R, cap, start, ccap,
+                       GM.w1, C::IN1, GM.b1);
+    JT_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_wgrad<1, NTB, 0>), dim3(wg_blocks), dim3(256), 0, st, rec + B::R_GF, C::APP,
+                       rec + B::R_PROD, C::NC, RC, vdir, pm, C::APP, offset, R, cap, start, ccap, GM.basis, C::NC,
+                       (float*)nullptr);
+    JT_LAUNCH_CHECK();
+  }
+  return JT_OK;
 }
 
 extern "C" int jt_shade_backward(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp,
@@ -18,5 +1056,30 @@ extern "C" int jt_shade_backward(const JtScene* scene, const JtFactors* factors,
                                  const float* g_rgb_s, const JtFactors* g_factors, const JtMlp* g_mlp,
                                  float* g_xyz_app, int n_entries_max, void* workspace, size_t workspace_bytes,
                                  void* stream) {
-  return JT_ERR_UNSUPPORTED;
+  Dev D;
+  int rc = make_dev(scene, factors, &D);
+  if (rc) return rc;
+  if (!factors || !mlp || !g_factors || !g_mlp || !rays_o || !rays_d || !tmin || !shade_offset || !entry_ray ||
+      !entry_smp || !viewdirs || !g_rgb_s || !g_xyz_app)
+    return JT_ERR_ARG;
+  if (!mlp->basis || !mlp->w1 || !mlp->b1 || !mlp->w2 || !mlp->b2 || !mlp->w3 || !mlp->b3) return JT_ERR_ARG;
+  if (!g_mlp->basis || !g_mlp->w1 || !g_mlp->b1 || !g_mlp->w2 || !g_mlp->b2 || !g_mlp->w3 || !g_mlp->b3)
+    return JT_ERR_ARG;
+  for (int a = 0; a < 3; ++a)
+    if (!g_factors->app_plane[a] || !g_factors->app_line[a]) return JT_ERR_ARG;
+  if (D.ndc && !zvals) return JT_ERR_ARG;
+  const int kind = shade_kind(scene);
+  if (kind < 0) return JT_ERR_UNSUPPORTED;
+  if (n_entries_max < 1) return JT_OK;
+  if (!workspace) return JT_ERR_ARG;
+  MlpDev M = {mlp->basis, mlp->w1, mlp->b1, mlp->w2, mlp->b2, mlp->w3, mlp->b3};
+  PeMask pm = pe_masks(scene->fea_pe_progress, scene->view_pe_progress, scene->fea_pe, scene->view_pe);
+  hipStream_t st = (hipStream_t)stream;
+  if (kind == 0)
+    return launch_shade_bwd<CfgBlender>(D, M, pm, *g_factors, *g_mlp, rays_o, rays_d, jitter, zvals, tmin,
+                                        shade_offset, n_rays, entry_ray, entry_smp, viewdirs, g_rgb_s, g_xyz_app,
+                                        n_entries_max, (float*)workspace, workspace_bytes, st);
+  return launch_shade_bwd<CfgLlff>(D, M, pm, *g_factors, *g_mlp, rays_o, rays_d, jitter, zvals, tmin, shade_offset,
+                                   n_rays, entry_ray, entry_smp, viewdirs, g_rgb_s, g_xyz_app, n_entries_max,
+                                   (float*)workspace, workspace_bytes, st);
 }

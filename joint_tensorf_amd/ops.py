@@ -195,7 +195,6 @@ class RenderRays(torch.autograd.Function):
         check(lib.jt_shade_list(scene, ptr(rays_d), R, ptr(offset), ptr(sidx), ptr(eray), ptr(esmp), ptr(vdir),
                                 cap, st), "jt_shade_list")
         rgb_s = torch.empty(cap_alloc, 3, **f32)
-        ws = None
         if cfg.shade_impl == "torch":
             prod = torch.empty(cap_alloc, 3 * cfg.n_comp_app, **f32)
             check(lib.jt_app_gather_forward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
@@ -206,18 +205,15 @@ class RenderRays(torch.autograd.Function):
                     rgb_s[:n] = _torch_shade(cfg, prod[:n], vdir[:n], *mlp_t)
             ctx.prod = prod
         else:
-            nbytes = lib.jt_shade_workspace_bytes(scene)
-            ws = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8)
             mlp = _mlp_struct(*mlp_t)
             check(lib.jt_shade_forward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
                                        ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(rgb_s),
-                                       cap, ptr(ws), nbytes, st), "jt_shade_forward")
+                                       cap, None, 0, st), "jt_shade_forward")
         rgb = torch.empty(R, 3, **f32)
         cmask = torch.empty(R, device=dev, dtype=torch.int32)
         check(lib.jt_composite_forward(scene, R, ptr(offset), ptr(sidx), ptr(weight), ptr(rgb_s), ptr(opacity),
                                        ptr(rgb), ptr(cmask), st), "jt_composite_forward")
         ctx.cfg, ctx.n, ctx.cap = cfg, n, cap
-        ctx.ws = ws
         ctx.saved = (rays_o, rays_d, jitter, zvals, sdp, sdl, sap, sal, mlp_t, sigma_feat, weight, tmin, offset,
                      sidx, eray, esmp, vdir, rgb_s, cmask)
         ctx.param_shapes = [tuple(p.shape) for p in params]
@@ -269,10 +265,12 @@ class RenderRays(torch.autograd.Function):
             g_mlp = [torch.zeros_like(t) for t in mlp_t]
             mlp = _mlp_struct(*mlp_t)
             gm = _mlp_struct(*g_mlp)
-            nbytes = ctx.ws.numel()
+            # records of one chunk of shaded samples (consumed by the weight-gradient GEMMs chunk by chunk)
+            nbytes = lib.jt_shade_workspace_bytes(scene)
+            ws = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8)
             check(lib.jt_shade_backward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
                                         ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(g_rgb_s),
-                                        gfac, gm, ptr(g_xyz), cap, ptr(ctx.ws), nbytes, st), "jt_shade_backward")
+                                        gfac, gm, ptr(g_xyz), cap, ptr(ws), nbytes, st), "jt_shade_backward")
         g_o = torch.empty(R, 3, **f32)
         g_d = torch.empty(R, 3, **f32)
         check(lib.jt_march_backward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals), R,

@@ -101,7 +101,7 @@ def _supported(fx):
 
 
 @pytest.mark.parametrize("name", CASES)
-@pytest.mark.parametrize("shade_impl", ["torch"])
+@pytest.mark.parametrize("shade_impl", ["mfma", "torch"])
 def test_hip_vs_golden_and_oracle(name, shade_impl):
     fx = Fixture(name)
     if not _supported(fx):
