@@ -170,7 +170,8 @@ int jt_composite_forward(const JtScene* scene, int n_rays, const int32_t* shade_
  * jt_app_gather_backward: g_prod [n][3*Ca] -> += g_factors.app_*, g_xyz_app [n][3] (overwritten).
  * jt_march_backward: density + transmittance backward:
  *   += g_factors.density_*; g_rays_o, g_rays_d [R][3] overwritten (include the app path's
- *   coordinate gradients read from g_xyz_app).  g_opacity [R] may be NULL. */
+ *   coordinate gradients read from g_xyz_app).  g_opacity [R] may be NULL.  workspace: caller-provided,
+ *   jt_march_backward_workspace_bytes(scene, n_rays) bytes (per-sample density gradients + run lists). */
 int jt_composite_backward(const JtScene* scene, int n_rays, const int32_t* shade_offset,
                           const int32_t* entry_ray, const int32_t* entry_smp, const float* weight,
                           const int32_t* clamp_mask, const float* g_rgb, float* g_rgb_s, int n_entries_max,
@@ -185,7 +186,9 @@ int jt_march_backward(const JtScene* scene, const JtFactors* factors, const floa
                       const float* weight, const float* tmin, const int32_t* shade_offset,
                       const uint16_t* shade_idx, const float* rgb_s, const int32_t* clamp_mask,
                       const float* g_rgb, const float* g_opacity, const float* g_xyz_app,
-                      const JtFactors* g_factors, float* g_rays_o, float* g_rays_d, void* stream);
+                      const JtFactors* g_factors, float* g_rays_o, float* g_rays_d, void* workspace,
+                      size_t workspace_bytes, void* stream);
+size_t jt_march_backward_workspace_bytes(const JtScene* scene, int n_rays);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused appearance path on the matrix cores (fp32 MFMA, exact-f32 numerics):

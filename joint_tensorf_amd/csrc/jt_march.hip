@@ -2,6 +2,7 @@
 // and their backward.  One 64-lane wavefront owns one ray; lanes stride over the ray's samples so
 // the transmittance product is a wave prefix scan with a carry between 64-sample chunks.
 #include "jt_common.h"
+#include "jt_walk.h"
 
 namespace jt {
 
@@ -230,31 +231,36 @@ __global__ __launch_bounds__(256) void k_composite_bwd(Dev D, const int* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// march backward.  Per ray (one wave):
+// march backward, two launches.
+//
+// k_march_bwd_scan -- one wave per ray:
 //   A (forward order)  alpha_i, T_i from the stored sigma_feat; G_i = dL/dw_i
-//   B (reverse order)  suffix sums -> dL/dalpha_i -> dL/dsigma_feat_i ; list of in-box samples
-//   C (channel-parallel, 4 samples x 16 channels per wave instruction) re-gather the density taps,
-//     scatter-add plane/line gradients as 64-byte-contiguous float atomics per texel, reduce the
-//     coordinate gradients over the channel lanes
-//   D  add the appearance path's coordinate gradients of the ray's shaded samples
-// LDS per wave: 3 float arrays + 1 u16 array of S entries.
+//   B (reverse order)  suffix sums -> dL/dalpha_i -> dL/dsigma_feat_i, written to gfeat[R][S]; the in-box
+//                      samples with a non-zero gradient are listed in vlist[R][S] (ascending), nvalid[R]
+//   D                  the appearance path's coordinate gradients of the ray's shaded samples and the NDC
+//                      |d| term seed g_rays_o / g_rays_d
+// k_march_bwd_walk -- one 16-lane group per run of 32 listed samples (lane = density channel):
+//   re-gathers the density taps of the three planes, run-length scatters the plane / line gradients
+//   (jt_walk.h) and adds the run's coordinate gradients to g_rays_o / g_rays_d.
+// LDS of the scan kernel per wave: 3 float arrays of S entries.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_march_bwd(Dev D, JtFactors G, const float* __restrict__ rays_o,
-                                                   const float* __restrict__ rays_d,
-                                                   const float* __restrict__ jitter,
-                                                   const float* __restrict__ zvals, int R,
-                                                   const float* __restrict__ sigma_feat,
-                                                   const float* __restrict__ weight,
-                                                   const float* __restrict__ tmin_in,
-                                                   const int* __restrict__ offset,
-                                                   const uint16_t* __restrict__ sidx,
-                                                   const float* __restrict__ rgb_s,
-                                                   const int* __restrict__ clamp_mask,
-                                                   const float* __restrict__ g_rgb,
-                                                   const float* __restrict__ g_opacity,
-                                                   const float* __restrict__ g_xyz_app,
-                                                   float* __restrict__ g_rays_o, float* __restrict__ g_rays_d,
-                                                   int Spad) {
+__global__ __launch_bounds__(256) void k_march_bwd_scan(Dev D, const float* __restrict__ rays_o,
+                                                        const float* __restrict__ rays_d,
+                                                        const float* __restrict__ jitter,
+                                                        const float* __restrict__ zvals, int R,
+                                                        const float* __restrict__ sigma_feat,
+                                                        const float* __restrict__ weight,
+                                                        const float* __restrict__ tmin_in,
+                                                        const int* __restrict__ offset,
+                                                        const uint16_t* __restrict__ sidx,
+                                                        const float* __restrict__ rgb_s,
+                                                        const int* __restrict__ clamp_mask,
+                                                        const float* __restrict__ g_rgb,
+                                                        const float* __restrict__ g_opacity,
+                                                        const float* __restrict__ g_xyz_app,
+                                                        float* __restrict__ gfeat, uint16_t* __restrict__ vlist,
+                                                        int* __restrict__ nvalid_out, float* __restrict__ g_rays_o,
+                                                        float* __restrict__ g_rays_d, int Spad) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -262,9 +268,7 @@ __global__ __launch_bounds__(256) void k_march_bwd(Dev D, JtFactors G, const flo
   if (ray >= R) return;
   float* s_alpha = reinterpret_cast<float*>(smem) + (size_t)wv * 3 * Spad;
   float* s_T = s_alpha + Spad;
-  float* s_G = s_T + Spad;  // G_i, later g_feat_i
-  uint16_t* s_list = reinterpret_cast<uint16_t*>(reinterpret_cast<float*>(smem) + (size_t)4 * 3 * Spad) +
-                     (size_t)wv * Spad;
+  float* s_G = s_T + Spad;
 
   Ray r;
   load_ray(D, rays_o, rays_d, jitter, tmin_in, ray, r);
@@ -320,9 +324,7 @@ __global__ __launch_bounds__(256) void k_march_bwd(Dev D, JtFactors G, const flo
   // ---- pass B (reverse) ----
   float suffix = 0.f;  // sum_{j>i} G_j w_j carried from later chunks
   float gnorm = 0.f;   // NDC: dL/d|d|
-  int nvalid = 0;
   const int nchunk = (S + 63) / 64;
-  // in-box samples are listed in DEscending chunk order; order is irrelevant for the sums
   for (int c = nchunk - 1; c >= 0; --c) {
     const int i = c * 64 + lane;
     const bool live = i < S;
@@ -339,8 +341,7 @@ __global__ __launch_bounds__(256) void k_march_bwd(Dev D, JtFactors G, const flo
       feat = sigma_feat[row + i];
     }
     float v = live ? Gw * (alpha * T) : 0.f;
-    // inclusive suffix scan over lanes
-    float inc = v;
+    float inc = v;  // inclusive suffix scan over lanes
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       float t = __shfl_down(inc, o);
@@ -352,7 +353,6 @@ __global__ __launch_bounds__(256) void k_march_bwd(Dev D, JtFactors G, const flo
     suffix += __shfl(inc, 0);
     float f = 1.f - alpha + 1e-10f;
     float g_alpha = Gw * T - after / f;
-    // alpha = 1 - exp(-sigma*delta*scale)
     float one_m = 1.f - alpha;  // = exp(-sigma delta scale)
     float dsc = delta * D.dist_scale;
     float g_sigma = g_alpha * dsc * one_m;
@@ -364,77 +364,22 @@ __global__ __launch_bounds__(256) void k_march_bwd(Dev D, JtFactors G, const flo
       float dz = (r.norm > 0.f) ? delta / r.norm : 0.f;
       gnorm += g_alpha * sigma * dz * D.dist_scale * one_m;
     }
-    if (live) s_G[i] = g_feat;
-    const bool keep = live && valid && (g_feat != 0.f);
+    if (live) {
+      gfeat[row + i] = g_feat;
+      s_G[i] = g_feat;
+    }
+  }
+  // ascending list of the samples that carry a density gradient
+  int nvalid = 0;
+  for (int base = 0; base < S; base += 64) {
+    const int i = base + lane;
+    const bool keep = (i < S) && (s_G[i] != 0.f);
     unsigned long long bal = __ballot(keep);
-    if (keep) s_list[nvalid + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
+    if (keep) vlist[row + nvalid + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
     nvalid += __popcll(bal);
   }
-  // ---- pass C: channel-parallel density backward ----
-  const int C = D.Cd;
-  const int sub = lane >> 4, ch = lane & 15;
-  float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < nvalid; k0 += 4) {
-    const int k = k0 + sub;
-    const bool on = k < nvalid;
-    const int i = on ? s_list[k] : 0;
-    const float g = on ? s_G[i] : 0.f;
-    const float z = sample_z(D, r, zvals, i);
-    float p[3], n[3];
-    sample_point(D, r, z, p);
-    normalize(D, p, n);
-    float gn[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-      PlaneTaps t = plane_taps(n[kM0[pl]], n[kM1[pl]], D.ph[pl], D.pw[pl], C);
-      Axis l = axis_taps(n[kV[pl]], D.ll[pl]);
-      const float* P = D.dP[pl];
-      const float* L = D.dL[pl];
-      float* gP = G.density_plane[pl];
-      float* gL = G.density_line[pl];
-      float aix = 0.f, aiy = 0.f, ail = 0.f;
-      for (int cq = ch; cq < C; cq += 16) {
-        float a = P[t.o00 + cq], b = P[t.o10 + cq], c = P[t.o01 + cq], d = P[t.o11 + cq];
-        float u = L[l.c0 * C + cq], v = L[l.c1 * C + cq];
-        float pv = t.w00 * a + t.w10 * b + t.w01 * c + t.w11 * d;
-        float lv = l.w0 * u + l.w1 * v;
-        float gpv = g * lv, glv = g * pv;
-        if (on) {
-          if (t.w00 != 0.f) atomicAdd(gP + t.o00 + cq, t.w00 * gpv);
-          if (t.w10 != 0.f) atomicAdd(gP + t.o10 + cq, t.w10 * gpv);
-          if (t.w01 != 0.f) atomicAdd(gP + t.o01 + cq, t.w01 * gpv);
-          if (t.w11 != 0.f) atomicAdd(gP + t.o11 + cq, t.w11 * gpv);
-          if (l.w0 != 0.f) atomicAdd(gL + l.c0 * C + cq, l.w0 * glv);
-          if (l.w1 != 0.f) atomicAdd(gL + l.c1 * C + cq, l.w1 * glv);
-        }
-        // d pv / d ix, d pv / d iy with out-of-range taps treated as zeros (grid_sampler backward)
-        float a_ = a * t.ax.m0 * t.ay.m0, b_ = b * t.ax.m1 * t.ay.m0, c_ = c * t.ax.m0 * t.ay.m1,
-              d_ = d * t.ax.m1 * t.ay.m1;
-        float fy = t.ay.f, fx = t.ax.f;
-        aix += gpv * ((b_ - a_) * (1.f - fy) + (d_ - c_) * fy);
-        aiy += gpv * ((c_ - a_) * (1.f - fx) + (d_ - b_) * fx);
-        ail += glv * (v * l.m1 - u * l.m0);
-      }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        aix += __shfl_xor(aix, o);
-        aiy += __shfl_xor(aiy, o);
-        ail += __shfl_xor(ail, o);
-      }
-      gn[kM0[pl]] += aix * t.ax.scale;
-      gn[kM1[pl]] += aiy * t.ay.scale;
-      gn[kV[pl]] += ail * l.scale;
-    }
-    if (on && ch == 0) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        float gx = gn[a] * D.inv[a];
-        go[a] += gx;
-        gd[a] += gx * z;
-      }
-    }
-  }
   // ---- pass D: appearance coordinate gradients of this ray's shaded samples ----
+  float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
   const int n = offset[ray + 1] - off;
   if (g_xyz_app) {
     for (int k = lane; k < n; k += 64) {
@@ -455,6 +400,7 @@ __global__ __launch_bounds__(256) void k_march_bwd(Dev D, JtFactors G, const flo
     gd[a] = wave_sum(gd[a]);
   }
   if (lane == 0) {
+    nvalid_out[ray] = nvalid;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       float g = gd[a];
@@ -463,6 +409,98 @@ __global__ __launch_bounds__(256) void k_march_bwd(Dev D, JtFactors G, const flo
       g_rays_d[ray * 3 + a] = g;
     }
   }
+}
+
+constexpr int kWalkRun = 32;  // listed samples per 16-lane group
+
+template <int CD>
+__global__ __launch_bounds__(256) void k_march_bwd_walk(Dev D, JtFactors G, const float* __restrict__ rays_o,
+                                                        const float* __restrict__ rays_d,
+                                                        const float* __restrict__ jitter,
+                                                        const float* __restrict__ zvals,
+                                                        const float* __restrict__ tmin_in, int R,
+                                                        const float* __restrict__ gfeat,
+                                                        const uint16_t* __restrict__ vlist,
+                                                        const int* __restrict__ nvalid, int runs_per_ray,
+                                                        float* __restrict__ g_rays_o, float* __restrict__ g_rays_d) {
+  constexpr int NCH = (CD + 15) / 16;
+  const int cl = threadIdx.x & 15;
+  const long item = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int ray = (int)(item / runs_per_ray);
+  const int run = (int)(item - (long)ray * runs_per_ray);
+  if (ray >= R) return;
+  const int nv = nvalid[ray];
+  const int k0 = run * kWalkRun;
+  if (k0 >= nv) return;
+  const int k1 = min(k0 + kWalkRun, nv);
+  Ray r;
+  load_ray(D, rays_o, rays_d, jitter, tmin_in, ray, r);
+  const size_t row = (size_t)ray * D.S;
+  PlaneWalker<NCH, CD> wk[3];
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) wk[pl].init(G.density_plane[pl], G.density_line[pl], D.ph[pl], D.pw[pl], D.ll[pl], cl);
+  TapVals<NCH> cur[3], nxt[3];
+  float zc, zn = 0.f, gc, gn = 0.f;
+  {
+    const int i = vlist[row + k0];
+    zc = sample_z(D, r, zvals, i);
+    gc = gfeat[row + i];
+    float p[3], n[3];
+    sample_point(D, r, zc, p);
+    normalize(D, p, n);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      tap_load<NCH, CD>(cur[pl], D.dP[pl], D.dL[pl], n[kM0[pl]], n[kM1[pl]], n[kV[pl]], D.ph[pl], D.pw[pl], D.ll[pl], cl);
+  }
+  float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+  for (int k = k0; k < k1; ++k) {
+    if (k + 1 < k1) {  // prefetch the next listed sample
+      const int i = vlist[row + k + 1];
+      zn = sample_z(D, r, zvals, i);
+      gn = gfeat[row + i];
+      float p[3], n[3];
+      sample_point(D, r, zn, p);
+      normalize(D, p, n);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        tap_load<NCH, CD>(nxt[pl], D.dP[pl], D.dL[pl], n[kM0[pl]], n[kM1[pl]], n[kV[pl]], D.ph[pl], D.pw[pl], D.ll[pl],
+                          cl);
+    }
+    float gn3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      wk[pl].advance(cur[pl].t.ax.i0, cur[pl].t.ay.i0, cur[pl].l.i0);
+      float g[NCH];
+#pragma unroll
+      for (int q = 0; q < NCH; ++q) g[q] = (cl + 16 * q < CD) ? gc : 0.f;
+      float aix = 0.f, aiy = 0.f, ail = 0.f;
+      wk[pl].add(cur[pl], g, aix, aiy, ail);
+      gn3[kM0[pl]] += aix * cur[pl].t.ax.scale;
+      gn3[kM1[pl]] += aiy * cur[pl].t.ay.scale;
+      gn3[kV[pl]] += ail * cur[pl].l.scale;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float gx = gn3[a] * D.inv[a];  // per-lane partial (its channels); reduced over the group at the end
+      go[a] += gx;
+      gd[a] += gx * zc;
+    }
+    if (k + 1 < k1) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) cur[pl] = nxt[pl];
+      zc = zn;
+      gc = gn;
+    }
+  }
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) wk[pl].finish();
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    go[a] = group16_sum(go[a]);
+    gd[a] = group16_sum(gd[a]);
+  }
+  if (cl < 3) atomicAdd(g_rays_o + ray * 3 + cl, cl == 0 ? go[0] : cl == 1 ? go[1] : go[2]);
+  else if (cl < 6) atomicAdd(g_rays_d + ray * 3 + (cl - 3), cl == 3 ? gd[0] : cl == 4 ? gd[1] : gd[2]);
 }
 
 }  // namespace jt
@@ -543,31 +581,74 @@ extern "C" int jt_composite_backward(const JtScene* scene, int n_rays, const int
   return JT_OK;
 }
 
+static size_t march_bwd_ws_layout(int S, int R, size_t* o_vlist, size_t* o_nvalid) {
+  size_t off = 0;
+  off += (size_t)R * S * sizeof(float);                 // gfeat
+  off = (off + 255) & ~(size_t)255;
+  *o_vlist = off;
+  off += (size_t)R * S * sizeof(uint16_t);
+  off = (off + 255) & ~(size_t)255;
+  *o_nvalid = off;
+  off += (size_t)R * sizeof(int);
+  return (off + 255) & ~(size_t)255;
+}
+
+extern "C" size_t jt_march_backward_workspace_bytes(const JtScene* scene, int n_rays) {
+  if (!scene || n_rays < 1 || scene->n_samples < 1) return 0;
+  size_t a, b;
+  return march_bwd_ws_layout(scene->n_samples, n_rays, &a, &b);
+}
+
 extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors, const float* rays_o,
                                  const float* rays_d, const float* jitter, const float* zvals, int n_rays,
                                  const float* sigma_feat, const float* weight, const float* tmin,
                                  const int32_t* shade_offset, const uint16_t* shade_idx, const float* rgb_s,
                                  const int32_t* clamp_mask, const float* g_rgb, const float* g_opacity,
                                  const float* g_xyz_app, const JtFactors* g_factors, float* g_rays_o,
-                                 float* g_rays_d, void* stream) {
+                                 float* g_rays_d, void* workspace, size_t workspace_bytes, void* stream) {
   Dev D;
   int rc = make_dev(scene, factors, &D);
   if (rc) return rc;
   if (!factors || !g_factors || !rays_o || !rays_d || !sigma_feat || !weight || !tmin || !shade_offset ||
-      !shade_idx || !clamp_mask || !g_rgb || !g_rays_o || !g_rays_d || n_rays < 1)
+      !shade_idx || !clamp_mask || !g_rgb || !g_rays_o || !g_rays_d || !workspace || n_rays < 1)
     return JT_ERR_ARG;
   for (int a = 0; a < 3; ++a)
     if (!g_factors->density_plane[a] || !g_factors->density_line[a]) return JT_ERR_ARG;
   if (D.ndc && !zvals) return JT_ERR_ARG;
   if ((rc = check_density_shape(D))) return rc;
+  size_t o_vlist, o_nvalid;
+  if (workspace_bytes < march_bwd_ws_layout(D.S, n_rays, &o_vlist, &o_nvalid)) return JT_ERR_ARG;
+  float* gfeat = reinterpret_cast<float*>(workspace);
+  uint16_t* vlist = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + o_vlist);
+  int* nvalid = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + o_nvalid);
   const int Spad = (D.S + 63) & ~63;
-  const size_t lds = (size_t)4 * 3 * Spad * sizeof(float) + (size_t)4 * Spad * sizeof(uint16_t);
+  const size_t lds = (size_t)4 * 3 * Spad * sizeof(float);
   if (lds > 160 * 1024) return JT_ERR_UNSUPPORTED;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                      (int)lds);
-  hipLaunchKernelGGL(k_march_bwd, dim3((n_rays + 3) / 4), dim3(256), lds, (hipStream_t)stream, D, *g_factors,
-                     rays_o, rays_d, jitter, zvals, n_rays, sigma_feat, weight, tmin, shade_offset, shade_idx,
-                     rgb_s, clamp_mask, g_rgb, g_opacity, g_xyz_app, g_rays_o, g_rays_d, Spad);
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_bwd_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  hipLaunchKernelGGL(k_march_bwd_scan, dim3((n_rays + 3) / 4), dim3(256), lds, st, D, rays_o, rays_d, jitter, zvals,
+                     n_rays, sigma_feat, weight, tmin, shade_offset, shade_idx, rgb_s, clamp_mask, g_rgb, g_opacity,
+                     g_xyz_app, gfeat, vlist, nvalid, g_rays_o, g_rays_d, Spad);
+  JT_LAUNCH_CHECK();
+  const int runs = (D.S + kWalkRun - 1) / kWalkRun;
+  const long items = (long)n_rays * runs;
+  const int blocks = (int)((items + 15) / 16);
+  if (D.Cd <= 16) {
+    if (D.Cd == 16)
+      hipLaunchKernelGGL(k_march_bwd_walk<16>, dim3(blocks), dim3(256), 0, st, D, *g_factors, rays_o, rays_d, jitter,
+                         zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d);
+    else if (D.Cd == 8)
+      hipLaunchKernelGGL(k_march_bwd_walk<8>, dim3(blocks), dim3(256), 0, st, D, *g_factors, rays_o, rays_d, jitter,
+                         zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d);
+    else
+      return JT_ERR_UNSUPPORTED;
+  } else if (D.Cd == 32) {
+    hipLaunchKernelGGL(k_march_bwd_walk<32>, dim3(blocks), dim3(256), 0, st, D, *g_factors, rays_o, rays_d, jitter,
+                       zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d);
+  } else {
+    return JT_ERR_UNSUPPORTED;
+  }
   JT_LAUNCH_CHECK();
   return JT_OK;
 }

@@ -14,6 +14,7 @@
 // row stride => conflict-free) simply reads the matching column.  The gather is split the same way:
 // half h loads the channel quads q with q % 2 == h as 16-byte vectors.
 #include "jt_common.h"
+#include "jt_walk.h"
 
 namespace jt {
 
@@ -350,12 +351,13 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
                                                       const float* __restrict__ vdir, float* __restrict__ rgb_s,
                                                       int cap) {
   extern __shared__ __align__(16) float smem[];
+  const int total = min(offset[R], cap);
+  const int ntiles = (total + 31) >> 5;
+  if ((int)blockIdx.x * 4 >= ntiles) return;
   load_weights_lds<C>(smem, M);
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j_ = lane & 31, h_ = lane >> 5;
-  const int total = min(offset[R], cap);
-  const int ntiles = (total + 31) >> 5;
   for (int tile = blockIdx.x * 4 + wv; tile < ntiles; tile += gridDim.x * 4) {
     int j = j_, h = h_;  // see k_shade_bwd: keeps per-lane address math from being hoisted out of the loop
     asm volatile("" : "+v"(j), "+v"(h));
@@ -434,7 +436,8 @@ __device__ inline void tp_store_rows(const float* tp, float* rec, size_t ld, int
 }
 
 // ---- channel-parallel scatter of one plane's product gradients ------------------------------------------
-// lanes: group = lane >> 4 (4 groups), cl = lane & 15.  Group g walks samples g*8 .. g*8+7 of the tile.
+// lanes: group = lane >> 4 (4 groups), cl = lane & 15.  Group g walks samples g*8 .. g*8+7 of the tile in
+// order (jt_walk.h); the taps of the next sample are loaded while the current one is accumulated.
 template <class C>
 __device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, const float* tp, const float* geo,
                                      float* gxyz, int nlive, int lane) {
@@ -443,153 +446,42 @@ __device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, c
   const int H = D.ph[pl], W = D.pw[pl], L = D.ll[pl];
   const float* P = D.aP[pl];
   const float* Ln = D.aL[pl];
-  float* gP = G.app_plane[pl];
-  float* gL = G.app_line[pl];
-  float acc[4][NCH], accl[2][NCH];
-#pragma unroll
-  for (int k = 0; k < NCH; ++k) {
-    acc[0][k] = acc[1][k] = acc[2][k] = acc[3][k] = 0.f;
-    accl[0][k] = accl[1][k] = 0.f;
+  PlaneWalker<NCH, C::CA> wk;
+  wk.init(G.app_plane[pl], G.app_line[pl], H, W, L, cl);
+  const int m0 = kM0[pl], m1 = kM1[pl], mv = kV[pl];
+  TapVals<NCH> cur, nxt;
+  {
+    const float* n = geo + (grp * 8) * 4;
+    tap_load<NCH, C::CA>(cur, P, Ln, n[m0], n[m1], n[mv], H, W, L, cl);
   }
-  int cx = -1000000, cy = -1000000, cz = -1000000;  // current cell (un-clamped floor indices)
-  auto flush_corner = [&](int i, int jj, float* a) {
-    const int x = cx + i, y = cy + jj;
-    const bool ok = (x >= 0) && (x < W) && (y >= 0) && (y < H);
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-      const int c = cl + 16 * k;
-      if (ok && c < C::CA && a[k] != 0.f) atomicAdd(gP + ((size_t)y * W + x) * C::CA + c, a[k]);
-      a[k] = 0.f;
-    }
-  };
-  auto flush_line = [&](int i, float* a) {
-    const int z = cz + i;
-    const bool ok = (z >= 0) && (z < L);
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-      const int c = cl + 16 * k;
-      if (ok && c < C::CA && a[k] != 0.f) atomicAdd(gL + (size_t)z * C::CA + c, a[k]);
-      a[k] = 0.f;
-    }
-  };
   for (int q = 0; q < 8; ++q) {
     const int sidx = grp * 8 + q;
     const bool on = sidx < nlive;
-    float n[3] = {geo[sidx * 4], geo[sidx * 4 + 1], geo[sidx * 4 + 2]};
-    PlaneTaps t = plane_taps(n[kM0[pl]], n[kM1[pl]], H, W, C::CA);
-    Axis l = axis_taps(n[kV[pl]], L);
-    if (on) {
-      const int nx = t.ax.i0, ny = t.ay.i0, nz = l.i0;
-      if (nx != cx || ny != cy) {
-        if (ny == cy && nx == cx + 1) {  // step +x: corners (1,*) become (0,*)
-          flush_corner(0, 0, acc[0]);
-          flush_corner(0, 1, acc[2]);
-#pragma unroll
-          for (int k = 0; k < NCH; ++k) {
-            acc[0][k] = acc[1][k];
-            acc[2][k] = acc[3][k];
-            acc[1][k] = acc[3][k] = 0.f;
-          }
-        } else if (ny == cy && nx == cx - 1) {
-          flush_corner(1, 0, acc[1]);
-          flush_corner(1, 1, acc[3]);
-#pragma unroll
-          for (int k = 0; k < NCH; ++k) {
-            acc[1][k] = acc[0][k];
-            acc[3][k] = acc[2][k];
-            acc[0][k] = acc[2][k] = 0.f;
-          }
-        } else if (nx == cx && ny == cy + 1) {
-          flush_corner(0, 0, acc[0]);
-          flush_corner(1, 0, acc[1]);
-#pragma unroll
-          for (int k = 0; k < NCH; ++k) {
-            acc[0][k] = acc[2][k];
-            acc[1][k] = acc[3][k];
-            acc[2][k] = acc[3][k] = 0.f;
-          }
-        } else if (nx == cx && ny == cy - 1) {
-          flush_corner(0, 1, acc[2]);
-          flush_corner(1, 1, acc[3]);
-#pragma unroll
-          for (int k = 0; k < NCH; ++k) {
-            acc[2][k] = acc[0][k];
-            acc[3][k] = acc[1][k];
-            acc[0][k] = acc[1][k] = 0.f;
-          }
-        } else {
-          flush_corner(0, 0, acc[0]);
-          flush_corner(1, 0, acc[1]);
-          flush_corner(0, 1, acc[2]);
-          flush_corner(1, 1, acc[3]);
-        }
-        cx = nx;
-        cy = ny;
-      }
-      if (nz != cz) {
-        if (nz == cz + 1) {
-          flush_line(0, accl[0]);
-#pragma unroll
-          for (int k = 0; k < NCH; ++k) {
-            accl[0][k] = accl[1][k];
-            accl[1][k] = 0.f;
-          }
-        } else if (nz == cz - 1) {
-          flush_line(1, accl[1]);
-#pragma unroll
-          for (int k = 0; k < NCH; ++k) {
-            accl[1][k] = accl[0][k];
-            accl[0][k] = 0.f;
-          }
-        } else {
-          flush_line(0, accl[0]);
-          flush_line(1, accl[1]);
-        }
-        cz = nz;
-      }
+    if (q < 7) {
+      const float* n = geo + (sidx + 1) * 4;
+      tap_load<NCH, C::CA>(nxt, P, Ln, n[m0], n[m1], n[mv], H, W, L, cl);
     }
-    float aix = 0.f, aiy = 0.f, ail = 0.f;
+    if (on) wk.advance(cur.t.ax.i0, cur.t.ay.i0, cur.l.i0);
+    float g[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const int c = cl + 16 * k;
-      const bool cv = c < C::CA;
-      const int cc = cv ? c : 0;
-      float a = P[t.o00 + cc], b = P[t.o10 + cc], cq = P[t.o01 + cc], d = P[t.o11 + cc];
-      float u = Ln[l.c0 * C::CA + cc], v = Ln[l.c1 * C::CA + cc];
-      float pv = t.w00 * a + t.w10 * b + t.w01 * cq + t.w11 * d;
-      float lv = l.w0 * u + l.w1 * v;
-      float g = (on && cv) ? tp[cc * 33 + sidx] : 0.f;
-      float gpv = g * lv, glv = g * pv;
-      acc[0][k] += t.w00 * gpv;
-      acc[1][k] += t.w10 * gpv;
-      acc[2][k] += t.w01 * gpv;
-      acc[3][k] += t.w11 * gpv;
-      accl[0][k] += l.w0 * glv;
-      accl[1][k] += l.w1 * glv;
-      float a_ = a * t.ax.m0 * t.ay.m0, b_ = b * t.ax.m1 * t.ay.m0, c_ = cq * t.ax.m0 * t.ay.m1,
-            d_ = d * t.ax.m1 * t.ay.m1;
-      aix += gpv * ((b_ - a_) * (1.f - t.ay.f) + (d_ - c_) * t.ay.f);
-      aiy += gpv * ((c_ - a_) * (1.f - t.ax.f) + (d_ - b_) * t.ax.f);
-      ail += glv * (v * l.m1 - u * l.m0);
+      g[k] = (on && c < C::CA) ? tp[c * 33 + sidx] : 0.f;
     }
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-      aix += __shfl_xor(aix, o);
-      aiy += __shfl_xor(aiy, o);
-      ail += __shfl_xor(ail, o);
-    }
+    float aix = 0.f, aiy = 0.f, ail = 0.f;
+    wk.add(cur, g, aix, aiy, ail);
+    aix = group16_sum(aix);
+    aiy = group16_sum(aiy);
+    ail = group16_sum(ail);
     if (on && cl == 0) {
-      gxyz[sidx * 4 + kM0[pl]] += aix * t.ax.scale * D.inv[kM0[pl]];
-      gxyz[sidx * 4 + kM1[pl]] += aiy * t.ay.scale * D.inv[kM1[pl]];
-      gxyz[sidx * 4 + kV[pl]] += ail * l.scale * D.inv[kV[pl]];
+      gxyz[sidx * 4 + m0] += aix * cur.t.ax.scale * D.inv[m0];
+      gxyz[sidx * 4 + m1] += aiy * cur.t.ay.scale * D.inv[m1];
+      gxyz[sidx * 4 + mv] += ail * cur.l.scale * D.inv[mv];
     }
+    if (q < 7) cur = nxt;
   }
-  flush_corner(0, 0, acc[0]);
-  flush_corner(1, 0, acc[1]);
-  flush_corner(0, 1, acc[2]);
-  flush_corner(1, 1, acc[3]);
-  flush_line(0, accl[0]);
-  flush_line(1, accl[1]);
+  wk.finish();
 }
 
 template <class C>
@@ -607,6 +499,10 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
                                                       int cap) {
   typedef BwdCfg<C> B;
   extern __shared__ __align__(16) float smem[];
+  const int total = min(offset[R], cap);
+  const int n_chunk = min(total - chunk_start, chunk_cap);
+  const int ntiles = (n_chunk + 31) >> 5;
+  if ((int)blockIdx.x * B::NWAVE >= ntiles) return;  // chunk beyond the shaded samples: nothing to do
   load_weights_lds<C>(smem, M);
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -614,9 +510,6 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
   float* tp = smem + C::LDS_FLOATS + wv * B::WAVE_FLOATS;
   float* geo = tp + B::TP_ROWS * B::TP_LD;
   float* gxyz = geo + 32 * 4;
-  const int total = min(offset[R], cap);
-  const int n_chunk = min(total - chunk_start, chunk_cap);
-  const int ntiles = (n_chunk + 31) >> 5;
   const size_t RC = B::REC_FLOATS;
   for (int tile = blockIdx.x * B::NWAVE + wv; tile < ntiles; tile += gridDim.x * B::NWAVE) {
     // re-materialise the lane indices per tile: otherwise every per-lane LDS address / select that depends
@@ -847,21 +740,55 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
 // A skinny GEMM over the sample axis with v_mfma_f32_32x32x2_f32: the two lane halves take two consecutive
 // samples per step, lane & 31 is the unit index for both operands (coalesced 128-byte row reads).
 // XF = 1 / 2 builds the layer-1 input row [f, d, PE(f), PE(d)] / [f, PE(f)] on the fly from the F record.
+template <int XF>
+__device__ inline float wgrad_b_value(const float* __restrict__ Bm, size_t row, int c, int N, bool ok,
+                                      const float* __restrict__ vdir, size_t e, const PeMask& pm, int APP) {
+  if (XF == 0) return (ok && c < N) ? Bm[row + c] : 0.f;
+  // layer-1 input column c: which scalar x it derives from and which function of x it is
+  int src = -1, fn = 0;
+  bool view = false;
+  const int npe = 4 * APP;
+  if (c < APP) {
+    src = c;
+  } else if (XF == 1 && c < APP + 3) {
+    src = c - APP;
+    view = true;
+  } else {
+    const int base = (XF == 1) ? APP + 3 : APP;
+    if (c < base + npe) {
+      src = (c - base) >> 2;
+      fn = 1 + ((c - base) & 3);
+    } else if (XF == 1 && c < base + npe + 12) {
+      src = (c - base - npe) >> 2;
+      fn = 1 + ((c - base - npe) & 3);
+      view = true;
+    }
+  }
+  if (!(ok && src >= 0 && c < N)) return 0.f;
+  const float x = view ? vdir[e * 3 + src] : Bm[row + src];
+  float sn, cs;
+  sincos_f(x, &sn, &cs);
+  const float m0 = view ? pm.v0 : pm.f0, m1 = view ? pm.v1 : pm.f1;
+  return (fn == 0) ? x : (fn == 1) ? sn * m0 : (fn == 2) ? 2.f * sn * cs * m1 : (fn == 3) ? cs * m0
+                                                                                         : (1.f - 2.f * sn * sn) * m1;
+}
+
 template <int MT, int NT, int XF>
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int M, const float* __restrict__ Bm,
                                                int N, size_t ld, const float* __restrict__ vdir, PeMask pm, int APP,
                                                const int* __restrict__ offset, int R, int cap, int chunk_start,
                                                int chunk_cap, float* __restrict__ dW, int ldw,
                                                float* __restrict__ db) {
+  __shared__ float s_red[4][16][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int m = lane & 31, h = lane >> 5;
   const int total = min(offset[R], cap);
   const int n = min(total - chunk_start, chunk_cap);
   if (n <= 0) return;
   const int nwaves = gridDim.x * 4;
-  const int per = (((n + nwaves - 1) / nwaves) + 1) & ~1;  // even number of samples per wave
+  const int per = (((n + nwaves - 1) / nwaves) + 7) & ~7;  // multiple of 8 samples per wave
   const int w = blockIdx.x * 4 + wv;
-  const int p_begin = w * per, p_end = min(p_begin + per, n);
+  const int p_begin = min(w * per, n), p_end = min(p_begin + per, n);
   f32x16 acc[MT][NT];
   float asum[MT];
 #pragma unroll
@@ -872,63 +799,51 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   }
-  // per-lane description of the layer-1 input column n = nt*32 + m
-  for (int p0 = p_begin; p0 < p_end; p0 += 2) {
-    const int p = p0 + h;
-    const bool ok = p < p_end;
-    const size_t row = (size_t)(ok ? p : p_begin) * ld;
-    float av[MT], bv[NT];
+  constexpr int U = 4;  // steps (sample pairs) whose loads are issued together
+  for (int p0 = p_begin; p0 < p_end; p0 += 2 * U) {
+    float av[U][MT], bv[U][NT];
 #pragma unroll
-    for (int a = 0; a < MT; ++a) {
-      const int c = a * 32 + m;
-      av[a] = (ok && c < M) ? A[row + c] : 0.f;
-      asum[a] += av[a];
-    }
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + 2 * u + h;
+      const bool ok = p < p_end;
+      const size_t row = (size_t)(ok ? p : p_begin) * ld;
 #pragma unroll
-    for (int b = 0; b < NT; ++b) {
-      const int c = b * 32 + m;
-      float v = 0.f;
-      if (XF == 0) {
-        v = (ok && c < N) ? Bm[row + c] : 0.f;
-      } else {
-        // source scalar x and which function of it this column holds
-        int src = -1, fn = 0;
-        bool view = false;
-        const int npe = 4 * APP;
-        if (c < APP) { src = c; fn = 0; }
-        else if (XF == 1 && c < APP + 3) { src = c - APP; fn = 0; view = true; }
-        else {
-          const int base = (XF == 1) ? APP + 3 : APP;
-          if (c < base + npe) { src = (c - base) >> 2; fn = 1 + ((c - base) & 3); }
-          else if (XF == 1 && c < base + npe + 12) { src = (c - base - npe) >> 2; fn = 1 + ((c - base - npe) & 3); view = true; }
-        }
-        if (ok && src >= 0 && c < N) {
-          const size_t e = (size_t)(chunk_start + p);
-          float x = view ? vdir[e * 3 + src] : Bm[row + src];
-          float sn, cs;
-          sincos_f(x, &sn, &cs);
-          const float m0 = view ? pm.v0 : pm.f0, m1 = view ? pm.v1 : pm.f1;
-          v = (fn == 0) ? x : (fn == 1) ? sn * m0 : (fn == 2) ? 2.f * sn * cs * m1 : (fn == 3) ? cs * m0
-                                                                                               : (1.f - 2.f * sn * sn) * m1;
-        }
+      for (int a = 0; a < MT; ++a) {
+        const int c = a * 32 + m;
+        av[u][a] = (ok && c < M) ? A[row + c] : 0.f;
       }
-      bv[b] = v;
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+        bv[u][b] = wgrad_b_value<XF>(Bm, row, b * 32 + m, N, ok, vdir, (size_t)(chunk_start + p), pm, APP);
     }
 #pragma unroll
-    for (int a = 0; a < MT; ++a)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+      for (int a = 0; a < MT; ++a) {
+        asum[a] += av[u][a];
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+      }
   }
-  // epilogue: D[i][k], i = a*32 + rowmap(r,h), k = b*32 + m  (128-byte contiguous atomics per half)
+  // epilogue: sum the four waves' tiles through LDS, then D[i][k], i = a*32 + rowmap(r,h), k = b*32 + m
+  // goes out as 128-byte-contiguous float atomics (wave w handles registers 4w .. 4w+3)
 #pragma unroll
   for (int a = 0; a < MT; ++a) {
 #pragma unroll
-    for (int b = 0; b < NT; ++b)
+    for (int b = 0; b < NT; ++b) {
+      __syncthreads();
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 16; ++r) s_red[wv][r][lane] = acc[a][b][r];
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = wv * 4 + rr;
+        const float v = s_red[0][r][lane] + s_red[1][r][lane] + s_red[2][r][lane] + s_red[3][r][lane];
         const int i = a * 32 + rowmap(r, 0) + 4 * h, k = b * 32 + m;
-        if (i < M && k < N && acc[a][b][r] != 0.f) atomicAdd(dW + (size_t)i * ldw + k, acc[a][b][r]);
+        if (i < M && k < N && v != 0.f) atomicAdd(dW + (size_t)i * ldw + k, v);
       }
+    }
     if (db) {
       float sacc = asum[a] + __shfl_xor(asum[a], 32);
       const int i = a * 32 + m;

@@ -273,10 +273,12 @@ class RenderRays(torch.autograd.Function):
                                         gfac, gm, ptr(g_xyz), cap, ptr(ws), nbytes, st), "jt_shade_backward")
         g_o = torch.empty(R, 3, **f32)
         g_d = torch.empty(R, 3, **f32)
+        mws_bytes = lib.jt_march_backward_workspace_bytes(scene, R)
+        mws = torch.empty(mws_bytes, device=dev, dtype=torch.uint8)
         check(lib.jt_march_backward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals), R,
                                     ptr(sigma_feat), ptr(weight), ptr(tmin), ptr(offset), ptr(sidx), ptr(rgb_s),
-                                    ptr(cmask), ptr(g_rgb), ptr(g_op), ptr(g_xyz), gfac, ptr(g_o), ptr(g_d), st),
-              "jt_march_backward")
+                                    ptr(cmask), ptr(g_rgb), ptr(g_op), ptr(g_xyz), gfac, ptr(g_o), ptr(g_d),
+                                    ptr(mws), mws_bytes, st), "jt_march_backward")
         g_factors = [factor_logical(t) for t in gdp + gdl + gap + gal]
         out = [None, g_o, g_d, None, None] + g_factors + list(g_mlp)
         return tuple(out)
