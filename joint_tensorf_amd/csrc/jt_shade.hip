@@ -13,6 +13,8 @@
 // map  row(r, h) = (r & 3) + 8 (r >> 2) + 4 h, and the A operand (weights, read from LDS with an odd
 // row stride => conflict-free) simply reads the matching column.  The gather is split the same way:
 // half h loads the channel quads q with q % 2 == h as 16-byte vectors.
+#include <cstdlib>
+
 #include "jt_common.h"
 #include "jt_walk.h"
 
@@ -394,10 +396,12 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
 // (4) leaves sample-major records (layer inputs / pre-activation gradients) for the weight-gradient
 // kernel k_wgrad, which is a skinny GEMM over the sample axis on the same MFMA instruction.
 
+// LDS hand-off between the lanes of ONE wave: the LDS executes a wave's instructions in order, so it is
+// enough to stop the compiler from moving LDS accesses across this point and to wait for the LDS queue
+// (lgkmcnt); global stores / atomics in flight (vmcnt) are NOT waited for.
 __device__ inline void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <class C>
@@ -431,6 +435,13 @@ __device__ inline void tp_write(float* tp, const f32x16* v, int j, int h) {
 
 // rec[(e0+s)*ld + col] = tp[col][s] for the tile's live samples; 256-byte contiguous row pieces
 __device__ inline void tp_store_rows(const float* tp, float* rec, size_t ld, int ncols, int e0, int nlive, int lane) {
+  if (nlive < 0) return;  // ablation switch (profiling only)
+  if (nlive == 32) {       // full tile: all 32 row stores issued back to back
+#pragma unroll 4
+    for (int sidx = 0; sidx < 32; ++sidx)
+      for (int col = lane; col < ncols; col += 64) rec[(size_t)(e0 + sidx) * ld + col] = tp[col * 33 + sidx];
+    return;
+  }
   for (int sidx = 0; sidx < nlive; ++sidx)
     for (int col = lane; col < ncols; col += 64) rec[(size_t)(e0 + sidx) * ld + col] = tp[col * 33 + sidx];
 }
@@ -454,7 +465,7 @@ __device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, c
     const float* n = geo + (grp * 8) * 4;
     tap_load<NCH, C::CA>(cur, P, Ln, n[m0], n[m1], n[mv], H, W, L, cl);
   }
-#pragma unroll
+#pragma unroll 1
   for (int q = 0; q < 8; ++q) {
     const int sidx = grp * 8 + q;
     const bool on = sidx < nlive;
@@ -496,7 +507,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
                                                       const float* __restrict__ vdir,
                                                       const float* __restrict__ g_rgb_s, float* __restrict__ g_xyz,
                                                       float* __restrict__ rec, int chunk_start, int chunk_cap,
-                                                      int cap) {
+                                                      int cap, int ablate) {
   typedef BwdCfg<C> B;
   extern __shared__ __align__(16) float smem[];
   const int total = min(offset[R], cap);
@@ -519,6 +530,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
     const int l0 = tile * 32;                // first record row of the tile (chunk-local)
     const int e = chunk_start + l0 + j;      // global entry of this lane's sample
     const int nlive = min(32, n_chunk - l0);
+    const int nrec = (ablate & 2) ? -1 : nlive;
     const bool on = j < nlive;
     const int ee = on ? e : chunk_start + l0 + nlive - 1;
     EntryGeom g = entry_geom(D, rays_o, rays_d, jitter, zvals, tmin, eray, esmp, ee);
@@ -563,16 +575,46 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
           if (m & 1) __builtin_amdgcn_sched_barrier(0);
         }
         wave_lds_sync();
-        tp_store_rows(tp, rec + B::R_PROD + i * C::CA, RC, C::CA, l0, nlive, lane);
+        tp_store_rows(tp, rec + B::R_PROD + i * C::CA, RC, C::CA, l0, nrec, lane);
         wave_lds_sync();
       }
     }
-    Hidden<C> h1 = layer1<C>(smem, facc, vd, pm, j, h);
-    relu_<C>(h1);
-    Hidden<C> h2 = layer2<C>(smem, h1, j, h);
-    relu_<C>(h2);
+    // Forward layers.  Each hidden activation is dropped as soon as the next layer has consumed it: its
+    // record goes out right away and only the ReLU sign bits (one register) survive for the backward.
+    constexpr int HOFF = (C::KIND == JT_MLP_FEA) ? 0 : 12;
+    unsigned mask1 = 0u, mask2 = 0u;
     float o[3];
-    layer3<C>(smem, h2, vd, pm, h, o);
+    {
+      Hidden<C> h1 = layer1<C>(smem, facc, vd, pm, j, h);
+      relu_<C>(h1);
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mask1 |= (h1.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
+      tp_write<C::MT>(tp, h1.v, j, h);
+      wave_lds_sync();
+      tp_store_rows(tp, rec + B::R_H1, RC, C::HID, l0, nrec, lane);
+      wave_lds_sync();
+      Hidden<C> h2 = layer2<C>(smem, h1, j, h);
+      relu_<C>(h2);
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mask2 |= (h2.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
+      tp_write<C::MT>(tp, h2.v, j, h);
+      wave_lds_sync();
+      tp_store_rows(tp, rec + B::R_MID + HOFF, RC, C::HID, l0, nrec, lane);
+      wave_lds_sync();
+      layer3<C>(smem, h2, vd, pm, h, o);
+    }
+    if (C::KIND != JT_MLP_FEA) {
+      float pe[12];
+      view_pe(vd, pm, pe);
+      if (on && h == 0 && nrec >= 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) rec[(size_t)(l0 + j) * RC + B::R_MID + k] = pe[k];
+      }
+    }
     // ---- output layer backward (VALU) ----
     float go[3];
 #pragma unroll
@@ -580,11 +622,10 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
       float rgb = 1.f / (1.f + expf(-o[c]));
       go[c] = on ? g_rgb_s[(size_t)e * 3 + c] * rgb * (1.f - rgb) : 0.f;
     }
-    if (on && h == 0) {
+    if (on && h == 0 && nrec >= 0) {
       float4 gq = make_float4(go[0], go[1], go[2], 0.f);
       *reinterpret_cast<float4*>(rec + (size_t)(l0 + j) * RC + B::R_GO) = gq;
     }
-    constexpr int HOFF = (C::KIND == JT_MLP_FEA) ? 0 : 12;
     Hidden<C> G2;
 #pragma unroll
     for (int mt = 0; mt < C::MT; ++mt)
@@ -593,24 +634,11 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
         const int k = HOFF + mt * 32 + rowmap(r, 0) + 4 * h;
         const float4 w = *reinterpret_cast<const float4*>(smem + C::O_W3 + k * 4);
         float gsum = go[0] * w.x + go[1] * w.y + go[2] * w.z;
-        G2.v[mt][r] = (h2.v[mt][r] > 0.f) ? gsum : 0.f;
+        G2.v[mt][r] = ((mask2 >> (mt * 16 + r)) & 1u) ? gsum : 0.f;
       }
-    // records: MID = [PE(d)] + relu(h2), G2
-    tp_write<C::MT>(tp, h2.v, j, h);
-    wave_lds_sync();
-    tp_store_rows(tp, rec + B::R_MID + HOFF, RC, C::HID, l0, nlive, lane);
-    wave_lds_sync();
-    if (C::KIND != JT_MLP_FEA) {
-      float pe[12];
-      view_pe(vd, pm, pe);
-      if (on && h == 0) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) rec[(size_t)(l0 + j) * RC + B::R_MID + k] = pe[k];
-      }
-    }
     tp_write<C::MT>(tp, G2.v, j, h);
     wave_lds_sync();
-    tp_store_rows(tp, rec + B::R_G2, RC, C::HID, l0, nlive, lane);
+    tp_store_rows(tp, rec + B::R_G2, RC, C::HID, l0, nrec, lane);
     wave_lds_sync();
     // ---- layer 2 backward: g_h1[k] = sum_i W2[i][k] G2[i] ; masked by relu(h1) ----
     Hidden<C> G1;
@@ -634,14 +662,10 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
 #pragma unroll
     for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) G1.v[mt][r] = (h1.v[mt][r] > 0.f) ? G1.v[mt][r] : 0.f;
-    tp_write<C::MT>(tp, h1.v, j, h);
-    wave_lds_sync();
-    tp_store_rows(tp, rec + B::R_H1, RC, C::HID, l0, nlive, lane);
-    wave_lds_sync();
+      for (int r = 0; r < 16; ++r) G1.v[mt][r] = ((mask1 >> (mt * 16 + r)) & 1u) ? G1.v[mt][r] : 0.f;
     tp_write<C::MT>(tp, G1.v, j, h);
     wave_lds_sync();
-    tp_store_rows(tp, rec + B::R_G1, RC, C::HID, l0, nlive, lane);
+    tp_store_rows(tp, rec + B::R_G1, RC, C::HID, l0, nrec, lane);
     wave_lds_sync();
     // ---- layer 1 backward, one M tile per encoding slot t: row rowmap(r,h) of tile t is the gradient of the
     //      very value this lane fed forward in k-step (r, t)  =>  chain rule through the encoding is lane-local
@@ -693,11 +717,11 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
     // records: F (basis_mat output) and GF
     tp_write<1>(tp, &facc, j, h);
     wave_lds_sync();
-    tp_store_rows(tp, rec + B::R_F, RC, 32, l0, nlive, lane);
+    tp_store_rows(tp, rec + B::R_F, RC, 32, l0, nrec, lane);
     wave_lds_sync();
     tp_write<1>(tp, &gf, j, h);
     wave_lds_sync();
-    tp_store_rows(tp, rec + B::R_GF, RC, 32, l0, nlive, lane);
+    tp_store_rows(tp, rec + B::R_GF, RC, 32, l0, nrec, lane);
     wave_lds_sync();
     // ---- basis_mat^T and the scatter, plane by plane ----
 #pragma unroll 1
@@ -725,7 +749,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
           if (ch < C::CA) tp[ch * 33 + j] = gp[T][r];
         }
       wave_lds_sync();
-      scatter_plane<C>(D, G, pl, tp, geo, gxyz, nlive, lane);
+      if (!(ablate & 1)) scatter_plane<C>(D, G, pl, tp, geo, gxyz, nlive, lane);
       wave_lds_sync();
     }
     if (on && h == 0) {
@@ -740,39 +764,63 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
 // A skinny GEMM over the sample axis with v_mfma_f32_32x32x2_f32: the two lane halves take two consecutive
 // samples per step, lane & 31 is the unit index for both operands (coalesced 128-byte row reads).
 // XF = 1 / 2 builds the layer-1 input row [f, d, PE(f), PE(d)] / [f, PE(f)] on the fly from the F record.
+// Column of the layer-1 weight matrix that N-tile b, lane m of the weight-gradient GEMM stands for.
+// Tile 0 holds the raw inputs (features, then the view direction for MLP_Fea), tile t = 1..4 holds
+// positional-encoding function t of the SAME source scalar, so a lane evaluates sin/cos once per sample
+// and feeds all five tiles.  Returns -1 for lanes that carry nothing.
 template <int XF>
-__device__ inline float wgrad_b_value(const float* __restrict__ Bm, size_t row, int c, int N, bool ok,
-                                      const float* __restrict__ vdir, size_t e, const PeMask& pm, int APP) {
-  if (XF == 0) return (ok && c < N) ? Bm[row + c] : 0.f;
-  // layer-1 input column c: which scalar x it derives from and which function of x it is
-  int src = -1, fn = 0;
-  bool view = false;
-  const int npe = 4 * APP;
-  if (c < APP) {
-    src = c;
-  } else if (XF == 1 && c < APP + 3) {
-    src = c - APP;
-    view = true;
-  } else {
-    const int base = (XF == 1) ? APP + 3 : APP;
-    if (c < base + npe) {
-      src = (c - base) >> 2;
-      fn = 1 + ((c - base) & 3);
-    } else if (XF == 1 && c < base + npe + 12) {
-      src = (c - base - npe) >> 2;
-      fn = 1 + ((c - base - npe) & 3);
-      view = true;
-    }
-  }
-  if (!(ok && src >= 0 && c < N)) return 0.f;
-  const float x = view ? vdir[e * 3 + src] : Bm[row + src];
-  float sn, cs;
-  sincos_f(x, &sn, &cs);
-  const float m0 = view ? pm.v0 : pm.f0, m1 = view ? pm.v1 : pm.f1;
-  return (fn == 0) ? x : (fn == 1) ? sn * m0 : (fn == 2) ? 2.f * sn * cs * m1 : (fn == 3) ? cs * m0
-                                                                                         : (1.f - 2.f * sn * sn) * m1;
+__device__ inline int l1_column(int b, int m, int APP) {
+  if (m < APP) return (b == 0) ? m : ((XF == 1) ? APP + 3 : APP) + 4 * m + (b - 1);
+  if (XF == 1 && m < APP + 3) return (b == 0) ? m : APP + 3 + 4 * APP + 4 * (m - APP) + (b - 1);
+  return -1;
 }
 
+template <int MT, int NT, int XF>
+struct WgradOperands {
+  float a[MT];
+  float b[NT];
+};
+
+// operands of one sample pair step: lane (m, h) reads sample p = p0 + h
+template <int MT, int NT, int XF>
+__device__ inline void wgrad_load(WgradOperands<MT, NT, XF>& o, const float* __restrict__ A, int M,
+                                  const float* __restrict__ Bm, int N, size_t ld, const float* __restrict__ vdir,
+                                  const PeMask& pm, int APP, int p, int p_end, int p_safe, int chunk_start, int m) {
+  const bool ok = p < p_end;
+  const size_t row = (size_t)(ok ? p : p_safe) * ld;
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+    const int c = a * 32 + m;
+    o.a[a] = (ok && c < M) ? A[row + c] : 0.f;
+  }
+  if (XF == 0) {
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      const int c = b * 32 + m;
+      o.b[b] = (ok && c < N) ? Bm[row + c] : 0.f;
+    }
+  } else {
+    const bool feat = m < APP, view = (XF == 1) && !feat && (m < APP + 3);
+    float x = 0.f;
+    if (ok && feat) x = Bm[row + m];
+    if (ok && view) x = vdir[(size_t)(chunk_start + p) * 3 + (m - APP)];
+    const bool live = ok && (feat || view);
+    float sn, cs;
+    sincos_f(x, &sn, &cs);
+    const float m0 = view ? pm.v0 : pm.f0, m1 = view ? pm.v1 : pm.f1;
+    o.b[0] = live ? x : 0.f;
+    o.b[1] = live ? sn * m0 : 0.f;
+    o.b[2] = live ? 2.f * sn * cs * m1 : 0.f;
+    o.b[3] = live ? cs * m0 : 0.f;
+    o.b[4] = live ? (1.f - 2.f * sn * sn) * m1 : 0.f;
+  }
+}
+
+// ---- weight gradients: dW[m][n] += sum_p A[p][m] * B[p][n],  db[m] += sum_p A[p][m] ------------------------
+// A skinny GEMM over the sample axis with v_mfma_f32_32x32x2_f32: the two lane halves take two consecutive
+// samples per step, lane & 31 is the unit index for both operands (coalesced 128-byte row reads).  The
+// operands of the next group of steps are loaded while the current group runs through the matrix core.
+// XF = 1 / 2: B is the layer-1 input [f, d, PE(f), PE(d)] / [f, PE(f)] rebuilt from the F record (NT = 5).
 template <int MT, int NT, int XF>
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int M, const float* __restrict__ Bm,
                                                int N, size_t ld, const float* __restrict__ vdir, PeMask pm, int APP,
@@ -785,10 +833,12 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
   const int total = min(offset[R], cap);
   const int n = min(total - chunk_start, chunk_cap);
   if (n <= 0) return;
+  constexpr int U = 2;  // steps (sample pairs) per operand group
   const int nwaves = gridDim.x * 4;
-  const int per = (((n + nwaves - 1) / nwaves) + 7) & ~7;  // multiple of 8 samples per wave
+  const int per = (((n + nwaves - 1) / nwaves) + 4 * U - 1) / (4 * U) * (4 * U);  // multiple of two groups
   const int w = blockIdx.x * 4 + wv;
   const int p_begin = min(w * per, n), p_end = min(p_begin + per, n);
+  const int p_safe = min(p_begin, n - 1);
   f32x16 acc[MT][NT];
   float asum[MT];
 #pragma unroll
@@ -799,35 +849,35 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   }
-  constexpr int U = 4;  // steps (sample pairs) whose loads are issued together
-  for (int p0 = p_begin; p0 < p_end; p0 += 2 * U) {
-    float av[U][MT], bv[U][NT];
+  typedef WgradOperands<MT, NT, XF> Op;
+  Op g0[U], g1[U];
+  auto load_group = [&](Op* g, int p0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int p = p0 + 2 * u + h;
-      const bool ok = p < p_end;
-      const size_t row = (size_t)(ok ? p : p_begin) * ld;
-#pragma unroll
-      for (int a = 0; a < MT; ++a) {
-        const int c = a * 32 + m;
-        av[u][a] = (ok && c < M) ? A[row + c] : 0.f;
-      }
-#pragma unroll
-      for (int b = 0; b < NT; ++b)
-        bv[u][b] = wgrad_b_value<XF>(Bm, row, b * 32 + m, N, ok, vdir, (size_t)(chunk_start + p), pm, APP);
-    }
+    for (int u = 0; u < U; ++u)
+      wgrad_load<MT, NT, XF>(g[u], A, M, Bm, N, ld, vdir, pm, APP, p0 + 2 * u + h, p_end, p_safe, chunk_start, m);
+  };
+  auto run_group = [&](const Op* g) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int a = 0; a < MT; ++a) {
-        asum[a] += av[u][a];
+        asum[a] += g[u].a[a];
 #pragma unroll
         for (int b = 0; b < NT; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[u].a[a], g[u].b[b], acc[a][b], 0, 0, 0);
       }
+  };
+  if (p_begin < p_end) {
+    load_group(g0, p_begin);
+    for (int p0 = p_begin; p0 < p_end; p0 += 4 * U) {
+      load_group(g1, p0 + 2 * U);  // rows >= p_end read as zeros
+      run_group(g0);
+      load_group(g0, p0 + 4 * U);
+      run_group(g1);
+    }
   }
-  // epilogue: sum the four waves' tiles through LDS, then D[i][k], i = a*32 + rowmap(r,h), k = b*32 + m
-  // goes out as 128-byte-contiguous float atomics (wave w handles registers 4w .. 4w+3)
+  // epilogue: sum the four waves' tiles through LDS, then D[i][k], i = a*32 + rowmap(r,h), goes out as
+  // 128-byte-contiguous float atomics (wave w handles registers 4w .. 4w+3)
 #pragma unroll
   for (int a = 0; a < MT; ++a) {
 #pragma unroll
@@ -836,12 +886,13 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
 #pragma unroll
       for (int r = 0; r < 16; ++r) s_red[wv][r][lane] = acc[a][b][r];
       __syncthreads();
+      const int k = (XF == 0) ? b * 32 + m : l1_column<XF>(b, m, APP);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int r = wv * 4 + rr;
         const float v = s_red[0][r][lane] + s_red[1][r][lane] + s_red[2][r][lane] + s_red[3][r][lane];
-        const int i = a * 32 + rowmap(r, 0) + 4 * h, k = b * 32 + m;
-        if (i < M && k < N && v != 0.f) atomicAdd(dW + (size_t)i * ldw + k, v);
+        const int i = a * 32 + rowmap(r, 0) + 4 * h;
+        if (i < M && k >= 0 && k < N && v != 0.f) atomicAdd(dW + (size_t)i * ldw + k, v);
       }
     }
     if (db) {
@@ -935,16 +986,19 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_bwd<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   const size_t RC = B::REC_FLOATS;
-  const int wg_blocks = 256;
+  const int wg_blocks = 512;
+  const char* abl_env = getenv("JT_ABLATE");  // profiling only: 1 = no scatter, 2 = no records, 4 = no wgrad
+  const int ablate = abl_env ? atoi(abl_env) : 0;
   for (int start = 0; start < cap; start += chunk) {
     const int ccap = std::min(chunk, cap - start);
     long tiles = ((long)ccap + 31) / 32;
     int blocks = (int)std::min<long>((tiles + B::NWAVE - 1) / B::NWAVE, 256);
     hipLaunchKernelGGL(k_shade_bwd<C>, dim3(blocks), dim3(512), lds, st, D, M, pm, G, rays_o, rays_d, jitter, zvals,
-                       tmin, offset, R, eray, esmp, vdir, g_rgb_s, g_xyz, rec, start, ccap, cap);
+                       tmin, offset, R, eray, esmp, vdir, g_rgb_s, g_xyz, rec, start, ccap, cap, ablate);
     JT_LAUNCH_CHECK();
+    if (ablate & 4) continue;
     // dW3/db3 = GO^T MID ; dW2/db2 = G2^T H1 ; dW1/db1 = G1^T X(F, d) ; dBasis = GF^T PROD
-    constexpr int NT3 = (C::IN3 + 31) / 32, NT1 = (C::IN1 + 31) / 32, NTB = (C::NC + 31) / 32;
+    constexpr int NT3 = (C::IN3 + 31) / 32, NT1 = 5, NTB = (C::NC + 31) / 32;
     hipLaunchKernelGGL((k_wgrad<1, NT3, 0>), dim3(wg_blocks), dim3(256), 0, st, rec + B::R_GO, 3, rec + B::R_MID,
                        C::IN3, RC, vdir, pm, C::APP, offset, R, cap, start, ccap, GM.w3, C::IN3, GM.b3);
     JT_LAUNCH_CHECK();
