@@ -197,8 +197,8 @@ size_t jt_march_backward_workspace_bytes(const JtScene* scene, int n_rays);
  * Replaces compute_appfeature + basis_mat + MLPRender_Fea[_WeakView].forward and their autograd.
  *   forward : rgb_s [n][3]
  *   backward: g_rgb_s [n][3] -> += g_factors.app_*, += g_mlp.*, g_xyz_app [n][3] (overwritten)
- * workspace: jt_shade_workspace_bytes(scene) bytes (packed weights), caller-provided. */
-size_t jt_shade_workspace_bytes(const JtScene* scene);
+ * workspace (backward only): jt_shade_workspace_bytes(scene, n_entries_max) bytes, caller-provided. */
+size_t jt_shade_workspace_bytes(const JtScene* scene, int n_entries_max);
 int jt_shade_forward(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp, const float* rays_o,
                      const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
                      const int32_t* shade_offset, int n_rays, const int32_t* entry_ray,

@@ -64,7 +64,7 @@ SIGNATURES = {
     "jt_app_gather_backward": (I, [SP, FP, P, P, P, P, P, P, I, P, P, P, FP, P, I, P]),
     "jt_march_backward": (I, [SP, FP, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, FP, P, P, P, ctypes.c_size_t, P]),
     "jt_march_backward_workspace_bytes": (ctypes.c_size_t, [SP, I]),
-    "jt_shade_workspace_bytes": (ctypes.c_size_t, [SP]),
+    "jt_shade_workspace_bytes": (ctypes.c_size_t, [SP, I]),
     "jt_shade_forward": (I, [SP, FP, MP, P, P, P, P, P, P, I, P, P, P, P, I, P, ctypes.c_size_t, P]),
     "jt_shade_backward": (I, [SP, FP, MP, P, P, P, P, P, P, I, P, P, P, P, FP, MP, P, I, P, ctypes.c_size_t, P]),
 }

@@ -825,8 +825,7 @@ template <int MT, int NT, int XF>
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int M, const float* __restrict__ Bm,
                                                int N, size_t ld, const float* __restrict__ vdir, PeMask pm, int APP,
                                                const int* __restrict__ offset, int R, int cap, int chunk_start,
-                                               int chunk_cap, float* __restrict__ dW, int ldw,
-                                               float* __restrict__ db) {
+                                               int chunk_cap, float* __restrict__ slab) {
   __shared__ float s_red[4][16][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int m = lane & 31, h = lane >> 5;
@@ -876,8 +875,11 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
       run_group(g1);
     }
   }
-  // epilogue: sum the four waves' tiles through LDS, then D[i][k], i = a*32 + rowmap(r,h), goes out as
-  // 128-byte-contiguous float atomics (wave w handles registers 4w .. 4w+3)
+  // epilogue: sum the four waves' tiles through LDS and park the block's partial result in its slab
+  // (plain 256-byte stores).  Many blocks atomically adding into the same few-KB weight matrix would run at
+  // a fraction of the float-atomic rate, so the cross-block sum is a second, deterministic pass
+  // (k_wgrad_reduce).
+  float* my = slab + (size_t)blockIdx.x * (MT * NT * 1024 + MT * 32);
 #pragma unroll
   for (int a = 0; a < MT; ++a) {
 #pragma unroll
@@ -886,20 +888,48 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
 #pragma unroll
       for (int r = 0; r < 16; ++r) s_red[wv][r][lane] = acc[a][b][r];
       __syncthreads();
-      const int k = (XF == 0) ? b * 32 + m : l1_column<XF>(b, m, APP);
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int r = wv * 4 + rr;
-        const float v = s_red[0][r][lane] + s_red[1][r][lane] + s_red[2][r][lane] + s_red[3][r][lane];
-        const int i = a * 32 + rowmap(r, 0) + 4 * h;
-        if (i < M && k >= 0 && k < N && v != 0.f) atomicAdd(dW + (size_t)i * ldw + k, v);
+        my[(a * NT + b) * 1024 + r * 64 + lane] =
+            s_red[0][r][lane] + s_red[1][r][lane] + s_red[2][r][lane] + s_red[3][r][lane];
       }
     }
-    if (db) {
-      float sacc = asum[a] + __shfl_xor(asum[a], 32);
-      const int i = a * 32 + m;
-      if (h == 0 && i < M && sacc != 0.f) atomicAdd(db + i, sacc);
-    }
+    __syncthreads();
+    s_red[wv][0][lane] = asum[a];
+    __syncthreads();
+    if (wv == 0 && h == 0)
+      my[MT * NT * 1024 + a * 32 + m] = s_red[0][0][m] + s_red[0][0][m + 32] + s_red[1][0][m] + s_red[1][0][m + 32] +
+                                       s_red[2][0][m] + s_red[2][0][m + 32] + s_red[3][0][m] + s_red[3][0][m + 32];
+  }
+}
+
+// dW[i][k] += sum over the live chunks' block slabs; one thread per slab element (deterministic order)
+template <int MT, int NT, int XF>
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slabs, int blocks_per_chunk,
+                                                      size_t chunk_stride, int chunk_entries,
+                                                      const int* __restrict__ offset, int R, int cap, int M, int N,
+                                                      int APP, float* __restrict__ dW, int ldw,
+                                                      float* __restrict__ db) {
+  const int total = min(offset[R], cap);
+  const int nchunks = (total + chunk_entries - 1) / chunk_entries;
+  constexpr int PER = MT * NT * 1024 + MT * 32;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= PER) return;
+  float sum = 0.f;
+  for (int c = 0; c < nchunks; ++c) {
+    const float* base = slabs + (size_t)c * chunk_stride + idx;
+    for (int b = 0; b < blocks_per_chunk; ++b) sum += base[(size_t)b * PER];
+  }
+  if (idx < MT * NT * 1024) {
+    const int tile = idx >> 10, r = (idx >> 6) & 15, lane = idx & 63;
+    const int a = tile / NT, b = tile - a * NT, m = lane & 31, h = lane >> 5;
+    const int i = a * 32 + rowmap(r, 0) + 4 * h;
+    const int k = (XF == 0) ? b * 32 + m : l1_column<XF>(b, m, APP);
+    if (i < M && k >= 0 && k < N) dW[(size_t)i * ldw + k] += sum;
+  } else if (db) {
+    const int i = idx - MT * NT * 1024;
+    if (i < M) db[i] += sum;
   }
 }
 
@@ -918,57 +948,30 @@ static int shade_kind(const JtScene* s) {
   return -1;
 }
 
-// workspace = sample-major records of one chunk of shaded samples (consumed by k_wgrad right after the
-// chunk's backward kernel, so with the default chunk they never leave the 256 MiB Infinity Cache)
+// workspace = [sample-major records of one chunk of shaded samples | per-(chunk, block) partial weight
+// gradients].  The records are consumed by k_wgrad right after the chunk's backward kernel, so with the
+// default chunk they stay in the 256 MiB Infinity Cache.
 static const int kChunkEntries = 96 * 1024;
-
-extern "C" size_t jt_shade_workspace_bytes(const JtScene* scene) {
-  const int kind = shade_kind(scene);
-  if (kind < 0) return 0;
-  const size_t rec = (kind == 0) ? BwdCfg<CfgBlender>::REC_FLOATS : BwdCfg<CfgLlff>::REC_FLOATS;
-  return rec * sizeof(float) * kChunkEntries;
-}
+static const int kWgradBlocks = 256;
 
 template <class C>
-static int launch_shade_fwd(const Dev& D, const MlpDev& M, const PeMask& pm, const float* rays_o,
-                            const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
-                            const int32_t* offset, int R, const int32_t* eray, const int32_t* esmp,
-                            const float* vdir, float* rgb_s, int cap, hipStream_t st) {
-  const size_t lds = C::LDS_FLOATS * sizeof(float);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_fwd<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
-  long tiles = ((long)cap + 31) / 32;
-  int blocks = (int)std::min<long>((tiles + 3) / 4, 512);
-  hipLaunchKernelGGL(k_shade_fwd<C>, dim3(blocks), dim3(256), lds, st, D, M, pm, rays_o, rays_d, jitter, zvals, tmin,
-                     offset, R, eray, esmp, vdir, rgb_s, cap);
-  JT_LAUNCH_CHECK();
-  return JT_OK;
-}
+struct WsLayout {
+  typedef BwdCfg<C> B;
+  static constexpr int NT3 = (C::IN3 + 31) / 32, NT1 = 5, NTB = (C::NC + 31) / 32;
+  static constexpr size_t P3 = 1 * NT3 * 1024 + 32, P2 = (size_t)C::MT * C::MT * 1024 + C::MT * 32,
+                          P1 = (size_t)C::MT * NT1 * 1024 + C::MT * 32, PB = 1 * NTB * 1024 + 32;
+  static size_t rec_floats() { return (size_t)B::REC_FLOATS * kChunkEntries; }
+  static size_t slab_floats_per_chunk() { return (P3 + P2 + P1 + PB) * kWgradBlocks; }
+  static size_t bytes(int cap) {
+    const int nchunks = (cap + kChunkEntries - 1) / kChunkEntries;
+    return (rec_floats() + slab_floats_per_chunk() * (size_t)std::max(nchunks, 1)) * sizeof(float);
+  }
+};
 
-extern "C" int jt_shade_forward(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp, const float* rays_o,
-                                const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
-                                const int32_t* shade_offset, int n_rays, const int32_t* entry_ray,
-                                const int32_t* entry_smp, const float* viewdirs, float* rgb_s, int n_entries_max,
-                                void* workspace, size_t workspace_bytes, void* stream) {
-  Dev D;
-  int rc = make_dev(scene, factors, &D);
-  if (rc) return rc;
-  if (!factors || !mlp || !rays_o || !rays_d || !tmin || !shade_offset || !entry_ray || !entry_smp || !viewdirs ||
-      !rgb_s)
-    return JT_ERR_ARG;
-  if (!mlp->basis || !mlp->w1 || !mlp->b1 || !mlp->w2 || !mlp->b2 || !mlp->w3 || !mlp->b3) return JT_ERR_ARG;
-  if (D.ndc && !zvals) return JT_ERR_ARG;
+extern "C" size_t jt_shade_workspace_bytes(const JtScene* scene, int n_entries_max) {
   const int kind = shade_kind(scene);
-  if (kind < 0) return JT_ERR_UNSUPPORTED;
-  if (n_entries_max < 1) return JT_OK;
-  MlpDev M = {mlp->basis, mlp->w1, mlp->b1, mlp->w2, mlp->b2, mlp->w3, mlp->b3};
-  PeMask pm = pe_masks(scene->fea_pe_progress, scene->view_pe_progress, scene->fea_pe, scene->view_pe);
-  hipStream_t st = (hipStream_t)stream;
-  if (kind == 0)
-    return launch_shade_fwd<CfgBlender>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, shade_offset, n_rays,
-                                        entry_ray, entry_smp, viewdirs, rgb_s, n_entries_max, st);
-  return launch_shade_fwd<CfgLlff>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, shade_offset, n_rays, entry_ray,
-                                   entry_smp, viewdirs, rgb_s, n_entries_max, st);
+  if (kind < 0 || n_entries_max < 1) return 0;
+  return (kind == 0) ? WsLayout<CfgBlender>::bytes(n_entries_max) : WsLayout<CfgLlff>::bytes(n_entries_max);
 }
 
 template <class C>
@@ -976,20 +979,26 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
                             const float* rays_o, const float* rays_d, const float* jitter, const float* zvals,
                             const float* tmin, const int32_t* offset, int R, const int32_t* eray,
                             const int32_t* esmp, const float* vdir, const float* g_rgb_s, float* g_xyz, int cap,
-                            float* rec, size_t rec_bytes, hipStream_t st) {
+                            float* ws, size_t ws_bytes, hipStream_t st) {
   typedef BwdCfg<C> B;
+  typedef WsLayout<C> W;
   const size_t lds = B::LDS_FLOATS * sizeof(float);
   if (lds > 160 * 1024) return JT_ERR_UNSUPPORTED;
-  int chunk = (int)std::min<size_t>(rec_bytes / (B::REC_FLOATS * sizeof(float)), (size_t)cap);
-  chunk &= ~31;
-  if (chunk < 32) return JT_ERR_ARG;
+  if (ws_bytes < W::bytes(cap)) return JT_ERR_ARG;
+  const int chunk = kChunkEntries;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_bwd<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   const size_t RC = B::REC_FLOATS;
-  const int wg_blocks = 512;
+  float* rec = ws;
+  float* slabs = ws + W::rec_floats();
+  const size_t cstride = W::slab_floats_per_chunk();
+  const int nb = kWgradBlocks;
   const char* abl_env = getenv("JT_ABLATE");  // profiling only: 1 = no scatter, 2 = no records, 4 = no wgrad
   const int ablate = abl_env ? atoi(abl_env) : 0;
-  for (int start = 0; start < cap; start += chunk) {
+  constexpr int NT3 = W::NT3, NT1 = W::NT1, NTB = W::NTB;
+  constexpr int XF1 = (C::KIND == JT_MLP_FEA) ? 1 : 2;
+  int ci = 0;
+  for (int start = 0; start < cap; start += chunk, ++ci) {
     const int ccap = std::min(chunk, cap - start);
     long tiles = ((long)ccap + 31) / 32;
     int blocks = (int)std::min<long>((tiles + B::NWAVE - 1) / B::NWAVE, 256);
@@ -998,21 +1007,39 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     JT_LAUNCH_CHECK();
     if (ablate & 4) continue;
     // dW3/db3 = GO^T MID ; dW2/db2 = G2^T H1 ; dW1/db1 = G1^T X(F, d) ; dBasis = GF^T PROD
-    constexpr int NT3 = (C::IN3 + 31) / 32, NT1 = 5, NTB = (C::NC + 31) / 32;
-    hipLaunchKernelGGL((k_wgrad<1, NT3, 0>), dim3(wg_blocks), dim3(256), 0, st, rec + B::R_GO, 3, rec + B::R_MID,
-                       C::IN3, RC, vdir, pm, C::APP, offset, R, cap, start, ccap, GM.w3, C::IN3, GM.b3);
+    float* s3 = slabs + (size_t)ci * cstride;
+    float* s2 = s3 + W::P3 * nb;
+    float* s1 = s2 + W::P2 * nb;
+    float* sb = s1 + W::P1 * nb;
+    hipLaunchKernelGGL((k_wgrad<1, NT3, 0>), dim3(nb), dim3(256), 0, st, rec + B::R_GO, 3, rec + B::R_MID, C::IN3,
+                       RC, vdir, pm, C::APP, offset, R, cap, start, ccap, s3);
     JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad<C::MT, C::MT, 0>), dim3(wg_blocks), dim3(256), 0, st, rec + B::R_G2, C::HID,
-                       rec + B::R_H1, C::HID, RC, vdir, pm, C::APP, offset, R, cap, start, ccap, GM.w2, C::HID,
-                       GM.b2);
+    hipLaunchKernelGGL((k_wgrad<C::MT, C::MT, 0>), dim3(nb), dim3(256), 0, st, rec + B::R_G2, C::HID, rec + B::R_H1,
+                       C::HID, RC, vdir, pm, C::APP, offset, R, cap, start, ccap, s2);
     JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad<C::MT, NT1, (C::KIND == JT_MLP_FEA ? 1 : 2)>), dim3(wg_blocks), dim3(256), 0, st,
-                       rec + B::R_G1, C::HID, rec + B::R_F, C::IN1, RC, vdir, pm, C::APP, offset, R, cap, start, ccap,
-                       GM.w1, C::IN1, GM.b1);
+    hipLaunchKernelGGL((k_wgrad<C::MT, NT1, XF1>), dim3(nb), dim3(256), 0, st, rec + B::R_G1, C::HID, rec + B::R_F,
+                       C::IN1, RC, vdir, pm, C::APP, offset, R, cap, start, ccap, s1);
     JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad<1, NTB, 0>), dim3(wg_blocks), dim3(256), 0, st, rec + B::R_GF, C::APP,
-                       rec + B::R_PROD, C::NC, RC, vdir, pm, C::APP, offset, R, cap, start, ccap, GM.basis, C::NC,
-                       (float*)nullptr);
+    hipLaunchKernelGGL((k_wgrad<1, NTB, 0>), dim3(nb), dim3(256), 0, st, rec + B::R_GF, C::APP, rec + B::R_PROD,
+                       C::NC, RC, vdir, pm, C::APP, offset, R, cap, start, ccap, sb);
+    JT_LAUNCH_CHECK();
+  }
+  if (!(ablate & 4)) {
+    float* s3 = slabs;
+    float* s2 = s3 + W::P3 * nb;
+    float* s1 = s2 + W::P2 * nb;
+    float* sb = s1 + W::P1 * nb;
+    hipLaunchKernelGGL((k_wgrad_reduce<1, NT3, 0>), dim3((W::P3 + 255) / 256), dim3(256), 0, st, s3, nb, cstride,
+                       chunk, offset, R, cap, 3, C::IN3, C::APP, GM.w3, C::IN3, GM.b3);
+    JT_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_wgrad_reduce<C::MT, C::MT, 0>), dim3((W::P2 + 255) / 256), dim3(256), 0, st, s2, nb,
+                       cstride, chunk, offset, R, cap, C::HID, C::HID, C::APP, GM.w2, C::HID, GM.b2);
+    JT_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_wgrad_reduce<C::MT, NT1, XF1>), dim3((W::P1 + 255) / 256), dim3(256), 0, st, s1, nb,
+                       cstride, chunk, offset, R, cap, C::HID, C::IN1, C::APP, GM.w1, C::IN1, GM.b1);
+    JT_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_wgrad_reduce<1, NTB, 0>), dim3((W::PB + 255) / 256), dim3(256), 0, st, sb, nb, cstride,
+                       chunk, offset, R, cap, C::APP, C::NC, C::APP, GM.basis, C::NC, (float*)nullptr);
     JT_LAUNCH_CHECK();
   }
   return JT_OK;

@@ -266,7 +266,7 @@ class RenderRays(torch.autograd.Function):
             mlp = _mlp_struct(*mlp_t)
             gm = _mlp_struct(*g_mlp)
             # records of one chunk of shaded samples (consumed by the weight-gradient GEMMs chunk by chunk)
-            nbytes = lib.jt_shade_workspace_bytes(scene)
+            nbytes = lib.jt_shade_workspace_bytes(scene, cap)
             ws = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8)
             check(lib.jt_shade_backward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
                                         ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(g_rgb_s),

@@ -45,4 +45,4 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert _lib.lib.jt_pose_forward(None, None, None, 12, 4, None, None) == 1
     assert _lib.lib.jt_blur_forward(None, None, None, 4, 4, 16, None, 65, None) == 1
     s = _lib.JtScene()
-    assert _lib.lib.jt_shade_workspace_bytes(ctypes.byref(s)) == 0  # unsupported shape -> 0
+    assert _lib.lib.jt_shade_workspace_bytes(ctypes.byref(s), 1000) == 0  # unsupported shape -> 0
