@@ -975,6 +975,48 @@ extern "C" size_t jt_shade_workspace_bytes(const JtScene* scene, int n_entries_m
 }
 
 template <class C>
+static int launch_shade_fwd(const Dev& D, const MlpDev& M, const PeMask& pm, const float* rays_o,
+                            const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
+                            const int32_t* offset, int R, const int32_t* eray, const int32_t* esmp,
+                            const float* vdir, float* rgb_s, int cap, hipStream_t st) {
+  const size_t lds = C::LDS_FLOATS * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_fwd<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  long tiles = ((long)cap + 31) / 32;
+  int blocks = (int)std::min<long>((tiles + 3) / 4, 512);
+  hipLaunchKernelGGL(k_shade_fwd<C>, dim3(blocks), dim3(256), lds, st, D, M, pm, rays_o, rays_d, jitter, zvals, tmin,
+                     offset, R, eray, esmp, vdir, rgb_s, cap);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
+extern "C" int jt_shade_forward(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp, const float* rays_o,
+                                const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
+                                const int32_t* shade_offset, int n_rays, const int32_t* entry_ray,
+                                const int32_t* entry_smp, const float* viewdirs, float* rgb_s, int n_entries_max,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  Dev D;
+  int rc = make_dev(scene, factors, &D);
+  if (rc) return rc;
+  if (!factors || !mlp || !rays_o || !rays_d || !tmin || !shade_offset || !entry_ray || !entry_smp || !viewdirs ||
+      !rgb_s)
+    return JT_ERR_ARG;
+  if (!mlp->basis || !mlp->w1 || !mlp->b1 || !mlp->w2 || !mlp->b2 || !mlp->w3 || !mlp->b3) return JT_ERR_ARG;
+  if (D.ndc && !zvals) return JT_ERR_ARG;
+  const int kind = shade_kind(scene);
+  if (kind < 0) return JT_ERR_UNSUPPORTED;
+  if (n_entries_max < 1) return JT_OK;
+  MlpDev M = {mlp->basis, mlp->w1, mlp->b1, mlp->w2, mlp->b2, mlp->w3, mlp->b3};
+  PeMask pm = pe_masks(scene->fea_pe_progress, scene->view_pe_progress, scene->fea_pe, scene->view_pe);
+  hipStream_t st = (hipStream_t)stream;
+  if (kind == 0)
+    return launch_shade_fwd<CfgBlender>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, shade_offset, n_rays,
+                                        entry_ray, entry_smp, viewdirs, rgb_s, n_entries_max, st);
+  return launch_shade_fwd<CfgLlff>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, shade_offset, n_rays, entry_ray,
+                                   entry_smp, viewdirs, rgb_s, n_entries_max, st);
+}
+
+template <class C>
 static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, const JtFactors& G, const JtMlp& GM,
                             const float* rays_o, const float* rays_d, const float* jitter, const float* zvals,
                             const float* tmin, const int32_t* offset, int R, const int32_t* eray,
