@@ -41,6 +41,9 @@ extern "C" {
 #define JT_MLP_FEA 0      /* MLPRender_Fea          tensorBase.py:101-126 */
 #define JT_MLP_WEAKVIEW 1 /* MLPRender_Fea_WeakView tensorBase.py:180-214 */
 
+#define JT_SHADE_SKIP_WGRAD 1 /* jt_shade_backward flags: leave out the MLP/basis weight-gradient pass
+                                 (kernel timing probes only; g_mlp is then not written) */
+
 /* Scene / call description: 4-byte fields only (mirrored 1:1 by ctypes in joint_tensorf_amd/_lib.py).
  * Replaces the TensorBase attributes set in tensorBase.py:430-488 plus the per-call keyword
  * arguments of BatBase.forward (batBase.py:44). */
@@ -209,7 +212,7 @@ int jt_shade_backward(const JtScene* scene, const JtFactors* factors, const JtMl
                       const int32_t* shade_offset, int n_rays, const int32_t* entry_ray,
                       const int32_t* entry_smp, const float* viewdirs, const float* g_rgb_s,
                       const JtFactors* g_factors, const JtMlp* g_mlp, float* g_xyz_app, int n_entries_max,
-                      void* workspace, size_t workspace_bytes, void* stream);
+                      void* workspace, size_t workspace_bytes, int flags, void* stream);
 
 #ifdef __cplusplus
 }

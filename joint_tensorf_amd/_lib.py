@@ -66,7 +66,7 @@ SIGNATURES = {
     "jt_march_backward_workspace_bytes": (ctypes.c_size_t, [SP, I]),
     "jt_shade_workspace_bytes": (ctypes.c_size_t, [SP, I]),
     "jt_shade_forward": (I, [SP, FP, MP, P, P, P, P, P, P, I, P, P, P, P, I, P, ctypes.c_size_t, P]),
-    "jt_shade_backward": (I, [SP, FP, MP, P, P, P, P, P, P, I, P, P, P, P, FP, MP, P, I, P, ctypes.c_size_t, P]),
+    "jt_shade_backward": (I, [SP, FP, MP, P, P, P, P, P, P, I, P, P, P, P, FP, MP, P, I, P, ctypes.c_size_t, I, P]),
 }
 
 

@@ -904,7 +904,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
   }
 }
 
-// dW[i][k] += sum over the live chunks' block slabs; one thread per slab element (deterministic order)
+// dW[i][k] += sum over the live chunks' block slabs; grid.y slab groups, a few atomics per element
 template <int MT, int NT, int XF>
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slabs, int blocks_per_chunk,
                                                       size_t chunk_stride, int chunk_entries,
@@ -916,20 +916,33 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   constexpr int PER = MT * NT * 1024 + MT * 32;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= PER) return;
-  float sum = 0.f;
-  for (int c = 0; c < nchunks; ++c) {
-    const float* base = slabs + (size_t)c * chunk_stride + idx;
-    for (int b = 0; b < blocks_per_chunk; ++b) sum += base[(size_t)b * PER];
+  // blockIdx.y strides over the (chunk, block) slabs; four independent partial sums keep loads in flight
+  const int nslab = nchunks * blocks_per_chunk;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int q = blockIdx.y;
+  const int gy = gridDim.y;
+  auto slab_at = [&](int t) {
+    const int c = t / blocks_per_chunk, b = t - c * blocks_per_chunk;
+    return slabs[(size_t)c * chunk_stride + (size_t)b * PER + idx];
+  };
+  for (; q + 3 * gy < nslab; q += 4 * gy) {
+    s0 += slab_at(q);
+    s1 += slab_at(q + gy);
+    s2 += slab_at(q + 2 * gy);
+    s3 += slab_at(q + 3 * gy);
   }
+  for (; q < nslab; q += gy) s0 += slab_at(q);
+  const float sum = (s0 + s1) + (s2 + s3);
+  if (sum == 0.f) return;
   if (idx < MT * NT * 1024) {
     const int tile = idx >> 10, r = (idx >> 6) & 15, lane = idx & 63;
     const int a = tile / NT, b = tile - a * NT, m = lane & 31, h = lane >> 5;
     const int i = a * 32 + rowmap(r, 0) + 4 * h;
     const int k = (XF == 0) ? b * 32 + m : l1_column<XF>(b, m, APP);
-    if (i < M && k >= 0 && k < N) dW[(size_t)i * ldw + k] += sum;
+    if (i < M && k >= 0 && k < N) atomicAdd(dW + (size_t)i * ldw + k, sum);
   } else if (db) {
     const int i = idx - MT * NT * 1024;
-    if (i < M) db[i] += sum;
+    if (i < M) atomicAdd(db + i, sum);
   }
 }
 
@@ -1021,7 +1034,7 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
                             const float* rays_o, const float* rays_d, const float* jitter, const float* zvals,
                             const float* tmin, const int32_t* offset, int R, const int32_t* eray,
                             const int32_t* esmp, const float* vdir, const float* g_rgb_s, float* g_xyz, int cap,
-                            float* ws, size_t ws_bytes, hipStream_t st) {
+                            float* ws, size_t ws_bytes, int flags, hipStream_t st) {
   typedef BwdCfg<C> B;
   typedef WsLayout<C> W;
   const size_t lds = B::LDS_FLOATS * sizeof(float);
@@ -1036,7 +1049,7 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   const size_t cstride = W::slab_floats_per_chunk();
   const int nb = kWgradBlocks;
   const char* abl_env = getenv("JT_ABLATE");  // profiling only: 1 = no scatter, 2 = no records, 4 = no wgrad
-  const int ablate = abl_env ? atoi(abl_env) : 0;
+  const int ablate = (abl_env ? atoi(abl_env) : 0) | ((flags & JT_SHADE_SKIP_WGRAD) ? 4 : 0);
   constexpr int NT3 = W::NT3, NT1 = W::NT1, NTB = W::NTB;
   constexpr int XF1 = (C::KIND == JT_MLP_FEA) ? 1 : 2;
   int ci = 0;
@@ -1071,16 +1084,16 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     float* s2 = s3 + W::P3 * nb;
     float* s1 = s2 + W::P2 * nb;
     float* sb = s1 + W::P1 * nb;
-    hipLaunchKernelGGL((k_wgrad_reduce<1, NT3, 0>), dim3((W::P3 + 255) / 256), dim3(256), 0, st, s3, nb, cstride,
+    hipLaunchKernelGGL((k_wgrad_reduce<1, NT3, 0>), dim3((W::P3 + 255) / 256, 32), dim3(256), 0, st, s3, nb, cstride,
                        chunk, offset, R, cap, 3, C::IN3, C::APP, GM.w3, C::IN3, GM.b3);
     JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad_reduce<C::MT, C::MT, 0>), dim3((W::P2 + 255) / 256), dim3(256), 0, st, s2, nb,
+    hipLaunchKernelGGL((k_wgrad_reduce<C::MT, C::MT, 0>), dim3((W::P2 + 255) / 256, 32), dim3(256), 0, st, s2, nb,
                        cstride, chunk, offset, R, cap, C::HID, C::HID, C::APP, GM.w2, C::HID, GM.b2);
     JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad_reduce<C::MT, NT1, XF1>), dim3((W::P1 + 255) / 256), dim3(256), 0, st, s1, nb,
+    hipLaunchKernelGGL((k_wgrad_reduce<C::MT, NT1, XF1>), dim3((W::P1 + 255) / 256, 32), dim3(256), 0, st, s1, nb,
                        cstride, chunk, offset, R, cap, C::HID, C::IN1, C::APP, GM.w1, C::IN1, GM.b1);
     JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad_reduce<1, NTB, 0>), dim3((W::PB + 255) / 256), dim3(256), 0, st, sb, nb, cstride,
+    hipLaunchKernelGGL((k_wgrad_reduce<1, NTB, 0>), dim3((W::PB + 255) / 256, 32), dim3(256), 0, st, sb, nb, cstride,
                        chunk, offset, R, cap, C::APP, C::NC, C::APP, GM.basis, C::NC, (float*)nullptr);
     JT_LAUNCH_CHECK();
   }
@@ -1093,7 +1106,7 @@ extern "C" int jt_shade_backward(const JtScene* scene, const JtFactors* factors,
                                  const int32_t* entry_ray, const int32_t* entry_smp, const float* viewdirs,
                                  const float* g_rgb_s, const JtFactors* g_factors, const JtMlp* g_mlp,
                                  float* g_xyz_app, int n_entries_max, void* workspace, size_t workspace_bytes,
-                                 void* stream) {
+                                 int flags, void* stream) {
   Dev D;
   int rc = make_dev(scene, factors, &D);
   if (rc) return rc;
@@ -1116,8 +1129,8 @@ extern "C" int jt_shade_backward(const JtScene* scene, const JtFactors* factors,
   if (kind == 0)
     return launch_shade_bwd<CfgBlender>(D, M, pm, *g_factors, *g_mlp, rays_o, rays_d, jitter, zvals, tmin,
                                         shade_offset, n_rays, entry_ray, entry_smp, viewdirs, g_rgb_s, g_xyz_app,
-                                        n_entries_max, (float*)workspace, workspace_bytes, st);
+                                        n_entries_max, (float*)workspace, workspace_bytes, flags, st);
   return launch_shade_bwd<CfgLlff>(D, M, pm, *g_factors, *g_mlp, rays_o, rays_d, jitter, zvals, tmin, shade_offset,
                                    n_rays, entry_ray, entry_smp, viewdirs, g_rgb_s, g_xyz_app, n_entries_max,
-                                   (float*)workspace, workspace_bytes, st);
+                                   (float*)workspace, workspace_bytes, flags, st);
 }

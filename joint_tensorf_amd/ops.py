@@ -270,7 +270,7 @@ class RenderRays(torch.autograd.Function):
             ws = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8)
             check(lib.jt_shade_backward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
                                         ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(g_rgb_s),
-                                        gfac, gm, ptr(g_xyz), cap, ptr(ws), nbytes, st), "jt_shade_backward")
+                                        gfac, gm, ptr(g_xyz), cap, ptr(ws), nbytes, 0, st), "jt_shade_backward")
         g_o = torch.empty(R, 3, **f32)
         g_d = torch.empty(R, 3, **f32)
         mws_bytes = lib.jt_march_backward_workspace_bytes(scene, R)
@@ -401,3 +401,102 @@ def gaussian_taps(sigma_vox, kernel_size, device):
     ns = torch.arange(-(kernel_size // 2), kernel_size // 2 + 1, dtype=torch.float32)
     k = 1 / (s * math.sqrt(2 * math.pi)) * torch.exp(-0.5 * (ns / s) * (ns / s))
     return torch.clamp(k, max=1.0).to(device)
+
+
+# ----------------------------------------------------------------------------------------------
+# kernel timing probe for bench.py's roofline line
+# ----------------------------------------------------------------------------------------------
+class KernelProbe:
+    """Times single launches of the fused appearance kernels (forward: k_shade_fwd; backward:
+    k_shade_bwd without the weight-gradient pass) with HIP events on the launch stream, on the shaded
+    samples of one ray batch.  Algorithmic bytes per shaded sample: forward gather
+    4*3*Ca*6 B; backward = the same bytes re-read + the same bytes added to the gradients."""
+
+    CHUNK = 96 * 1024  # entries of one backward launch (kChunkEntries in jt_shade.hip)
+
+    def __init__(self, tf, rays_o, rays_d, n_samples, white_bg=True, ndc=False):
+        dev = rays_o.device
+        g = tf.gridSize.tolist()
+        self.cfg = RenderCfg(
+            aabb=tf.aabb.view(-1).tolist(), plane_hw=[(g[MAT_MODE[i][1]], g[MAT_MODE[i][0]]) for i in range(3)],
+            line_len=[g[VEC_MODE[i]] for i in range(3)], n_comp_density=tf.density_n_comp[0],
+            n_comp_app=tf.app_n_comp[0], step_size=float(tf.stepSize), near_far=tf.near_far,
+            distance_scale=tf.distance_scale, density_shift=tf.density_shift,
+            density_act=_lib.JT_ACT_SOFTPLUS if tf.fea2denseAct == "softplus" else _lib.JT_ACT_RELU,
+            weight_thres=tf.rayMarch_weight_thres, n_samples=n_samples, ndc=ndc, white_bg=white_bg,
+            app_dim=tf.app_dim, mlp_kind=tf.renderModule.kind, mlp_hidden=tf.featureC, view_pe=tf.view_pe,
+            fea_pe=tf.fea_pe)
+        self.tf = tf
+        self.o = rays_o.detach().contiguous().float()
+        self.d = rays_d.detach().contiguous().float()
+        self.jitter = torch.rand(self.o.shape[0], device=dev)
+        self.dev = dev
+
+    def run(self, reps=10):
+        cfg, tf, dev = self.cfg, self.tf, self.dev
+        scene = cfg.scene()
+        R, S = self.o.shape[0], cfg.n_samples
+        f32 = dict(device=dev, dtype=torch.float32)
+        sd = [[factor_storage(p) for p in lst] for lst in (tf.density_plane, tf.density_line, tf.app_plane, tf.app_line)]
+        fac = _factors_struct(*sd)
+        mlp_t = [t.detach().contiguous() for t in (tf.basis_mat.weight,) + tuple(tf.renderModule.weights())]
+        mlp = _mlp_struct(*mlp_t)
+        st = _stream()
+        sigma_feat, weight, tmin = torch.empty(R, S, **f32), torch.empty(R, S, **f32), torch.empty(R, **f32)
+        count = torch.empty(R, device=dev, dtype=torch.int32)
+        offset = torch.empty(R + 1, device=dev, dtype=torch.int32)
+        sidx = torch.empty(R, S, device=dev, dtype=torch.int16)
+        opacity, depth = torch.empty(R, **f32), torch.empty(R, **f32)
+        check(lib.jt_march_forward(scene, fac, ptr(self.o), ptr(self.d), ptr(self.jitter), None, R, ptr(sigma_feat),
+                                   ptr(weight), ptr(tmin), ptr(count), ptr(offset), ptr(sidx), ptr(opacity),
+                                   ptr(depth), st), "jt_march_forward")
+        n = int(offset[R].item())
+        n_in_box = int((sigma_feat != 0).sum().item())
+        eray = torch.empty(max(n, 1), device=dev, dtype=torch.int32)
+        esmp = torch.empty(max(n, 1), device=dev, dtype=torch.int32)
+        vdir = torch.empty(max(n, 1), 3, **f32)
+        rgb_s = torch.empty(max(n, 1), 3, **f32)
+        check(lib.jt_shade_list(scene, ptr(self.d), R, ptr(offset), ptr(sidx), ptr(eray), ptr(esmp), ptr(vdir), n, st),
+              "jt_shade_list")
+        bytes_per = 4 * 3 * cfg.n_comp_app * 6
+
+        def timed(fn):
+            fn()
+            torch.cuda.synchronize()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for a, b in ev:
+                a.record()
+                fn()
+                b.record()
+            torch.cuda.synchronize()
+            return sorted(a.elapsed_time(b) for a, b in ev)[len(ev) // 2] * 1e-3
+
+        t_fwd = timed(lambda: check(lib.jt_shade_forward(
+            scene, fac, mlp, ptr(self.o), ptr(self.d), ptr(self.jitter), None, ptr(tmin), ptr(offset), R, ptr(eray),
+            ptr(esmp), ptr(vdir), ptr(rgb_s), n, None, 0, st), "jt_shade_forward"))
+        # one backward launch = one chunk of shaded samples
+        nb = min(n, self.CHUNK)
+        g_rgb_s = torch.rand(max(n, 1), 3, **f32)
+        gfac = _factors_struct(*[[torch.zeros_like(t) for t in lst] for lst in sd])
+        self._keep = gfac
+        gm_t = [torch.zeros_like(t) for t in mlp_t]
+        gm = _mlp_struct(*gm_t)
+        g_xyz = torch.empty(max(n, 1), 3, **f32)
+        nbytes = lib.jt_shade_workspace_bytes(scene, nb)
+        ws = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8)
+        t_bwd = timed(lambda: check(lib.jt_shade_backward(
+            scene, fac, mlp, ptr(self.o), ptr(self.d), ptr(self.jitter), None, ptr(tmin), ptr(offset), R, ptr(eray),
+            ptr(esmp), ptr(vdir), ptr(g_rgb_s), gfac, gm, ptr(g_xyz), nb, ptr(ws), nbytes, 1, st),
+            "jt_shade_backward"))
+        peak = 8000.0
+        bwd = nb * 2 * bytes_per / t_bwd / 1e9
+        fwd = n * bytes_per / t_fwd / 1e9
+        return {
+            "bound": "hbm", "kernel": "k_shade_bwd (one launch = one chunk of shaded samples, weight-gradient pass excluded)",
+            "achieved": bwd, "peak": peak, "unit": "GB/s", "frac": bwd / peak, "traffic": None,
+            "launch_ms": t_bwd * 1e3, "samples_per_launch": nb, "bytes_per_sample": 2 * bytes_per,
+            "forward": {"kernel": "k_shade_fwd (gather + basis + MLP, one launch)", "achieved": fwd, "peak": peak,
+                        "unit": "GB/s", "frac": fwd / peak, "launch_ms": t_fwd * 1e3, "samples_per_launch": n,
+                        "bytes_per_sample": bytes_per},
+            "in_box_samples": n_in_box, "shaded_samples": n,
+        }
