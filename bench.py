@@ -90,11 +90,12 @@ def allreduce_grads(model, world):
     jdist.allreduce_gradients(list(model.graph.parameters()), world)
 
 
-def cpu_baseline(opt_name, seconds_budget=20.0):
+def cpu_baseline(opt_name, seconds_budget=24.0):
     """The reference algorithm (torch-CPU oracle port, parity-pinned) on config C1 of SURVEY §8(d):
-    grid 64^3, 512 rays (4 views x 128), S = 221, fwd + loss + bwd, blur off."""
+    grid 64^3, 512 rays (4 views x 128), S = 221, fwd + loss + bwd, blur off.  A few intra-op thread counts
+    are tried (the path is thousands of small ops; all cores of a big host oversubscribe it badly) and the
+    best one is reported with the thread count it used."""
     from oracle import tensorf_oracle as O
-    torch.set_num_threads(os.cpu_count())
     g = torch.Generator().manual_seed(0)
     grid = [64, 64, 64]
     cfg = O.SceneCfg([-1.5] * 3 + [1.5] * 3, grid, [2.0, 6.0])
@@ -123,20 +124,30 @@ def cpu_baseline(opt_name, seconds_budget=20.0):
         loss = O.render_loss(rgb.view(B, r, 3), target) + 8e-5 * O.density_L1(params)
         loss.backward()
 
-    step()  # warm-up
-    times = []
-    t_end = time.time() + seconds_budget
-    while time.time() < t_end or len(times) < 3:
-        t0 = time.time()
-        step()
-        times.append(time.time() - t0)
-        if len(times) >= 25:
-            break
-    med = float(np.median(times))
-    return dict(value=B * r / med, unit="rays/s", cores=os.cpu_count(), kind="port",
-                sample="C1: grid 64^3, 512 rays x 221 samples, fwd+loss+bwd, blur off, %d reps, median %.0f ms "
-                       "(min %.0f / max %.0f), torch %d threads" % (len(times), med * 1e3, min(times) * 1e3,
-                                                                   max(times) * 1e3, torch.get_num_threads()))
+    ncpu = os.cpu_count() or 1
+    cands = sorted({t for t in (8, 16, 32) if t <= ncpu} or {ncpu})
+    best = None
+    t_start = time.time()
+    for nt in cands:
+        torch.set_num_threads(nt)
+        step()  # warm-up at this thread count
+        times = []
+        while len(times) < 9 and (time.time() - t_start) < seconds_budget * (cands.index(nt) + 1) / len(cands):
+            t0 = time.time()
+            step()
+            times.append(time.time() - t0)
+        if not times:
+            t0 = time.time()
+            step()
+            times.append(time.time() - t0)
+        med = float(np.median(times))
+        if best is None or med < best[0]:
+            best = (med, nt, times)
+    med, nt, times = best
+    return dict(value=B * r / med, unit="rays/s", cores=nt, kind="port",
+                sample="C1: grid 64^3, 512 rays x 221 samples, fwd+loss+bwd, blur off; best of thread counts %s: "
+                       "%d threads, %d reps, median %.0f ms (min %.0f / max %.0f); host has %d logical CPUs"
+                       % (cands, nt, len(times), med * 1e3, min(times) * 1e3, max(times) * 1e3, ncpu))
 
 
 def measure_roofline(model, opt, var, reps=20):
