@@ -412,7 +412,8 @@ struct BwdCfg {
   static constexpr int NWAVE = 8;
   static constexpr int LDS_FLOATS = C::LDS_FLOATS + NWAVE * WAVE_FLOATS;
   static constexpr int PT = (C::CA + 31) / 32;  // M tiles of one plane's channels in the basis backward
-  // sample-major records handed to k_wgrad (floats per entry)
+  // TILE-BLOCKED records handed to k_wgrad: rec[tile][row][32 samples]; every accumulator register goes
+  // out as one coalesced 128-byte-per-half store, no transposition (k_wgrad reads rows, one per lane)
   static constexpr int R_G1 = 0;
   static constexpr int R_G2 = R_G1 + C::HID;
   static constexpr int R_H1 = R_G2 + C::HID;
@@ -420,9 +421,20 @@ struct BwdCfg {
   static constexpr int R_F = R_MID + C::IN3;
   static constexpr int R_GF = R_F + 32;
   static constexpr int R_GO = R_GF + 32;
-  static constexpr int R_PROD = R_GO + 4;
-  static constexpr int REC_FLOATS = R_PROD + C::NC;
+  static constexpr int R_VD = R_GO + 4;    // view direction (3 rows + pad)
+  static constexpr int R_PROD = R_VD + 4;
+  static constexpr int REC_FLOATS = R_PROD + C::NC;   // rows of one tile; a tile is [REC_FLOATS][32 samples]
 };
+
+// record rows row0 + t*32 + rowmap(r,h) of the tile <- accumulator registers (lane = sample j)
+template <int NT>
+__device__ inline void rec_store(float* rt, int row0, const f32x16* v, int j, int h, bool on) {
+  if (!on) return;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rt[(size_t)(row0 + t * 32 + rowmap(r, 0) + 4 * h) * 32 + j] = v[t][r];
+}
 
 // rows = tile*32 + rowmap(r,h), column = sample j  ->  tp[row][j]
 template <int NT>
@@ -530,8 +542,9 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
     const int l0 = tile * 32;                // first record row of the tile (chunk-local)
     const int e = chunk_start + l0 + j;      // global entry of this lane's sample
     const int nlive = min(32, n_chunk - l0);
-    const int nrec = (ablate & 2) ? -1 : nlive;
     const bool on = j < nlive;
+    const bool onrec = on && !(ablate & 2);
+    float* rt = rec + (size_t)tile * RC * 32;  // this tile's record block
     const int ee = on ? e : chunk_start + l0 + nlive - 1;
     EntryGeom g = entry_geom(D, rays_o, rays_d, jitter, zvals, tmin, eray, esmp, ee);
     float vd[3] = {vdir[(size_t)ee * 3], vdir[(size_t)ee * 3 + 1], vdir[(size_t)ee * 3 + 2]};
@@ -568,15 +581,12 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             float bv = live ? pr[k] : 0.f;
-            if (live) tp[(c0 + k) * 33 + j] = pr[k];
+            if (live && onrec) rt[(size_t)(B::R_PROD + i * C::CA + c0 + k) * 32 + j] = pr[k];
             float av = sb[i * C::CA + c0 + k];
             facc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, facc, 0, 0, 0);
           }
           if (m & 1) __builtin_amdgcn_sched_barrier(0);
         }
-        wave_lds_sync();
-        tp_store_rows(tp, rec + B::R_PROD + i * C::CA, RC, C::CA, l0, nrec, lane);
-        wave_lds_sync();
       }
     }
     // Forward layers.  Each hidden activation is dropped as soon as the next layer has consumed it: its
@@ -591,28 +601,22 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
       for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mask1 |= (h1.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
-      tp_write<C::MT>(tp, h1.v, j, h);
-      wave_lds_sync();
-      tp_store_rows(tp, rec + B::R_H1, RC, C::HID, l0, nrec, lane);
-      wave_lds_sync();
+      rec_store<C::MT>(rt, B::R_H1, h1.v, j, h, onrec);
       Hidden<C> h2 = layer2<C>(smem, h1, j, h);
       relu_<C>(h2);
 #pragma unroll
       for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mask2 |= (h2.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
-      tp_write<C::MT>(tp, h2.v, j, h);
-      wave_lds_sync();
-      tp_store_rows(tp, rec + B::R_MID + HOFF, RC, C::HID, l0, nrec, lane);
-      wave_lds_sync();
+      rec_store<C::MT>(rt, B::R_MID + HOFF, h2.v, j, h, onrec);
       layer3<C>(smem, h2, vd, pm, h, o);
     }
     if (C::KIND != JT_MLP_FEA) {
       float pe[12];
       view_pe(vd, pm, pe);
-      if (on && h == 0 && nrec >= 0) {
+      if (onrec && h == 0) {
 #pragma unroll
-        for (int k = 0; k < 12; ++k) rec[(size_t)(l0 + j) * RC + B::R_MID + k] = pe[k];
+        for (int k = 0; k < 12; ++k) rt[(size_t)(B::R_MID + k) * 32 + j] = pe[k];
       }
     }
     // ---- output layer backward (VALU) ----
@@ -622,9 +626,12 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
       float rgb = 1.f / (1.f + expf(-o[c]));
       go[c] = on ? g_rgb_s[(size_t)e * 3 + c] * rgb * (1.f - rgb) : 0.f;
     }
-    if (on && h == 0 && nrec >= 0) {
-      float4 gq = make_float4(go[0], go[1], go[2], 0.f);
-      *reinterpret_cast<float4*>(rec + (size_t)(l0 + j) * RC + B::R_GO) = gq;
+    if (onrec && h == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        rt[(size_t)(B::R_GO + c) * 32 + j] = go[c];
+        rt[(size_t)(B::R_VD + c) * 32 + j] = vd[c];
+      }
     }
     Hidden<C> G2;
 #pragma unroll
@@ -636,10 +643,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
         float gsum = go[0] * w.x + go[1] * w.y + go[2] * w.z;
         G2.v[mt][r] = ((mask2 >> (mt * 16 + r)) & 1u) ? gsum : 0.f;
       }
-    tp_write<C::MT>(tp, G2.v, j, h);
-    wave_lds_sync();
-    tp_store_rows(tp, rec + B::R_G2, RC, C::HID, l0, nrec, lane);
-    wave_lds_sync();
+    rec_store<C::MT>(rt, B::R_G2, G2.v, j, h, onrec);
     // ---- layer 2 backward: g_h1[k] = sum_i W2[i][k] G2[i] ; masked by relu(h1) ----
     Hidden<C> G1;
 #pragma unroll
@@ -663,10 +667,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
     for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) G1.v[mt][r] = ((mask1 >> (mt * 16 + r)) & 1u) ? G1.v[mt][r] : 0.f;
-    tp_write<C::MT>(tp, G1.v, j, h);
-    wave_lds_sync();
-    tp_store_rows(tp, rec + B::R_G1, RC, C::HID, l0, nrec, lane);
-    wave_lds_sync();
+    rec_store<C::MT>(rt, B::R_G1, G1.v, j, h, onrec);
     // ---- layer 1 backward, one M tile per encoding slot t: row rowmap(r,h) of tile t is the gradient of the
     //      very value this lane fed forward in k-step (r, t)  =>  chain rule through the encoding is lane-local
     f32x16 gf;
@@ -715,14 +716,8 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
     for (int r = 0; r < 16; ++r)
       if (rowmap(r, 0) + 4 * h >= C::APP) gf[r] = 0.f;
     // records: F (basis_mat output) and GF
-    tp_write<1>(tp, &facc, j, h);
-    wave_lds_sync();
-    tp_store_rows(tp, rec + B::R_F, RC, 32, l0, nrec, lane);
-    wave_lds_sync();
-    tp_write<1>(tp, &gf, j, h);
-    wave_lds_sync();
-    tp_store_rows(tp, rec + B::R_GF, RC, 32, l0, nrec, lane);
-    wave_lds_sync();
+    rec_store<1>(rt, B::R_F, &facc, j, h, onrec);
+    rec_store<1>(rt, B::R_GF, &gf, j, h, onrec);
     // ---- basis_mat^T and the scatter, plane by plane ----
 #pragma unroll 1
     for (int pl = 0; pl < 3; ++pl) {
@@ -775,55 +770,33 @@ __device__ inline int l1_column(int b, int m, int APP) {
   return -1;
 }
 
-template <int MT, int NT, int XF>
-struct WgradOperands {
-  float a[MT];
-  float b[NT];
-};
+// ---- weight gradients: dW[m][n] += sum_p A[p][m] * B[p][n],  db[m] += sum_p A[p][m] ------------------------
+// A skinny GEMM over the sample axis with v_mfma_f32_32x32x2_f32.  The records are tile-blocked
+// ([row][32 samples]), and the MFMA wants the unit on the lane (lane & 31) and the sample on the k axis
+// (lane half + step): every lane therefore reads ITS unit's 128-byte row of the tile with eight 16-byte
+// loads (the same access shape as the factor gather) and feeds its 16 same-parity samples step by step --
+// no LDS, no transposition.  XF = 1 / 2: B is the layer-1 input [f, d, PE(f), PE(d)] / [f, PE(f)]: lane m
+// loads the row of source scalar m once, takes sin/cos once per sample and serves all five N tiles.
+template <int XF>
+__device__ inline float pe_pick(int b, float x, float sn, float cs, float m0, float m1) {
+  return (b == 0) ? x : (b == 1) ? sn * m0 : (b == 2) ? 2.f * sn * cs * m1 : (b == 3) ? cs * m0
+                                                                                    : (1.f - 2.f * sn * sn) * m1;
+}
 
-// operands of one sample pair step: lane (m, h) reads sample p = p0 + h
-template <int MT, int NT, int XF>
-__device__ inline void wgrad_load(WgradOperands<MT, NT, XF>& o, const float* __restrict__ A, int M,
-                                  const float* __restrict__ Bm, int N, size_t ld, const float* __restrict__ vdir,
-                                  const PeMask& pm, int APP, int p, int p_end, int p_safe, int chunk_start, int m) {
-  const bool ok = p < p_end;
-  const size_t row = (size_t)(ok ? p : p_safe) * ld;
+// the 16 samples of parity h of one record row (zeros beyond nl live samples or for a dead row)
+__device__ inline void load_row_parity(const float* __restrict__ row, bool live, int h, int nl, float out[16]) {
 #pragma unroll
-  for (int a = 0; a < MT; ++a) {
-    const int c = a * 32 + m;
-    o.a[a] = (ok && c < M) ? A[row + c] : 0.f;
-  }
-  if (XF == 0) {
-#pragma unroll
-    for (int b = 0; b < NT; ++b) {
-      const int c = b * 32 + m;
-      o.b[b] = (ok && c < N) ? Bm[row + c] : 0.f;
-    }
-  } else {
-    const bool feat = m < APP, view = (XF == 1) && !feat && (m < APP + 3);
-    float x = 0.f;
-    if (ok && feat) x = Bm[row + m];
-    if (ok && view) x = vdir[(size_t)(chunk_start + p) * 3 + (m - APP)];
-    const bool live = ok && (feat || view);
-    float sn, cs;
-    sincos_f(x, &sn, &cs);
-    const float m0 = view ? pm.v0 : pm.f0, m1 = view ? pm.v1 : pm.f1;
-    o.b[0] = live ? x : 0.f;
-    o.b[1] = live ? sn * m0 : 0.f;
-    o.b[2] = live ? 2.f * sn * cs * m1 : 0.f;
-    o.b[3] = live ? cs * m0 : 0.f;
-    o.b[4] = live ? (1.f - 2.f * sn * sn) * m1 : 0.f;
+  for (int q = 0; q < 8; ++q) {
+    float4 v = live ? ld4(row + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float e0 = h ? v.y : v.x, e1 = h ? v.w : v.z;
+    out[2 * q] = (4 * q + h < nl) ? e0 : 0.f;
+    out[2 * q + 1] = (4 * q + 2 + h < nl) ? e1 : 0.f;
   }
 }
 
-// ---- weight gradients: dW[m][n] += sum_p A[p][m] * B[p][n],  db[m] += sum_p A[p][m] ------------------------
-// A skinny GEMM over the sample axis with v_mfma_f32_32x32x2_f32: the two lane halves take two consecutive
-// samples per step, lane & 31 is the unit index for both operands (coalesced 128-byte row reads).  The
-// operands of the next group of steps are loaded while the current group runs through the matrix core.
-// XF = 1 / 2: B is the layer-1 input [f, d, PE(f), PE(d)] / [f, PE(f)] rebuilt from the F record (NT = 5).
 template <int MT, int NT, int XF>
-__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int M, const float* __restrict__ Bm,
-                                               int N, size_t ld, const float* __restrict__ vdir, PeMask pm, int APP,
+__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ rec, int a_row0, int M, int b_row0, int N,
+                                               int f_row0, int vd_row0, int rec_rows, PeMask pm, int APP,
                                                const int* __restrict__ offset, int R, int cap, int chunk_start,
                                                int chunk_cap, float* __restrict__ slab) {
   __shared__ float s_red[4][16][64];
@@ -832,12 +805,11 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
   const int total = min(offset[R], cap);
   const int n = min(total - chunk_start, chunk_cap);
   if (n <= 0) return;
-  constexpr int U = 2;  // steps (sample pairs) per operand group
+  const int ntiles = (n + 31) >> 5;
   const int nwaves = gridDim.x * 4;
-  const int per = (((n + nwaves - 1) / nwaves) + 4 * U - 1) / (4 * U) * (4 * U);  // multiple of two groups
+  const int per = (ntiles + nwaves - 1) / nwaves;
   const int w = blockIdx.x * 4 + wv;
-  const int p_begin = min(w * per, n), p_end = min(p_begin + per, n);
-  const int p_safe = min(p_begin, n - 1);
+  const int t_begin = min(w * per, ntiles), t_end = min(t_begin + per, ntiles);
   f32x16 acc[MT][NT];
   float asum[MT];
 #pragma unroll
@@ -848,31 +820,49 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ A, int 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   }
-  typedef WgradOperands<MT, NT, XF> Op;
-  Op g0[U], g1[U];
-  auto load_group = [&](Op* g, int p0) {
+  for (int t = t_begin; t < t_end; ++t) {
+    const float* rt = rec + (size_t)t * rec_rows * 32;
+    const int nl = min(32, n - t * 32);
+    float av[MT][16];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      wgrad_load<MT, NT, XF>(g[u], A, M, Bm, N, ld, vdir, pm, APP, p0 + 2 * u + h, p_end, p_safe, chunk_start, m);
-  };
-  auto run_group = [&](const Op* g) {
+    for (int a = 0; a < MT; ++a) {
+      const int c = a * 32 + m;
+      load_row_parity(rt + (size_t)(a_row0 + min(c, M - 1)) * 32, c < M, h, nl, av[a]);
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+      for (int q = 0; q < 16; ++q) asum[a] += av[a][q];
+    }
+    if (XF == 0) {
 #pragma unroll
-      for (int a = 0; a < MT; ++a) {
-        asum[a] += g[u].a[a];
+      for (int b = 0; b < NT; ++b) {
+        const int c = b * 32 + m;
+        float bv[16];
+        load_row_parity(rt + (size_t)(b_row0 + min(c, N - 1)) * 32, c < N, h, nl, bv);
 #pragma unroll
-        for (int b = 0; b < NT; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[u].a[a], g[u].b[b], acc[a][b], 0, 0, 0);
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+          for (int a = 0; a < MT; ++a)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][q], bv[q], acc[a][b], 0, 0, 0);
       }
-  };
-  if (p_begin < p_end) {
-    load_group(g0, p_begin);
-    for (int p0 = p_begin; p0 < p_end; p0 += 4 * U) {
-      load_group(g1, p0 + 2 * U);  // rows >= p_end read as zeros
-      run_group(g0);
-      load_group(g0, p0 + 4 * U);
-      run_group(g1);
+    } else {
+      const bool feat = m < APP, view = (XF == 1) && !feat && (m < APP + 3);
+      const int srow = feat ? f_row0 + m : vd_row0 + (view ? m - APP : 0);
+      float x[16], sn[16], cs[16];
+      load_row_parity(rt + (size_t)srow * 32, feat || view, h, nl, x);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sincos_f(x[q], &sn[q], &cs[q]);
+      const float m0 = view ? pm.v0 : pm.f0, m1 = view ? pm.v1 : pm.f1;
+      const bool live = feat || view;
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const bool sok = (2 * q + h) < nl;  // x is 0 beyond nl, but cos(0) = 1: mask explicitly
+          const float bv = (live && sok) ? pe_pick<XF>(b, x[q], sn[q], cs[q], m0, m1) : 0.f;
+#pragma unroll
+          for (int a = 0; a < MT; ++a)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][q], bv, acc[a][b], 0, 0, 0);
+        }
+      }
     }
   }
   // epilogue: sum the four waves' tiles through LDS and park the block's partial result in its slab
@@ -1066,17 +1056,18 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     float* s2 = s3 + W::P3 * nb;
     float* s1 = s2 + W::P2 * nb;
     float* sb = s1 + W::P1 * nb;
-    hipLaunchKernelGGL((k_wgrad<1, NT3, 0>), dim3(nb), dim3(256), 0, st, rec + B::R_GO, 3, rec + B::R_MID, C::IN3,
-                       RC, vdir, pm, C::APP, offset, R, cap, start, ccap, s3);
+    const int RR = B::REC_FLOATS;
+    hipLaunchKernelGGL((k_wgrad<1, NT3, 0>), dim3(nb), dim3(256), 0, st, rec, B::R_GO, 3, B::R_MID, C::IN3, B::R_F,
+                       B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s3);
     JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad<C::MT, C::MT, 0>), dim3(nb), dim3(256), 0, st, rec + B::R_G2, C::HID, rec + B::R_H1,
-                       C::HID, RC, vdir, pm, C::APP, offset, R, cap, start, ccap, s2);
+    hipLaunchKernelGGL((k_wgrad<C::MT, C::MT, 0>), dim3(nb), dim3(256), 0, st, rec, B::R_G2, C::HID, B::R_H1, C::HID,
+                       B::R_F, B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s2);
     JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad<C::MT, NT1, XF1>), dim3(nb), dim3(256), 0, st, rec + B::R_G1, C::HID, rec + B::R_F,
-                       C::IN1, RC, vdir, pm, C::APP, offset, R, cap, start, ccap, s1);
+    hipLaunchKernelGGL((k_wgrad<C::MT, NT1, XF1>), dim3(nb), dim3(256), 0, st, rec, B::R_G1, C::HID, B::R_F, C::IN1,
+                       B::R_F, B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s1);
     JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad<1, NTB, 0>), dim3(nb), dim3(256), 0, st, rec + B::R_GF, C::APP, rec + B::R_PROD,
-                       C::NC, RC, vdir, pm, C::APP, offset, R, cap, start, ccap, sb);
+    hipLaunchKernelGGL((k_wgrad<1, NTB, 0>), dim3(nb), dim3(256), 0, st, rec, B::R_GF, C::APP, B::R_PROD, C::NC,
+                       B::R_F, B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, sb);
     JT_LAUNCH_CHECK();
   }
   if (!(ablate & 4)) {
