@@ -54,7 +54,7 @@ struct ShadeCfg {
   static constexpr int O_B2 = O_B1 + HID;
   static constexpr int O_B3 = O_B2 + HID;
   static constexpr int LDS_FLOATS = O_B3 + 4;
-  static_assert(HID % 32 == 0 && APP <= 32 && CA % 4 == 0, "shape");
+  static_assert(HID % 32 == 0 && APP <= 32 && CA % 4 == 0 && CA <= 64, "shape");
 };
 
 // Column of W1 (torch layout [HID][IN1]) that lane-half h consumes in k-step (r, t), t = 0..4:
@@ -197,7 +197,7 @@ __device__ inline void sincos_f(float x, float* sn, float* cs) {
 //   [x, sin x * m0, sin 2x * m1, cos x * m0, cos 2x * m1]     (tensorBase.py:43-55)
 template <class C>
 __device__ inline void l1_inputs(const f32x16& facc, const float vd[3], const PeMask& pm, int h, int r,
-                                 float out[5]) {
+                                 float out[5], float* sn_out, float* cs_out) {
   const int a0 = rowmap(r, 0), a1 = rowmap(r, 1);
   const bool feat0 = a0 < C::APP, feat1 = a1 < C::APP;
   const bool dir1 = (C::KIND == JT_MLP_FEA) && a1 >= 28 && a1 <= 30;
@@ -210,6 +210,8 @@ __device__ inline void l1_inputs(const f32x16& facc, const float vd[3], const Pe
   }
   float sn, cs;
   sincos_f(x, &sn, &cs);
+  *sn_out = sn;
+  *cs_out = cs;
   out[0] = live ? x : 0.f;
   out[1] = live ? sn * m0 : 0.f;
   out[2] = live ? 2.f * sn * cs * m1 : 0.f;
@@ -225,7 +227,7 @@ struct Hidden {
 // ---- layer 1: IN1 -> HID, + bias, ReLU -----------------------------------------------------------------
 template <class C>
 __device__ inline Hidden<C> layer1(const float* s, const f32x16& facc, const float vd[3], const PeMask& pm, int j,
-                                   int h) {
+                                   int h, float* stash = nullptr, int lane = 0) {
   Hidden<C> acc;
 #pragma unroll
   for (int mt = 0; mt < C::MT; ++mt)
@@ -234,8 +236,12 @@ __device__ inline Hidden<C> layer1(const float* s, const f32x16& facc, const flo
   constexpr int RS = l1_rsteps<C>();
 #pragma unroll
   for (int r = 0; r < RS; ++r) {
-    float in[5];
-    l1_inputs<C>(facc, vd, pm, h, r, in);
+    float in[5], sn, cs;
+    l1_inputs<C>(facc, vd, pm, h, r, in, &sn, &cs);
+    if (stash) {  // lane-private slots, conflict-free
+      stash[(2 * r) * 64 + lane] = sn;
+      stash[(2 * r + 1) * 64 + lane] = cs;
+    }
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
       const int col = h ? w1_col<C>(1, r, t) : w1_col<C>(0, r, t);
@@ -406,7 +412,7 @@ __device__ inline void wave_lds_sync() {
 
 template <class C>
 struct BwdCfg {
-  static constexpr int TP_ROWS = (C::HID > 32 || C::CA > 32) ? 64 : 32;
+  static constexpr int TP_ROWS = 64;  // >= CA rows of product gradients; also the 2*16*64-float sin/cos stash
   static constexpr int TP_LD = 33;
   static constexpr int WAVE_FLOATS = TP_ROWS * TP_LD + 32 * 4 + 32 * 4;
   static constexpr int NWAVE = 8;
@@ -595,7 +601,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
     unsigned mask1 = 0u, mask2 = 0u;
     float o[3];
     {
-      Hidden<C> h1 = layer1<C>(smem, facc, vd, pm, j, h);
+      Hidden<C> h1 = layer1<C>(smem, facc, vd, pm, j, h, tp, lane);
       relu_<C>(h1);
 #pragma unroll
       for (int mt = 0; mt < C::MT; ++mt)
@@ -671,6 +677,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
     // ---- layer 1 backward, one M tile per encoding slot t: row rowmap(r,h) of tile t is the gradient of the
     //      very value this lane fed forward in k-step (r, t)  =>  chain rule through the encoding is lane-local
     f32x16 gf;
+    const float* stash = tp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) gf[r] = 0.f;
 #pragma unroll
@@ -700,8 +707,10 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
       for (int r = 0; r < 16; ++r) {
         if (rowmap(r, 0) >= C::APP && rowmap(r, 1) >= C::APP) continue;
         float x = facc[r];
-        float sn, cs;
-        sincos_f(x, &sn, &cs);
+        // sin/cos of this row were computed by the forward layer and parked in the wave's LDS scratch
+        // (keeping 30 of them in registers across the backward chain spilled to scratch memory)
+        (void)x;
+        const float sn = stash[(2 * r) * 64 + lane], cs = stash[(2 * r + 1) * 64 + lane];
         float dv;
         if (t == 0) dv = 1.f;
         else if (t == 1) dv = cs * pm.f0;
