@@ -963,7 +963,7 @@ static int shade_kind(const JtScene* s) {
 // workspace = [sample-major records of one chunk of shaded samples | per-(chunk, block) partial weight
 // gradients].  The records are consumed by k_wgrad right after the chunk's backward kernel, so with the
 // default chunk they stay in the 256 MiB Infinity Cache.
-static const int kChunkEntries = 96 * 1024;
+static const int kChunkEntries = 1 << 20;
 static const int kWgradBlocks = 256;
 
 template <class C>

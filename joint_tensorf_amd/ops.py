@@ -412,7 +412,7 @@ class KernelProbe:
     samples of one ray batch.  Algorithmic bytes per shaded sample: forward gather
     4*3*Ca*6 B; backward = the same bytes re-read + the same bytes added to the gradients."""
 
-    CHUNK = 96 * 1024  # entries of one backward launch (kChunkEntries in jt_shade.hip)
+    CHUNK = 1 << 20  # entries of one backward launch (kChunkEntries in jt_shade.hip)
 
     def __init__(self, tf, rays_o, rays_d, n_samples, white_bg=True, ndc=False):
         dev = rays_o.device
