@@ -214,6 +214,18 @@ int jt_shade_backward(const JtScene* scene, const JtFactors* factors, const JtMl
                       const JtFactors* g_factors, const JtMlp* g_mlp, float* g_xyz_app, int n_entries_max,
                       void* workspace, size_t workspace_bytes, int flags, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Regularisers over one channel-last factor [H][W][C] (a line is W = 1) in a single pass.
+ * Replaces TensorVMSplit.density_L1 (tensoRF.py:212-216) and TVLoss.forward (tensorBase.py:16-41) and
+ * their autograd:
+ *   forward : out3[0] += sum |x|, out3[1] += sum_{y} (x[y+1,x]-x[y,x])^2, out3[2] += sum_{x} (x[y,x+1]-x[y,x])^2
+ *             (out3 zeroed by the caller; the means / weights are applied by the caller)
+ *   backward: g (+)= coef3[0]*sign(x) + coef3[1]*d(out3[1])/dx + coef3[2]*d(out3[2])/dx, coef3 on the device;
+ *             accumulate != 0 adds to g, 0 overwrites it. */
+int jt_factor_reg_forward(const float* x, int H, int W, int C, float* out3, void* stream);
+int jt_factor_reg_backward(const float* x, int H, int W, int C, const float* coef3, float* g, int accumulate,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -328,6 +328,37 @@ def blur_factor(x, taps):
 
 
 # ----------------------------------------------------------------------------------------------
+# regularisers
+# ----------------------------------------------------------------------------------------------
+class FactorReg(torch.autograd.Function):
+    """(sum|x|, sum_h (dx)^2, sum_w (dx)^2) of a logical [1,C,H,W] factor in one pass; the backward adds
+    the three gradients, weighted by the incoming (device) scalars, in one more pass."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xs = factor_storage(x)
+        H, W, C = xs.shape
+        out = torch.zeros(3, device=xs.device, dtype=torch.float32)
+        check(lib.jt_factor_reg_forward(ptr(xs), H, W, C, ptr(out), _stream()), "jt_factor_reg_forward")
+        ctx.xs = xs
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        xs = ctx.xs
+        H, W, C = xs.shape
+        g = torch.empty_like(xs)
+        coef = g_out.contiguous().float()
+        check(lib.jt_factor_reg_backward(ptr(xs), H, W, C, ptr(coef), ptr(g), 0, _stream()),
+              "jt_factor_reg_backward")
+        return factor_logical(g)
+
+
+def factor_reg(x):
+    return FactorReg.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------
 # camera
 # ----------------------------------------------------------------------------------------------
 class TrainPose(torch.autograd.Function):

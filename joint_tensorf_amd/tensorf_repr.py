@@ -196,22 +196,49 @@ class BAT_VMSplit(torch.nn.Module):
                 {"params": self.basis_mat.parameters(), "lr": lr_init_network},
                 {"params": self.renderModule.parameters(), "lr": lr_init_network}]
 
+    # The three regularisers below are evaluated by ONE pass per factor (ops.factor_reg -> jt_factor_reg_*);
+    # the per-tensor sums are cached until the parameter changes so density_L1 and TV_loss_density share them.
+    def _reg_sums(self, p):
+        if not p.is_cuda:
+            raise RuntimeError("joint_tensorf_amd computes regularisers on the GPU only")
+        key = (id(p), p._version, p.data_ptr())
+        cache = self.__dict__.setdefault("_reg_cache", {})
+        hit = cache.get(id(p))
+        if hit is not None and hit[0] == key and torch.is_grad_enabled() == hit[2]:
+            return hit[1]
+        sums = ops.factor_reg(p)
+        cache[id(p)] = (key, sums, torch.is_grad_enabled())
+        return sums
+
     def density_L1(self):
+        """sum_i mean|P_i| + mean|L_i| over the density factors (tensoRF.py:212-216)."""
         total = 0
         for i in range(3):
-            total = total + torch.mean(torch.abs(self.density_plane[i])) + torch.mean(torch.abs(self.density_line[i]))
+            total = total + self._reg_sums(self.density_plane[i])[0] / self.density_plane[i].numel() \
+                + self._reg_sums(self.density_line[i])[0] / self.density_line[i].numel()
         return total
+
+    def _tv(self, p, weight=1.0):
+        """TVLoss.forward (tensorBase.py:21-38) from the two difference sums."""
+        b, c, h, w = p.shape
+        s = self._reg_sums(p)
+        total = 0
+        if c * (h - 1) * w > 0:
+            total = total + s[1] / (c * (h - 1) * w)
+        if c * h * (w - 1) > 0:
+            total = total + s[2] / (c * h * (w - 1))
+        return weight * 2 * total / b
 
     def TV_loss_density(self, reg):
         total = 0
         for i in range(3):
-            total = total + reg(self.density_plane[i]) * 1e-2
+            total = total + self._tv(self.density_plane[i], getattr(reg, "TVLoss_weight", 1)) * 1e-2
         return total
 
     def TV_loss_app(self, reg):
         total = 0
         for i in range(3):
-            total = total + reg(self.app_plane[i]) * 1e-2
+            total = total + self._tv(self.app_plane[i], getattr(reg, "TVLoss_weight", 1)) * 1e-2
         return total
 
     # ---- resolution changes (tensoRF.py:274-295) --------------------------------------------------
@@ -289,6 +316,7 @@ class BAT_VMSplit(torch.nn.Module):
                 is_test_optim=False, view_pe_progress=1.0, fea_pe_progress=1.0):
         self._check_flags(opt)
         self.opt = opt
+        self.__dict__.setdefault("_reg_cache", {}).clear()  # regulariser sums are per forward call
         dev = center.device
         S = N_samples if N_samples > 0 else self.nSamples
         near, far = float(self.near_far[0]), float(self.near_far[1])

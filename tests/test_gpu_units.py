@@ -169,3 +169,31 @@ def test_march_stage_vs_oracle(name):
     for r_ in range(R):
         want = np.nonzero(aux["app_mask"][r_].numpy())[0]
         assert np.array_equal(sidx_np[r_, :len(want)], want)
+
+
+@pytest.mark.parametrize("shape", [(16, 14, 14), (48, 23, 17), (16, 33, 1)])
+def test_factor_reg_vs_oracle(shape):
+    """fused L1 / TV sums and their gradient against the oracle's torch ops."""
+    from joint_tensorf_amd import ops
+    C, H, W = shape
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, C, H, W, generator=g)
+    w = torch.tensor([0.3, 1.7, -0.4])
+    a = x.clone().requires_grad_(True)
+    ref = torch.stack([a.abs().sum(), ((a[:, :, 1:, :] - a[:, :, :-1, :]) ** 2).sum(),
+                       ((a[:, :, :, 1:] - a[:, :, :, :-1]) ** 2).sum()])
+    (ref * w).sum().backward()
+    b = ops.factor_logical(ops.factor_storage(x).to(DEV)).requires_grad_(True)
+    out = ops.factor_reg(b)
+    (out * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5)
+    assert _rel(b.grad.cpu().numpy(), a.grad.numpy()) < 1e-5
+    # TV loss assembled from the sums equals the oracle's tv_loss
+    tv_ref = O.tv_loss(x)
+    s = out.detach().cpu()
+    tv = 0.0
+    if H > 1:
+        tv = tv + s[1] / (C * (H - 1) * W)
+    if W > 1:
+        tv = tv + s[2] / (C * H * (W - 1))
+    np.testing.assert_allclose(float(2 * tv), float(tv_ref), rtol=2e-5)
