@@ -297,18 +297,27 @@ def render_rays(cfg, rays_o, rays_d, jitter, zvals, density_plane, density_line,
 class BlurFactor(torch.autograd.Function):
     """Replicate-padded separable blur of a logical [1,C,H,W] factor (plane, or line with W == 1).
 
-    Replaces BAT_VMSplit.convolute_plane / convolute_line (bateRF.py:8-39) for cubic planes."""
+    Replaces BAT_VMSplit.convolute_plane / convolute_line (bateRF.py:8-39).  `reinterpret=True` reproduces
+    what the reference does to a plane: it reshapes the [C, g[m1], g[m0]] memory to [C, H=g[m0], W=g[m1]]
+    before blurring (bateRF.py:29 with the (H, W) of the call sites bateRF.py:68,76,110,117) and returns
+    [1, C, g[m0], g[m1]].  The reshape keeps every channel's flat texel index, so in
+    channel-last storage it is the SAME buffer read with rows and columns exchanged in the shape only --
+    no data movement; for square planes it is the identity."""
 
     @staticmethod
-    def forward(ctx, x, taps):
+    def forward(ctx, x, taps, reinterpret):
         xs = factor_storage(x)
         H, W, C = xs.shape
+        if reinterpret and W > 1:
+            H, W = W, H
+            xs = xs.reshape(H, W, C)
         taps = taps.detach().contiguous().float()
         out = torch.empty_like(xs)
         tmp = torch.empty_like(xs) if (H > 1 and W > 1) else None
         check(lib.jt_blur_forward(ptr(xs), ptr(out), ptr(tmp), H, W, C, ptr(taps), taps.numel(), _stream()),
               "jt_blur_forward")
         ctx.save_for_backward(taps)
+        ctx.in_hw = tuple(x.shape[2:])
         return factor_logical(out)
 
     @staticmethod
@@ -320,11 +329,11 @@ class BlurFactor(torch.autograd.Function):
         tmp = torch.empty_like(gs) if (H > 1 and W > 1) else None
         check(lib.jt_blur_backward(ptr(gs), ptr(gin), ptr(tmp), H, W, C, ptr(taps), taps.numel(), _stream()),
               "jt_blur_backward")
-        return factor_logical(gin), None
+        return factor_logical(gin.reshape(ctx.in_hw[0], ctx.in_hw[1], C)), None, None
 
 
-def blur_factor(x, taps):
-    return BlurFactor.apply(x, taps)
+def blur_factor(x, taps, reinterpret=False):
+    return BlurFactor.apply(x, taps, reinterpret)
 
 
 # ----------------------------------------------------------------------------------------------

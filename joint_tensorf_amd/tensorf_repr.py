@@ -342,14 +342,12 @@ class BAT_VMSplit(torch.nn.Module):
         g = self.gridSize.tolist()
         plane_hw = [(g[MAT_MODE[i][1]], g[MAT_MODE[i][0]]) for i in range(3)]
         if c2f_mode is not None:
-            for i in range(3):
-                if g[MAT_MODE[i][0]] != g[MAT_MODE[i][1]]:
-                    raise NotImplementedError(
-                        "blur of non-square planes reproduces a reshape quirk of the reference "
-                        "(SURVEY.md App. B-10); not built yet")
-            dP = [ops.blur_factor(p, self.kernel_density) for p in dP]
+            # the reference blurs planes through a reshape that exchanges (H, W) in the shape (bateRF.py:29,
+            # SURVEY.md App. B-10): the blurred plane i is [1, C, g[m0], g[m1]] and is sampled as such
+            plane_hw = [(g[MAT_MODE[i][0]], g[MAT_MODE[i][1]]) for i in range(3)]
+            dP = [ops.blur_factor(p, self.kernel_density, True) for p in dP]
             dL = [ops.blur_factor(p, self.kernel_density) for p in dL]
-            aP = [ops.blur_factor(p, self.kernel_color) for p in aP]
+            aP = [ops.blur_factor(p, self.kernel_color, True) for p in aP]
             aL = [ops.blur_factor(p, self.kernel_color) for p in aL]
         # white background: static flag or the reference's CPU coin (batBase.py:154)
         if white_bg:

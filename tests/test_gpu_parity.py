@@ -93,10 +93,6 @@ def replay_hip(fx, shade_impl, pin_rays=True, device="cuda"):
 
 
 def _supported(fx):
-    m = fx.meta
-    g = m["gridSize"]
-    if m["c2f_mode"] is not None and len(set(g)) != 1:
-        return False  # non-cubic blur quirk not built yet
     return True
 
 

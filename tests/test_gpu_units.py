@@ -90,6 +90,23 @@ def test_blur_plane_vs_oracle(shape, sigma):
     assert _rel(b.grad.cpu().numpy(), a.grad.numpy()) < 1e-5
 
 
+def test_blur_noncubic_reinterpret_vs_golden():
+    """the reference's reshape quirk on a non-square plane (known answer captured from the reference)."""
+    from joint_tensorf_amd import ops
+    d = np.load(GOLDEN + "/known_answers.npz")
+    x = torch.tensor(d["blur.noncubic.in"])  # [1,4,13,9] = [1,C,g[m1],g[m0]]
+    k = torch.tensor(d["blur.kernel"])
+    b = ops.factor_logical(ops.factor_storage(x).to(DEV))
+    out = ops.blur_factor(b, k.to(DEV), True)
+    assert tuple(out.shape) == tuple(d["blur.noncubic.out"].shape) == (1, 4, 9, 13)
+    np.testing.assert_allclose(out.cpu().numpy(), d["blur.noncubic.out"], atol=2e-5, rtol=1e-5)
+    # square plane: the re-interpretation is the identity (first 4 of the fixture's 5 channels; the kernels
+    # take channel counts that are multiples of 4)
+    cub = torch.tensor(d["blur.cubic.in"])[:, :4].contiguous()
+    outc = ops.blur_factor(ops.factor_logical(ops.factor_storage(cub).to(DEV)), k.to(DEV), True)
+    np.testing.assert_allclose(outc.cpu().numpy(), d["blur.cubic.out"][:, :4], atol=2e-5, rtol=1e-5)
+
+
 def test_blur_line_vs_oracle():
     from joint_tensorf_amd import ops
     g = torch.Generator().manual_seed(1)
