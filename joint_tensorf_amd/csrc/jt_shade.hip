@@ -960,9 +960,10 @@ static int shade_kind(const JtScene* s) {
   return -1;
 }
 
-// workspace = [sample-major records of one chunk of shaded samples | per-(chunk, block) partial weight
-// gradients].  The records are consumed by k_wgrad right after the chunk's backward kernel, so with the
-// default chunk they stay in the 256 MiB Infinity Cache.
+// workspace = [tile-blocked records of every chunk of shaded samples | per-(chunk, block) partial weight
+// gradients].  Every chunk has its own record block so that the weight-gradient GEMMs of all chunks can run
+// on an auxiliary stream, concurrently with whatever the caller enqueues next on the main stream (the
+// density backward: atomics / VALU bound, while the GEMMs are MFMA bound).
 static const int kChunkEntries = 1 << 20;
 static const int kWgradBlocks = 256;
 
@@ -972,11 +973,11 @@ struct WsLayout {
   static constexpr int NT3 = (C::IN3 + 31) / 32, NT1 = 5, NTB = (C::NC + 31) / 32;
   static constexpr size_t P3 = 1 * NT3 * 1024 + 32, P2 = (size_t)C::MT * C::MT * 1024 + C::MT * 32,
                           P1 = (size_t)C::MT * NT1 * 1024 + C::MT * 32, PB = 1 * NTB * 1024 + 32;
-  static size_t rec_floats() { return (size_t)B::REC_FLOATS * kChunkEntries; }
+  static size_t rec_floats_per_chunk() { return (size_t)B::REC_FLOATS * kChunkEntries; }
   static size_t slab_floats_per_chunk() { return (P3 + P2 + P1 + PB) * kWgradBlocks; }
   static size_t bytes(int cap) {
     const int nchunks = (cap + kChunkEntries - 1) / kChunkEntries;
-    return (rec_floats() + slab_floats_per_chunk() * (size_t)std::max(nchunks, 1)) * sizeof(float);
+    return (rec_floats_per_chunk() + slab_floats_per_chunk()) * (size_t)std::max(nchunks, 1) * sizeof(float);
   }
 };
 
@@ -1033,69 +1034,85 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
                             const float* rays_o, const float* rays_d, const float* jitter, const float* zvals,
                             const float* tmin, const int32_t* offset, int R, const int32_t* eray,
                             const int32_t* esmp, const float* vdir, const float* g_rgb_s, float* g_xyz, int cap,
-                            float* ws, size_t ws_bytes, int flags, hipStream_t st) {
+                            float* ws, size_t ws_bytes, int flags, hipStream_t st, hipStream_t aux,
+                            hipEvent_t ev_fork, hipEvent_t ev_join) {
   typedef BwdCfg<C> B;
   typedef WsLayout<C> W;
   const size_t lds = B::LDS_FLOATS * sizeof(float);
   if (lds > 160 * 1024) return JT_ERR_UNSUPPORTED;
   if (ws_bytes < W::bytes(cap)) return JT_ERR_ARG;
   const int chunk = kChunkEntries;
+  const int nchunks = (cap + chunk - 1) / chunk;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_bwd<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-  const size_t RC = B::REC_FLOATS;
-  float* rec = ws;
-  float* slabs = ws + W::rec_floats();
+  float* recs = ws;
+  float* slabs = ws + W::rec_floats_per_chunk() * (size_t)nchunks;
   const size_t cstride = W::slab_floats_per_chunk();
   const int nb = kWgradBlocks;
   const char* abl_env = getenv("JT_ABLATE");  // profiling only: 1 = no scatter, 2 = no records, 4 = no wgrad
   const int ablate = (abl_env ? atoi(abl_env) : 0) | ((flags & JT_SHADE_SKIP_WGRAD) ? 4 : 0);
   constexpr int NT3 = W::NT3, NT1 = W::NT1, NTB = W::NTB;
   constexpr int XF1 = (C::KIND == JT_MLP_FEA) ? 1 : 2;
-  int ci = 0;
-  for (int start = 0; start < cap; start += chunk, ++ci) {
-    const int ccap = std::min(chunk, cap - start);
+  // ---- per-sample backward of every chunk on the main stream ----
+  for (int ci = 0; ci < nchunks; ++ci) {
+    const int start = ci * chunk, ccap = std::min(chunk, cap - start);
     long tiles = ((long)ccap + 31) / 32;
     int blocks = (int)std::min<long>((tiles + B::NWAVE - 1) / B::NWAVE, 256);
     hipLaunchKernelGGL(k_shade_bwd<C>, dim3(blocks), dim3(512), lds, st, D, M, pm, G, rays_o, rays_d, jitter, zvals,
-                       tmin, offset, R, eray, esmp, vdir, g_rgb_s, g_xyz, rec, start, ccap, cap, ablate);
+                       tmin, offset, R, eray, esmp, vdir, g_rgb_s, g_xyz, recs + W::rec_floats_per_chunk() * ci,
+                       start, ccap, cap, ablate);
     JT_LAUNCH_CHECK();
-    if (ablate & 4) continue;
+  }
+  if (ablate & 4) return JT_OK;
+  // ---- weight gradients: on the auxiliary stream when the caller provided one ----
+  hipStream_t ws_st = st;
+  if (aux && ev_fork && ev_join) {
+    if (hipEventRecord(ev_fork, st) != hipSuccess) return JT_ERR_ARG;
+    if (hipStreamWaitEvent(aux, ev_fork, 0) != hipSuccess) return JT_ERR_ARG;
+    ws_st = aux;
+  }
+  const int RR = B::REC_FLOATS;
+  for (int ci = 0; ci < nchunks; ++ci) {
+    const int start = ci * chunk, ccap = std::min(chunk, cap - start);
+    const float* rec = recs + W::rec_floats_per_chunk() * ci;
     // dW3/db3 = GO^T MID ; dW2/db2 = G2^T H1 ; dW1/db1 = G1^T X(F, d) ; dBasis = GF^T PROD
     float* s3 = slabs + (size_t)ci * cstride;
     float* s2 = s3 + W::P3 * nb;
     float* s1 = s2 + W::P2 * nb;
     float* sb = s1 + W::P1 * nb;
-    const int RR = B::REC_FLOATS;
-    hipLaunchKernelGGL((k_wgrad<1, NT3, 0>), dim3(nb), dim3(256), 0, st, rec, B::R_GO, 3, B::R_MID, C::IN3, B::R_F,
+    hipLaunchKernelGGL((k_wgrad<1, NT3, 0>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_GO, 3, B::R_MID, C::IN3, B::R_F,
                        B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s3);
     JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad<C::MT, C::MT, 0>), dim3(nb), dim3(256), 0, st, rec, B::R_G2, C::HID, B::R_H1, C::HID,
+    hipLaunchKernelGGL((k_wgrad<C::MT, C::MT, 0>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_G2, C::HID, B::R_H1, C::HID,
                        B::R_F, B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s2);
     JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad<C::MT, NT1, XF1>), dim3(nb), dim3(256), 0, st, rec, B::R_G1, C::HID, B::R_F, C::IN1,
+    hipLaunchKernelGGL((k_wgrad<C::MT, NT1, XF1>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_G1, C::HID, B::R_F, C::IN1,
                        B::R_F, B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s1);
     JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad<1, NTB, 0>), dim3(nb), dim3(256), 0, st, rec, B::R_GF, C::APP, B::R_PROD, C::NC,
+    hipLaunchKernelGGL((k_wgrad<1, NTB, 0>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_GF, C::APP, B::R_PROD, C::NC,
                        B::R_F, B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, sb);
     JT_LAUNCH_CHECK();
   }
-  if (!(ablate & 4)) {
+  {
     float* s3 = slabs;
     float* s2 = s3 + W::P3 * nb;
     float* s1 = s2 + W::P2 * nb;
     float* sb = s1 + W::P1 * nb;
-    hipLaunchKernelGGL((k_wgrad_reduce<1, NT3, 0>), dim3((W::P3 + 255) / 256, 32), dim3(256), 0, st, s3, nb, cstride,
+    hipLaunchKernelGGL((k_wgrad_reduce<1, NT3, 0>), dim3((W::P3 + 255) / 256, 32), dim3(256), 0, ws_st, s3, nb, cstride,
                        chunk, offset, R, cap, 3, C::IN3, C::APP, GM.w3, C::IN3, GM.b3);
     JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad_reduce<C::MT, C::MT, 0>), dim3((W::P2 + 255) / 256, 32), dim3(256), 0, st, s2, nb,
+    hipLaunchKernelGGL((k_wgrad_reduce<C::MT, C::MT, 0>), dim3((W::P2 + 255) / 256, 32), dim3(256), 0, ws_st, s2, nb,
                        cstride, chunk, offset, R, cap, C::HID, C::HID, C::APP, GM.w2, C::HID, GM.b2);
     JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad_reduce<C::MT, NT1, XF1>), dim3((W::P1 + 255) / 256, 32), dim3(256), 0, st, s1, nb,
+    hipLaunchKernelGGL((k_wgrad_reduce<C::MT, NT1, XF1>), dim3((W::P1 + 255) / 256, 32), dim3(256), 0, ws_st, s1, nb,
                        cstride, chunk, offset, R, cap, C::HID, C::IN1, C::APP, GM.w1, C::IN1, GM.b1);
     JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad_reduce<1, NTB, 0>), dim3((W::PB + 255) / 256, 32), dim3(256), 0, st, sb, nb, cstride,
+    hipLaunchKernelGGL((k_wgrad_reduce<1, NTB, 0>), dim3((W::PB + 255) / 256, 32), dim3(256), 0, ws_st, sb, nb, cstride,
                        chunk, offset, R, cap, C::APP, C::NC, C::APP, GM.basis, C::NC, (float*)nullptr);
     JT_LAUNCH_CHECK();
+  }
+  if (ws_st != st) {
+    if (hipEventRecord(ev_join, aux) != hipSuccess) return JT_ERR_ARG;
   }
   return JT_OK;
 }
@@ -1106,7 +1123,7 @@ extern "C" int jt_shade_backward(const JtScene* scene, const JtFactors* factors,
                                  const int32_t* entry_ray, const int32_t* entry_smp, const float* viewdirs,
                                  const float* g_rgb_s, const JtFactors* g_factors, const JtMlp* g_mlp,
                                  float* g_xyz_app, int n_entries_max, void* workspace, size_t workspace_bytes,
-                                 int flags, void* stream) {
+                                 int flags, void* stream, void* aux_stream, void* ev_fork, void* ev_join) {
   Dev D;
   int rc = make_dev(scene, factors, &D);
   if (rc) return rc;
@@ -1129,8 +1146,10 @@ extern "C" int jt_shade_backward(const JtScene* scene, const JtFactors* factors,
   if (kind == 0)
     return launch_shade_bwd<CfgBlender>(D, M, pm, *g_factors, *g_mlp, rays_o, rays_d, jitter, zvals, tmin,
                                         shade_offset, n_rays, entry_ray, entry_smp, viewdirs, g_rgb_s, g_xyz_app,
-                                        n_entries_max, (float*)workspace, workspace_bytes, flags, st);
+                                        n_entries_max, (float*)workspace, workspace_bytes, flags, st, (hipStream_t)aux_stream,
+                                        (hipEvent_t)ev_fork, (hipEvent_t)ev_join);
   return launch_shade_bwd<CfgLlff>(D, M, pm, *g_factors, *g_mlp, rays_o, rays_d, jitter, zvals, tmin, shade_offset,
                                    n_rays, entry_ray, entry_smp, viewdirs, g_rgb_s, g_xyz_app, n_entries_max,
-                                   (float*)workspace, workspace_bytes, flags, st);
+                                   (float*)workspace, workspace_bytes, flags, st, (hipStream_t)aux_stream,
+                                   (hipEvent_t)ev_fork, (hipEvent_t)ev_join);
 }

@@ -22,6 +22,21 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_AUX = {}
+
+
+def _aux_stream(dev):
+    """per-device auxiliary stream + fork/join events for the overlapped weight-gradient GEMMs."""
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    if key not in _AUX:
+        with torch.cuda.device(key):
+            _AUX[key] = (torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event())
+            # touch the events once so that their handles exist
+            for ev in _AUX[key][1:]:
+                ev.record()
+    return _AUX[key]
+
+
 def factor_storage(p):
     """logical [1,C,H,W] -> contiguous [H,W,C] tensor (no copy if p is stored channel-last)."""
     x = p.detach()[0].permute(1, 2, 0)
@@ -246,6 +261,7 @@ class RenderRays(torch.autograd.Function):
         gal = [torch.zeros_like(t) for t in sal]
         gfac = _factors_struct(gdp, gdl, gap, gal)
         g_xyz = torch.empty(cap_alloc, 3, **f32)
+        join = None
         if cfg.shade_impl == "torch":
             g_mlp = [torch.zeros_like(t) for t in mlp_t]
             if n > 0:
@@ -268,9 +284,16 @@ class RenderRays(torch.autograd.Function):
             # records of one chunk of shaded samples (consumed by the weight-gradient GEMMs chunk by chunk)
             nbytes = lib.jt_shade_workspace_bytes(scene, cap)
             ws = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8)
+            aux, ev_fork, ev_join = _aux_stream(dev)
+            # the weight-gradient GEMMs read mlp_t / ws and write g_mlp on the auxiliary stream
+            for t in list(mlp_t) + g_mlp + [ws, offset]:
+                t.record_stream(aux)
             check(lib.jt_shade_backward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
                                         ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(g_rgb_s),
-                                        gfac, gm, ptr(g_xyz), cap, ptr(ws), nbytes, 0, st), "jt_shade_backward")
+                                        gfac, gm, ptr(g_xyz), cap, ptr(ws), nbytes, 0, st,
+                                        ctypes.c_void_p(aux.cuda_stream), ctypes.c_void_p(ev_fork.cuda_event),
+                                        ctypes.c_void_p(ev_join.cuda_event)), "jt_shade_backward")
+            join = ev_join
         g_o = torch.empty(R, 3, **f32)
         g_d = torch.empty(R, 3, **f32)
         mws_bytes = lib.jt_march_backward_workspace_bytes(scene, R)
@@ -279,6 +302,8 @@ class RenderRays(torch.autograd.Function):
                                     ptr(sigma_feat), ptr(weight), ptr(tmin), ptr(offset), ptr(sidx), ptr(rgb_s),
                                     ptr(cmask), ptr(g_rgb), ptr(g_op), ptr(g_xyz), gfac, ptr(g_o), ptr(g_d),
                                     ptr(mws), mws_bytes, st), "jt_march_backward")
+        if join is not None:
+            torch.cuda.current_stream().wait_event(join)  # weight gradients done before anyone reads them
         g_factors = [factor_logical(t) for t in gdp + gdl + gap + gal]
         out = [None, g_o, g_d, None, None] + g_factors + list(g_mlp)
         return tuple(out)
@@ -526,7 +551,7 @@ class KernelProbe:
         ws = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8)
         t_bwd = timed(lambda: check(lib.jt_shade_backward(
             scene, fac, mlp, ptr(self.o), ptr(self.d), ptr(self.jitter), None, ptr(tmin), ptr(offset), R, ptr(eray),
-            ptr(esmp), ptr(vdir), ptr(g_rgb_s), gfac, gm, ptr(g_xyz), nb, ptr(ws), nbytes, 1, st),
+            ptr(esmp), ptr(vdir), ptr(g_rgb_s), gfac, gm, ptr(g_xyz), nb, ptr(ws), nbytes, 1, st, None, None, None),
             "jt_shade_backward"))
         peak = 8000.0
         bwd = nb * 2 * bytes_per / t_bwd / 1e9
