@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void k_march_bwd_walk(Dev D, JtFactors G, cons
     float gn3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
-      wk[pl].advance(cur[pl].t, cur[pl].l);
+      wk[pl].advance(cur[pl].t.ax.i0, cur[pl].t.ay.i0, cur[pl].l.i0);
       float g[NCH];
 #pragma unroll
       for (int q = 0; q < NCH; ++q) g[q] = (cl + 16 * q < CD) ? gc : 0.f;

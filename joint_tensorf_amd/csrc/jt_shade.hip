@@ -491,7 +491,7 @@ __device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, c
       const float* n = geo + (sidx + 1) * 4;
       tap_load<NCH, C::CA>(nxt, P, Ln, n[m0], n[m1], n[mv], H, W, L, cl);
     }
-    if (on) wk.advance(cur.t, cur.l);
+    if (on) wk.advance(cur.t.ax.i0, cur.t.ay.i0, cur.l.i0);
     float g[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {

@@ -8,6 +8,7 @@ a logical [1,C,H,W] parameter without a copy when the parameter already lives ch
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -23,6 +24,22 @@ def _stream():
 
 
 _AUX = {}
+_WS = {}
+
+
+def _workspace(dev, name, nbytes):
+    """Persistent scratch buffer (grown on demand).  Re-used across iterations instead of a fresh
+    torch.empty per call: multi-GB blocks that are also touched by the auxiliary stream make the caching
+    allocator fall back to hipMalloc / hipFree, which shows up as multi-ms spikes."""
+    key = (str(dev), name)
+    t = _WS.get(key)
+    if t is None or t.numel() < nbytes:
+        _WS[key] = t = torch.empty(max(int(nbytes), 16), device=dev, dtype=torch.uint8)
+    return t
+
+# weight-gradient GEMMs on an auxiliary stream (overlaps the MFMA-bound GEMMs with the atomics-bound density
+# backward); JT_NO_AUX=1 keeps everything on one stream, e.g. for clean per-kernel profiles
+USE_AUX_STREAM = os.environ.get("JT_NO_AUX", "0") != "1"
 
 
 def _aux_stream(dev):
@@ -283,21 +300,25 @@ class RenderRays(torch.autograd.Function):
             gm = _mlp_struct(*g_mlp)
             # records of one chunk of shaded samples (consumed by the weight-gradient GEMMs chunk by chunk)
             nbytes = lib.jt_shade_workspace_bytes(scene, cap)
-            ws = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8)
-            aux, ev_fork, ev_join = _aux_stream(dev)
-            # the weight-gradient GEMMs read mlp_t / ws and write g_mlp on the auxiliary stream
-            for t in list(mlp_t) + g_mlp + [ws, offset]:
-                t.record_stream(aux)
+            ws = _workspace(dev, "shade_bwd", nbytes)
+            if USE_AUX_STREAM:
+                aux, ev_fork, ev_join = _aux_stream(dev)
+                # the weight-gradient GEMMs read mlp_t / ws and write g_mlp on the auxiliary stream
+                for t in list(mlp_t) + g_mlp + [offset]:
+                    t.record_stream(aux)
+                h_aux = (ctypes.c_void_p(aux.cuda_stream), ctypes.c_void_p(ev_fork.cuda_event),
+                         ctypes.c_void_p(ev_join.cuda_event))
+                join = ev_join
+            else:
+                h_aux = (None, None, None)
             check(lib.jt_shade_backward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
                                         ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(g_rgb_s),
-                                        gfac, gm, ptr(g_xyz), cap, ptr(ws), nbytes, 0, st,
-                                        ctypes.c_void_p(aux.cuda_stream), ctypes.c_void_p(ev_fork.cuda_event),
-                                        ctypes.c_void_p(ev_join.cuda_event)), "jt_shade_backward")
-            join = ev_join
+                                        gfac, gm, ptr(g_xyz), cap, ptr(ws), nbytes, 0, st, *h_aux),
+                  "jt_shade_backward")
         g_o = torch.empty(R, 3, **f32)
         g_d = torch.empty(R, 3, **f32)
         mws_bytes = lib.jt_march_backward_workspace_bytes(scene, R)
-        mws = torch.empty(mws_bytes, device=dev, dtype=torch.uint8)
+        mws = _workspace(dev, "march_bwd", mws_bytes)
         check(lib.jt_march_backward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals), R,
                                     ptr(sigma_feat), ptr(weight), ptr(tmin), ptr(offset), ptr(sidx), ptr(rgb_s),
                                     ptr(cmask), ptr(g_rgb), ptr(g_op), ptr(g_xyz), gfac, ptr(g_o), ptr(g_d),
