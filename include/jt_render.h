@@ -231,6 +231,32 @@ int jt_factor_reg_forward(const float* x, int H, int W, int C, float* out3, void
 int jt_factor_reg_backward(const float* x, int H, int W, int C, const float* coef3, float* g, int accumulate,
                            void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Photometric loss.  Replaces the render term of tensorf.Graph.compute_loss (model/tensorf.py:96-124) with
+ * Graph.MSE_loss = nanmean of the squared error (model/base.py:259-261), including the `image[:, ray_idx]`
+ * gather: rgb [B][r][3], image [B][3][n_pixels], ray_idx [r] int64; edge_mask [B][n_pixels] u8 or NULL.
+ *   edge_mask == NULL: loss = nanmean((rgb - img)^2)
+ *   else             : loss = edge_factor * nanmean((rgb*m - img*m)^2) + non_edge_factor * nanmean((rgb*(1-m) - img*(1-m))^2)
+ * acc4: 4 floats of device scratch shared by forward and backward; g_loss: dL/dloss on the device. */
+int jt_render_loss_forward(const float* rgb, const float* image, const int64_t* ray_idx, const uint8_t* edge_mask,
+                           int n_views, int rays_per_view, int n_pixels, float edge_factor, float non_edge_factor,
+                           float* acc4, float* loss, void* stream);
+int jt_render_loss_backward(const float* rgb, const float* image, const int64_t* ray_idx, const uint8_t* edge_mask,
+                            int n_views, int rays_per_view, int n_pixels, float edge_factor, float non_edge_factor,
+                            const float* acc4, const float* g_loss, float* g_rgb, void* stream);
+
+/* All regularisers of one scene in one call (replaces the loop bodies of model/tensorf.py:127-130):
+ *   out3 = { density_L1(), TV_loss_density(TVLoss()), TV_loss_app(TVLoss()) }   (tensoRF.py:212-228).
+ * plane_hw_line[9] = {H_i, W_i, L_i} for i = 0..2; scratch36: 36 floats of device scratch.
+ * backward: g3 = dL/d out3 on the device; ADDS the gradients into g_factors (density planes + lines always,
+ * appearance planes when with_tv_app != 0; with_tv_density is informational -- its coefficient is on the
+ * device and zero when the term is unused). */
+int jt_reg_losses_forward(const JtFactors* factors, const int32_t* plane_hw_line, int n_comp_density,
+                          int n_comp_app, float* scratch36, float* out3, void* stream);
+int jt_reg_losses_backward(const JtFactors* factors, const int32_t* plane_hw_line, int n_comp_density,
+                           int n_comp_app, const float* g3, int with_tv_density, int with_tv_app,
+                           const JtFactors* g_factors, float* scratch36, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

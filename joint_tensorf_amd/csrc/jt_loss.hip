@@ -1,0 +1,117 @@
+// Photometric loss of the training step in one kernel each way.
+// Replaces tensorf.Graph.compute_loss's render term (model/tensorf.py:96-124) with Graph.MSE_loss =
+// nanmean of squared error (model/base.py:259-261): the GT pixel gather `image[:, ray_idx]`, the hard
+// edge-mask split  edge_factor * MSE(rgb*m, img*m) + non_edge_factor * MSE(rgb*(1-m), img*(1-m))  and the
+// plain MSE; the stock-op version is ~30 tiny launches forward + backward.
+#include "jt_common.h"
+
+namespace jt {
+
+// acc[0] = sum (m d)^2, acc[1] = #non-NaN of it, acc[2] = sum ((1-m) d)^2, acc[3] = #non-NaN
+__global__ __launch_bounds__(256) void k_render_loss_fwd(const float* __restrict__ rgb, const float* __restrict__ image,
+                                                         const int64_t* __restrict__ ray_idx,
+                                                         const uint8_t* __restrict__ mask, int B, int r, int HW,
+                                                         float* __restrict__ acc) {
+  __shared__ float red[4][4];
+  const long n = (long)B * r * 3;
+  float s0 = 0.f, c0 = 0.f, s1 = 0.f, c1 = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % 3);
+    const long bk = i / 3;
+    const int k = (int)(bk % r), b = (int)(bk / r);
+    const long pix = ray_idx[k];
+    const float d = rgb[i] - image[((long)b * 3 + ch) * HW + pix];
+    const float m = mask ? (float)mask[(long)b * HW + pix] : 1.f;
+    const float e = m * d, ne = (1.f - m) * d;
+    if (e == e) {
+      s0 += e * e;
+      c0 += 1.f;
+    }
+    if (ne == ne) {
+      s1 += ne * ne;
+      c1 += 1.f;
+    }
+  }
+  s0 = wave_sum(s0);
+  c0 = wave_sum(c0);
+  s1 = wave_sum(s1);
+  c1 = wave_sum(c1);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[wv][0] = s0;
+    red[wv][1] = c0;
+    red[wv][2] = s1;
+    red[wv][3] = c1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) atomicAdd(acc + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void k_render_loss_final(const float* __restrict__ acc, float fe, float fne, int masked,
+                                    float* __restrict__ loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    // nanmean of an all-NaN tensor is NaN (0/0), as in torch
+    const float edge = acc[0] / acc[1];
+    loss[0] = masked ? fe * edge + fne * (acc[2] / acc[3]) : edge;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_render_loss_bwd(const float* __restrict__ rgb, const float* __restrict__ image,
+                                                         const int64_t* __restrict__ ray_idx,
+                                                         const uint8_t* __restrict__ mask, int B, int r, int HW,
+                                                         const float* __restrict__ acc, float fe, float fne,
+                                                         const float* __restrict__ g, float* __restrict__ g_rgb) {
+  const long n = (long)B * r * 3;
+  const float gg = g[0];
+  const float ke = (mask ? fe : 1.f) * 2.f / acc[1], kne = mask ? fne * 2.f / acc[3] : 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % 3);
+    const long bk = i / 3;
+    const int k = (int)(bk % r), b = (int)(bk / r);
+    const long pix = ray_idx[k];
+    const float d = rgb[i] - image[((long)b * 3 + ch) * HW + pix];
+    const float m = mask ? (float)mask[(long)b * HW + pix] : 1.f;
+    const float e = m * d, ne = (1.f - m) * d;
+    float v = 0.f;
+    if (e == e) v += ke * m * e;
+    if (mask && ne == ne) v += kne * (1.f - m) * ne;
+    g_rgb[i] = gg * v;
+  }
+}
+
+}  // namespace jt
+
+using namespace jt;
+
+extern "C" int jt_render_loss_forward(const float* rgb, const float* image, const int64_t* ray_idx,
+                                      const uint8_t* edge_mask, int n_views, int rays_per_view, int n_pixels,
+                                      float edge_factor, float non_edge_factor, float* acc4, float* loss,
+                                      void* stream) {
+  if (!rgb || !image || !ray_idx || !acc4 || !loss || n_views < 1 || rays_per_view < 1 || n_pixels < 1)
+    return JT_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(acc4, 0, 4 * sizeof(float), st) != hipSuccess) return JT_ERR_ARG;
+  long n = (long)n_views * rays_per_view * 3;
+  int blocks = (int)min((n + 255) / 256, 512L);
+  hipLaunchKernelGGL(k_render_loss_fwd, dim3(blocks), dim3(256), 0, st, rgb, image, ray_idx, edge_mask, n_views,
+                     rays_per_view, n_pixels, acc4);
+  JT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_render_loss_final, dim3(1), dim3(64), 0, st, (const float*)acc4, edge_factor,
+                     non_edge_factor, edge_mask ? 1 : 0, loss);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
+extern "C" int jt_render_loss_backward(const float* rgb, const float* image, const int64_t* ray_idx,
+                                       const uint8_t* edge_mask, int n_views, int rays_per_view, int n_pixels,
+                                       float edge_factor, float non_edge_factor, const float* acc4,
+                                       const float* g_loss, float* g_rgb, void* stream) {
+  if (!rgb || !image || !ray_idx || !acc4 || !g_loss || !g_rgb || n_views < 1 || rays_per_view < 1 || n_pixels < 1)
+    return JT_ERR_ARG;
+  long n = (long)n_views * rays_per_view * 3;
+  int blocks = (int)min((n + 255) / 256, 512L);
+  hipLaunchKernelGGL(k_render_loss_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rgb, image, ray_idx,
+                     edge_mask, n_views, rays_per_view, n_pixels, acc4, edge_factor, non_edge_factor, g_loss, g_rgb);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}

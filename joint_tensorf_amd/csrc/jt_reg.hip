@@ -114,3 +114,122 @@ extern "C" int jt_factor_reg_backward(const float* x, int H, int W, int C, const
   JT_LAUNCH_CHECK();
   return JT_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// All regularisers of one scene in one call: L1 over the six density factors, TV over the three density
+// planes and over the three appearance planes.  One sums launch per tensor + one tiny combine kernel instead
+// of ~150 elementwise / reduce launches of the stock-op formulation (which left the host launch-bound).
+// ---------------------------------------------------------------------------------------------
+namespace jt {
+
+struct RegTensor {
+  const float* x;
+  float* g;
+  int H, W, C;
+};
+
+struct RegSet {
+  RegTensor t[12];  // 0-2 density planes, 3-5 density lines, 6-8 app planes, 9-11 app lines
+};
+
+// out3 = {L1, TV_density, TV_color} with the reference's normalisations (tensoRF.py:212-228, tensorBase.py:21-38)
+__global__ void k_reg_combine(const float* __restrict__ sums, RegSet S, float* __restrict__ out3) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float l1 = 0.f, tvd = 0.f, tva = 0.f;
+  for (int i = 0; i < 6; ++i) l1 += sums[i * 3] / ((float)S.t[i].H * S.t[i].W * S.t[i].C);
+  for (int i = 0; i < 3; ++i) {
+    const RegTensor& a = S.t[i];
+    const RegTensor& b = S.t[6 + i];
+    float ta = 0.f, tb = 0.f;
+    if (a.H > 1) ta += sums[i * 3 + 1] / ((float)a.C * (a.H - 1) * a.W);
+    if (a.W > 1) ta += sums[i * 3 + 2] / ((float)a.C * a.H * (a.W - 1));
+    if (b.H > 1) tb += sums[(6 + i) * 3 + 1] / ((float)b.C * (b.H - 1) * b.W);
+    if (b.W > 1) tb += sums[(6 + i) * 3 + 2] / ((float)b.C * b.H * (b.W - 1));
+    tvd += 2.f * ta * 1e-2f;
+    tva += 2.f * tb * 1e-2f;
+  }
+  out3[0] = l1;
+  out3[1] = tvd;
+  out3[2] = tva;
+}
+
+// coefficient triple of tensor i from the upstream gradients g3 = dL/d{L1, TV_density, TV_color}
+__global__ void k_reg_coefs(const float* __restrict__ g3, RegSet S, float* __restrict__ coef) {
+  const int i = threadIdx.x;
+  if (i >= 12) return;
+  const RegTensor& a = S.t[i];
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  if (i < 6) c0 = g3[0] / ((float)a.H * a.W * a.C);
+  const bool dplane = i < 3, aplane = (i >= 6 && i < 9);
+  if (dplane || aplane) {
+    const float gt = dplane ? g3[1] : g3[2];
+    if (a.H > 1) c1 = gt * 2e-2f / ((float)a.C * (a.H - 1) * a.W);
+    if (a.W > 1) c2 = gt * 2e-2f / ((float)a.C * a.H * (a.W - 1));
+  }
+  coef[i * 3] = c0;
+  coef[i * 3 + 1] = c1;
+  coef[i * 3 + 2] = c2;
+}
+
+}  // namespace jt
+
+static int reg_set(const JtFactors* f, const JtFactors* g, const int32_t* hw, int Cd, int Ca, RegSet* S) {
+  if (!f || !hw || Cd < 4 || Ca < 4 || (Cd % 4) || (Ca % 4)) return JT_ERR_ARG;
+  for (int i = 0; i < 3; ++i) {
+    const int H = hw[i * 3], W = hw[i * 3 + 1], L = hw[i * 3 + 2];
+    if (H < 1 || W < 1 || L < 1) return JT_ERR_ARG;
+    S->t[i] = {f->density_plane[i], g ? g->density_plane[i] : nullptr, H, W, Cd};
+    S->t[3 + i] = {f->density_line[i], g ? g->density_line[i] : nullptr, L, 1, Cd};
+    S->t[6 + i] = {f->app_plane[i], g ? g->app_plane[i] : nullptr, H, W, Ca};
+    S->t[9 + i] = {f->app_line[i], g ? g->app_line[i] : nullptr, L, 1, Ca};
+  }
+  for (int i = 0; i < 12; ++i)
+    if (!S->t[i].x) return JT_ERR_ARG;
+  return JT_OK;
+}
+
+extern "C" int jt_reg_losses_forward(const JtFactors* factors, const int32_t* plane_hw_line, int n_comp_density,
+                                     int n_comp_app, float* scratch36, float* out3, void* stream) {
+  RegSet S;
+  int rc = reg_set(factors, nullptr, plane_hw_line, n_comp_density, n_comp_app, &S);
+  if (rc) return rc;
+  if (!scratch36 || !out3) return JT_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(scratch36, 0, 36 * sizeof(float), st) != hipSuccess) return JT_ERR_ARG;
+  for (int i = 0; i < 9; ++i) {  // app lines (9-11) enter no regulariser
+    const RegTensor& t = S.t[i];
+    long total = (long)t.H * t.W * (t.C / 4);
+    int blocks = (int)min((total + 255) / 256, 1024L);
+    hipLaunchKernelGGL(k_factor_reg_fwd, dim3(blocks), dim3(256), 0, st, t.x, t.H, t.W, t.C, scratch36 + i * 3);
+    JT_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_reg_combine, dim3(1), dim3(64), 0, st, (const float*)scratch36, S, out3);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
+extern "C" int jt_reg_losses_backward(const JtFactors* factors, const int32_t* plane_hw_line, int n_comp_density,
+                                      int n_comp_app, const float* g3, int with_tv_density, int with_tv_app,
+                                      const JtFactors* g_factors, float* scratch36, void* stream) {
+  RegSet S;
+  int rc = reg_set(factors, g_factors, plane_hw_line, n_comp_density, n_comp_app, &S);
+  if (rc) return rc;
+  if (!g3 || !scratch36 || !g_factors) return JT_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_reg_coefs, dim3(1), dim3(64), 0, st, g3, S, scratch36);
+  JT_LAUNCH_CHECK();
+  for (int i = 0; i < 9; ++i) {
+    const bool dens = i < 6;
+    const bool need = dens || (i >= 6 && with_tv_app);  // density tensors always carry the L1 term
+    if (!need) continue;
+    const RegTensor& t = S.t[i];
+    if (!t.g) return JT_ERR_ARG;
+    (void)with_tv_density;  // the TV coefficient of a density plane is on the device (0 when its weight is 0)
+    long total = (long)t.H * t.W * (t.C / 4);
+    int blocks = (int)min((total + 255) / 256, 2048L);
+    hipLaunchKernelGGL(k_factor_reg_bwd, dim3(blocks), dim3(256), 0, st, t.x, t.H, t.W, t.C,
+                       (const float*)(scratch36 + i * 3), t.g, 1);
+    JT_LAUNCH_CHECK();
+  }
+  return JT_OK;
+}

@@ -282,25 +282,36 @@ class Graph(torch.nn.Module):
     def compute_loss(self, opt, var, mode=None):
         loss = Opt()
         batch_size = len(var.idx)
-        image = var.image.view(batch_size, 3, opt.H * opt.W).permute(0, 2, 1)
-        if mode in ("train", "test-optim"):
-            image = image[:, var.ray_idx]
         if opt.loss_weight.render is not None:
             edge_on = False
             if _has(opt, "edge_mask_on_render_loss") and opt.edge_mask_on_render_loss:
                 edge_on = (self.it % 2 == 0) if (_has(opt, "alternate_edge_loss") and opt.alternate_edge_loss) else True
-            if edge_on and mode == "train" and self.it < opt.edge_mask_before_iter:
-                m = var.train_edge_masks[:, var.ray_idx].view(batch_size, len(var.ray_idx), 1).expand(-1, -1, 3)
-                if _has(opt, "soft_edge_loss") and opt.soft_edge_loss:
-                    m = m * opt.edge_loss_factor + opt.non_edge_loss_factor
-                    loss.render = self.MSE_loss(var.rgb * m, image * m)
+            use_edge = edge_on and mode == "train" and self.it < opt.edge_mask_before_iter
+            soft = use_edge and _has(opt, "soft_edge_loss") and opt.soft_edge_loss
+            fused = var.rgb.is_cuda and mode in ("train", "test-optim") and not soft
+            if fused:
+                # GT gather + (edge-split) nanmean MSE in one kernel each way (jt_render_loss_*)
+                if use_edge:
+                    loss.render = ops.render_loss(var.rgb, var.image, var.ray_idx, var.train_edge_masks,
+                                                  opt.edge_loss_factor, opt.non_edge_loss_factor)
                 else:
-                    edge = self.MSE_loss(var.rgb * m, image * m)
-                    non_edge = self.MSE_loss(var.rgb * (1 - m), image * (1 - m))
-                    loss.render = opt.edge_loss_factor * edge + opt.non_edge_loss_factor * non_edge
+                    loss.render = ops.render_loss(var.rgb, var.image, var.ray_idx)
             else:
-                loss.render = self.MSE_loss(var.rgb, image)
+                image = var.image.view(batch_size, 3, opt.H * opt.W).permute(0, 2, 1)
+                if mode in ("train", "test-optim"):
+                    image = image[:, var.ray_idx]
+                if use_edge:
+                    m = var.train_edge_masks[:, var.ray_idx].view(batch_size, len(var.ray_idx), 1).expand(-1, -1, 3)
+                    if soft:
+                        m = m * opt.edge_loss_factor + opt.non_edge_loss_factor
+                        loss.render = self.MSE_loss(var.rgb * m, image * m)
+                    else:
+                        loss.render = opt.edge_loss_factor * self.MSE_loss(var.rgb * m, image * m) + \
+                            opt.non_edge_loss_factor * self.MSE_loss(var.rgb * (1 - m), image * (1 - m))
+                else:
+                    loss.render = self.MSE_loss(var.rgb, image)
         tf = self.nerf.tensorf
+        tf.reg_with_tv = (float(opt.loss_weight.TV_density or 0) != 0.0, float(opt.loss_weight.TV_color or 0) != 0.0)
         loss.L1 = tf.density_L1()
         loss.TV_density = tf.TV_loss_density(self.tvloss)
         loss.TV_color = tf.TV_loss_app(self.tvloss)

@@ -413,6 +413,86 @@ def factor_reg(x):
     return FactorReg.apply(x)
 
 
+class RegLosses(torch.autograd.Function):
+    """(L1, TV_density, TV_color) of a scene's twelve factors in one ABI call each way."""
+
+    @staticmethod
+    def forward(ctx, with_tv_density, with_tv_app, *factors):
+        dp, dl, ap, al = factors[0:3], factors[3:6], factors[6:9], factors[9:12]
+        st_ = [[factor_storage(p) for p in lst] for lst in (dp, dl, ap, al)]
+        dev = st_[0][0].device
+        hw = []
+        for i in range(3):
+            H, W, _ = st_[0][i].shape
+            hw += [H, W, st_[1][i].shape[0]]
+        hw_arr = (ctypes.c_int32 * 9)(*hw)
+        fac = _factors_struct(*st_)
+        scratch = torch.empty(36, device=dev, dtype=torch.float32)
+        out = torch.empty(3, device=dev, dtype=torch.float32)
+        Cd, Ca = st_[0][0].shape[2], st_[2][0].shape[2]
+        check(lib.jt_reg_losses_forward(fac, hw_arr, Cd, Ca, ptr(scratch), ptr(out), _stream()),
+              "jt_reg_losses_forward")
+        ctx.saved = (st_, hw, Cd, Ca, bool(with_tv_density), bool(with_tv_app))
+        return out
+
+    @staticmethod
+    def backward(ctx, g3):
+        st_, hw, Cd, Ca, wd, wa = ctx.saved
+        dev = st_[0][0].device
+        hw_arr = (ctypes.c_int32 * 9)(*hw)
+        fac = _factors_struct(*st_)
+        gd = [torch.zeros_like(t) for t in st_[0]]
+        gl = [torch.zeros_like(t) for t in st_[1]]
+        ga = [torch.zeros_like(t) for t in st_[2]] if wa else [None] * 3
+        gfac = _factors_struct(gd, gl, ga if wa else st_[2], st_[3])  # unused slots just need a non-null pointer
+        scratch = torch.empty(36, device=dev, dtype=torch.float32)
+        g3c = g3.contiguous().float()
+        check(lib.jt_reg_losses_backward(fac, hw_arr, Cd, Ca, ptr(g3c), int(wd), int(wa), gfac, ptr(scratch), _stream()),
+              "jt_reg_losses_backward")
+        grads = [factor_logical(t) for t in gd] + [factor_logical(t) for t in gl] + \
+                [factor_logical(t) if t is not None else None for t in ga] + [None] * 3
+        return (None, None) + tuple(grads)
+
+
+def reg_losses(density_plane, density_line, app_plane, app_line, with_tv_density=True, with_tv_app=True):
+    return RegLosses.apply(with_tv_density, with_tv_app, *density_plane, *density_line, *app_plane, *app_line)
+
+
+class RenderLoss(torch.autograd.Function):
+    """nanmean squared error between rgb [B,r,3] and the GT pixels image[:, :, ray_idx], optionally with the
+    hard edge-mask split (model/tensorf.py:112-124, base.py:259-261) -- one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, rgb, image, ray_idx, edge_mask, edge_factor, non_edge_factor):
+        rgb_c = rgb.detach().contiguous().float()
+        B, r = rgb_c.shape[0], rgb_c.shape[1]
+        img = image.detach().contiguous().float().view(B, 3, -1)
+        idx = ray_idx.detach().contiguous().to(torch.int64)
+        m = None if edge_mask is None else edge_mask.detach().contiguous().to(torch.uint8)
+        dev = rgb_c.device
+        acc = torch.empty(4, device=dev, dtype=torch.float32)
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        check(lib.jt_render_loss_forward(ptr(rgb_c), ptr(img), ptr(idx), ptr(m), B, r, img.shape[2],
+                                         float(edge_factor), float(non_edge_factor), ptr(acc), ptr(loss), _stream()),
+              "jt_render_loss_forward")
+        ctx.saved = (rgb_c, img, idx, m, acc, float(edge_factor), float(non_edge_factor))
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        rgb_c, img, idx, m, acc, fe, fne = ctx.saved
+        B, r = rgb_c.shape[0], rgb_c.shape[1]
+        gc = g.contiguous().float().view(1)
+        g_rgb = torch.empty_like(rgb_c)
+        check(lib.jt_render_loss_backward(ptr(rgb_c), ptr(img), ptr(idx), ptr(m), B, r, img.shape[2], fe, fne,
+                                          ptr(acc), ptr(gc), ptr(g_rgb), _stream()), "jt_render_loss_backward")
+        return g_rgb, None, None, None, None, None
+
+
+def render_loss(rgb, image, ray_idx, edge_mask=None, edge_factor=1.0, non_edge_factor=1.0):
+    return RenderLoss.apply(rgb, image, ray_idx, edge_mask, edge_factor, non_edge_factor)
+
+
 # ----------------------------------------------------------------------------------------------
 # camera
 # ----------------------------------------------------------------------------------------------

@@ -196,50 +196,34 @@ class BAT_VMSplit(torch.nn.Module):
                 {"params": self.basis_mat.parameters(), "lr": lr_init_network},
                 {"params": self.renderModule.parameters(), "lr": lr_init_network}]
 
-    # The three regularisers below are evaluated by ONE pass per factor (ops.factor_reg -> jt_factor_reg_*);
-    # the per-tensor sums are cached until the parameter changes so density_L1 and TV_loss_density share them.
-    def _reg_sums(self, p):
-        if not p.is_cuda:
+    # The three regularisers are evaluated together by one ABI call (ops.reg_losses -> jt_reg_losses_*): one
+    # pass over each factor, and one autograd node instead of ~150 tiny elementwise / reduce launches.  The
+    # result is cached per forward call so that density_L1 / TV_loss_density / TV_loss_app share it.
+    # `reg_with_tv` = (density, app): whether the TV terms will receive a gradient (their loss weight is
+    # non-zero); the values are computed either way.
+    reg_with_tv = (True, True)
+
+    def _reg(self):
+        if not self.density_plane[0].is_cuda:
             raise RuntimeError("joint_tensorf_amd computes regularisers on the GPU only")
-        key = (id(p), p._version, p.data_ptr())
         cache = self.__dict__.setdefault("_reg_cache", {})
-        hit = cache.get(id(p))
-        if hit is not None and hit[0] == key and torch.is_grad_enabled() == hit[2]:
-            return hit[1]
-        sums = ops.factor_reg(p)
-        cache[id(p)] = (key, sums, torch.is_grad_enabled())
-        return sums
+        key = (tuple(p._version for p in list(self.density_plane) + list(self.app_plane)), torch.is_grad_enabled())
+        if cache.get("key") != key:
+            cache["key"] = key
+            cache["val"] = ops.reg_losses(list(self.density_plane), list(self.density_line), list(self.app_plane),
+                                          list(self.app_line), *self.reg_with_tv)
+        return cache["val"]
 
     def density_L1(self):
         """sum_i mean|P_i| + mean|L_i| over the density factors (tensoRF.py:212-216)."""
-        total = 0
-        for i in range(3):
-            total = total + self._reg_sums(self.density_plane[i])[0] / self.density_plane[i].numel() \
-                + self._reg_sums(self.density_line[i])[0] / self.density_line[i].numel()
-        return total
-
-    def _tv(self, p, weight=1.0):
-        """TVLoss.forward (tensorBase.py:21-38) from the two difference sums."""
-        b, c, h, w = p.shape
-        s = self._reg_sums(p)
-        total = 0
-        if c * (h - 1) * w > 0:
-            total = total + s[1] / (c * (h - 1) * w)
-        if c * h * (w - 1) > 0:
-            total = total + s[2] / (c * h * (w - 1))
-        return weight * 2 * total / b
+        return self._reg()[0]
 
     def TV_loss_density(self, reg):
-        total = 0
-        for i in range(3):
-            total = total + self._tv(self.density_plane[i], getattr(reg, "TVLoss_weight", 1)) * 1e-2
-        return total
+        """sum_i TVLoss(density_plane_i) * 1e-2 (tensoRF.py:218-222)."""
+        return self._reg()[1] * getattr(reg, "TVLoss_weight", 1)
 
     def TV_loss_app(self, reg):
-        total = 0
-        for i in range(3):
-            total = total + self._tv(self.app_plane[i], getattr(reg, "TVLoss_weight", 1)) * 1e-2
-        return total
+        return self._reg()[2] * getattr(reg, "TVLoss_weight", 1)
 
     # ---- resolution changes (tensoRF.py:274-295) --------------------------------------------------
     @torch.no_grad()

@@ -214,3 +214,48 @@ def test_factor_reg_vs_oracle(shape):
     if W > 1:
         tv = tv + s[2] / (C * H * (W - 1))
     np.testing.assert_allclose(float(2 * tv), float(tv_ref), rtol=2e-5)
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_render_loss_vs_oracle(masked):
+    """fused GT gather + (edge-split) nanmean MSE, value and gradient."""
+    from joint_tensorf_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, r, H, W = 5, 37, 20, 30
+    rgb = torch.rand(B, r, 3, generator=g)
+    image = torch.rand(B, 3, H, W, generator=g)
+    ray_idx = torch.randperm(H * W, generator=g)[:r]
+    mask = (torch.rand(B, H * W, generator=g) < 0.4).to(torch.uint8)
+    a = rgb.clone().requires_grad_(True)
+    img_at = image.view(B, 3, -1).permute(0, 2, 1)[:, ray_idx]
+    ref = O.render_loss(a, img_at, mask[:, ray_idx] if masked else None, 1.5, 0.5)
+    (ref * 0.7).backward()
+    b = rgb.clone().to(DEV).requires_grad_(True)
+    out = ops.render_loss(b, image.to(DEV), ray_idx.to(DEV), mask.to(DEV) if masked else None, 1.5, 0.5)
+    (out * 0.7).backward()
+    np.testing.assert_allclose(float(out.detach()), float(ref.detach()), rtol=2e-6)
+    assert _rel(b.grad.cpu().numpy(), a.grad.numpy()) < 1e-5
+
+
+def test_reg_losses_vs_oracle():
+    """one-call L1 / TV_density / TV_color and their gradients against the oracle's formulas."""
+    from joint_tensorf_amd import ops
+    g = torch.Generator().manual_seed(13)
+    grid = [9, 11, 10]
+    p = O.init_params(grid, density_n_comp=(16, 16, 16), app_n_comp=(20, 20, 20), app_dim=20, featureC=32,
+                      shadingMode="MLP_Fea_WeakView", scale=0.3, bias=-0.1, generator=g)
+    for grp in ("density_plane", "density_line", "app_plane", "app_line"):
+        p[grp] = [t - 0.05 for t in p[grp]]  # both signs, so that sign(x) matters
+    leaves = [t.clone().requires_grad_(True) for grp in ("density_plane", "density_line", "app_plane", "app_line")
+              for t in p[grp]]
+    pp = dict(density_plane=leaves[0:3], density_line=leaves[3:6], app_plane=leaves[6:9], app_line=leaves[9:12])
+    w = torch.tensor([0.3, 1.7, 0.9])
+    ref = torch.stack([O.density_L1(pp), O.tv_planes(pp["density_plane"]), O.tv_planes(pp["app_plane"])])
+    (ref * w).sum().backward()
+    dev = [ops.factor_logical(ops.factor_storage(t.detach()).to(DEV)).requires_grad_(True) for t in leaves]
+    out = ops.reg_losses(dev[0:3], dev[3:6], dev[6:9], dev[9:12], True, True)
+    (out * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=3e-5)
+    for i in range(9):
+        assert _rel(dev[i].grad.cpu().numpy(), leaves[i].grad.numpy()) < 2e-5, i
+    assert all(dev[i].grad is None for i in range(9, 12))
