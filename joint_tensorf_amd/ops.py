@@ -20,7 +20,9 @@ VEC_MODE = (2, 1, 0)
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """raw hipStream_t of torch's current stream (the fast accessor; torch.cuda.current_stream() builds a
+    Python Stream object per call, ~10 us, and the hot loop asks ~20 times per iteration)."""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 _AUX = {}
@@ -376,6 +378,60 @@ class BlurFactor(torch.autograd.Function):
         check(lib.jt_blur_backward(ptr(gs), ptr(gin), ptr(tmp), H, W, C, ptr(taps), taps.numel(), _stream()),
               "jt_blur_backward")
         return factor_logical(gin.reshape(ctx.in_hw[0], ctx.in_hw[1], C)), None, None
+
+
+class BlurFactors(torch.autograd.Function):
+    """All factor blurs of one forward call behind ONE autograd node (12 tensors: planes re-interpreted as
+    the reference does, lines plain).  Same kernels as BlurFactor; this only removes per-tensor Python /
+    autograd overhead, which is what bounds the early (small-grid, blur-on) stages."""
+
+    @staticmethod
+    def forward(ctx, taps_density, taps_color, *factors):
+        st = _stream()
+        outs, meta = [], []
+        td = taps_density.detach().contiguous().float()
+        tc = taps_color.detach().contiguous().float()
+        for i, x in enumerate(factors):
+            is_plane = (i % 6) < 3          # order: dP0-2, dL0-2, aP0-2, aL0-2
+            taps = td if i < 6 else tc
+            xs = factor_storage(x)
+            H, W, C = xs.shape
+            if is_plane and W > 1:
+                H, W = W, H
+                xs = xs.reshape(H, W, C)
+            out = torch.empty_like(xs)
+            tmp = torch.empty_like(xs) if (H > 1 and W > 1) else None
+            check(lib.jt_blur_forward(ptr(xs), ptr(out), ptr(tmp), H, W, C, ptr(taps), taps.numel(), st),
+                  "jt_blur_forward")
+            outs.append(factor_logical(out))
+            meta.append((tuple(x.shape[2:]), i < 6))
+        ctx.meta = meta
+        ctx.save_for_backward(td, tc)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        td, tc = ctx.saved_tensors
+        st = _stream()
+        grads = []
+        for g, (in_hw, dens) in zip(gs, ctx.meta):
+            if g is None:
+                grads.append(None)
+                continue
+            taps = td if dens else tc
+            gsx = factor_storage(g)
+            H, W, C = gsx.shape
+            gin = torch.empty_like(gsx)
+            tmp = torch.empty_like(gsx) if (H > 1 and W > 1) else None
+            check(lib.jt_blur_backward(ptr(gsx), ptr(gin), ptr(tmp), H, W, C, ptr(taps), taps.numel(), st),
+                  "jt_blur_backward")
+            grads.append(factor_logical(gin.reshape(in_hw[0], in_hw[1], C)))
+        return (None, None) + tuple(grads)
+
+
+def blur_factors(taps_density, taps_color, density_plane, density_line, app_plane, app_line):
+    out = BlurFactors.apply(taps_density, taps_color, *density_plane, *density_line, *app_plane, *app_line)
+    return list(out[0:3]), list(out[3:6]), list(out[6:9]), list(out[9:12])
 
 
 def blur_factor(x, taps, reinterpret=False):

@@ -329,10 +329,7 @@ class BAT_VMSplit(torch.nn.Module):
             # the reference blurs planes through a reshape that exchanges (H, W) in the shape (bateRF.py:29,
             # SURVEY.md App. B-10): the blurred plane i is [1, C, g[m0], g[m1]] and is sampled as such
             plane_hw = [(g[MAT_MODE[i][0]], g[MAT_MODE[i][1]]) for i in range(3)]
-            dP = [ops.blur_factor(p, self.kernel_density, True) for p in dP]
-            dL = [ops.blur_factor(p, self.kernel_density) for p in dL]
-            aP = [ops.blur_factor(p, self.kernel_color, True) for p in aP]
-            aL = [ops.blur_factor(p, self.kernel_color) for p in aL]
+            dP, dL, aP, aL = ops.blur_factors(self.kernel_density, self.kernel_color, dP, dL, aP, aL)
         # white background: static flag or the reference's CPU coin (batBase.py:154)
         if white_bg:
             wb = True
