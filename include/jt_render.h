@@ -198,9 +198,13 @@ size_t jt_march_backward_workspace_bytes(const JtScene* scene, int n_rays);
  * gather(app planes/lines) -> outer product -> basis_mat -> PE -> MLP -> sigmoid, per shaded
  * sample, without materialising the [n][3*Ca] product matrix.
  * Replaces compute_appfeature + basis_mat + MLPRender_Fea[_WeakView].forward and their autograd.
- *   forward : rgb_s [n][3]
- *   backward: g_rgb_s [n][3] -> += g_factors.app_*, += g_mlp.*, g_xyz_app [n][3] (overwritten)
- * workspace (backward only): jt_shade_workspace_bytes(scene, n_entries_max) bytes, caller-provided.
+ *   forward : rgb_s [n][3]; with workspace != NULL (training) it also leaves the per-sample layer inputs
+ *             (products, basis output, hidden activations, ReLU masks, sample coordinates) in the workspace
+ *   backward: g_rgb_s [n][3] -> += g_factors.app_*, += g_mlp.*, g_xyz_app [n][3] (overwritten); consumes the
+ *             records the forward of the SAME samples left in `workspace` (the autograd tape of the chain:
+ *             nothing is gathered or evaluated twice) and the forward's rgb_s
+ * workspace: jt_shade_workspace_bytes(scene, n_entries_max) bytes, caller-provided; forward with
+ *            workspace == NULL is the inference path (no records).
  * aux_stream / ev_fork / ev_join (hipStream_t / hipEvent_t, all three or none): when given, the MLP / basis
  * weight-gradient GEMMs are enqueued on aux_stream behind ev_fork (recorded on `stream` after the per-sample
  * kernels) and ev_join is recorded on aux_stream at their end; the caller makes whoever consumes g_mlp wait
@@ -214,7 +218,7 @@ int jt_shade_forward(const JtScene* scene, const JtFactors* factors, const JtMlp
 int jt_shade_backward(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp, const float* rays_o,
                       const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
                       const int32_t* shade_offset, int n_rays, const int32_t* entry_ray,
-                      const int32_t* entry_smp, const float* viewdirs, const float* g_rgb_s,
+                      const int32_t* entry_smp, const float* viewdirs, const float* rgb_s, const float* g_rgb_s,
                       const JtFactors* g_factors, const JtMlp* g_mlp, float* g_xyz_app, int n_entries_max,
                       void* workspace, size_t workspace_bytes, int flags, void* stream, void* aux_stream,
                       void* ev_fork, void* ev_join);

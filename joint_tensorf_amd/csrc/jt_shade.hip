@@ -138,9 +138,13 @@ __device__ inline EntryGeom entry_geom(const Dev& D, const float* rays_o, const 
   return g;
 }
 
-// ---- stage 1: gather + products + basis_mat  -> feature accumulator (16 regs: rows rowmap(r,h)) -----
 template <class C>
-__device__ inline f32x16 gather_basis(const Dev& D, const float* s, const float n[3], int j, int h) {
+struct BwdCfg;
+
+// ---- stage 1: gather + products + basis_mat  -> feature accumulator (16 regs: rows rowmap(r,h)) -----
+template <class C, bool REC>
+__device__ inline f32x16 gather_basis(const Dev& D, const float* s, const float n[3], int j, int h, float* rt,
+                                      bool onrec) {
   f32x16 facc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) facc[r] = 0.f;
@@ -166,6 +170,7 @@ __device__ inline f32x16 gather_basis(const Dev& D, const float* s, const float 
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float bv = live ? pr[k] : 0.f;
+        if (REC && live && onrec) rt[(size_t)(BwdCfg<C>::R_PROD + i * C::CA + c0 + k) * 32 + j] = pr[k];
         float av = sb[i * C::CA + c0 + k];
         facc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, facc, 0, 0, 0);
       }
@@ -349,6 +354,43 @@ static inline PeMask pe_masks(float fea_progress, float view_progress, int fea_p
 }
 
 template <class C>
+struct BwdCfg {
+  static constexpr int TP_ROWS = 64;  // >= CA rows of product gradients; also the 2*16*64-float sin/cos stash
+  static constexpr int TP_LD = 33;
+  static constexpr int WAVE_FLOATS = TP_ROWS * TP_LD + 32 * 4 + 32 * 4;
+  static constexpr int NWAVE = 8;
+  static constexpr int LDS_FLOATS = C::LDS_FLOATS + NWAVE * WAVE_FLOATS;
+  static constexpr int PT = (C::CA + 31) / 32;  // M tiles of one plane's channels in the basis backward
+  // TILE-BLOCKED records: rec[tile][row][32 samples]; every accumulator register goes out as one coalesced
+  // 128-byte-per-half store, no transposition (k_wgrad reads rows, one per lane).  The training forward
+  // writes the layer inputs (PROD, F, VD, GEO, H1, MID, MASK), the backward adds the gradients (GO, G2, G1, GF).
+  static constexpr int R_G1 = 0;
+  static constexpr int R_G2 = R_G1 + C::HID;
+  static constexpr int R_H1 = R_G2 + C::HID;
+  static constexpr int R_MID = R_H1 + C::HID;
+  static constexpr int R_F = R_MID + C::IN3;
+  static constexpr int R_GF = R_F + 32;
+  static constexpr int R_GO = R_GF + 32;
+  static constexpr int R_VD = R_GO + 4;    // view direction (3 rows + pad)
+  static constexpr int R_MASK = R_VD + 4;  // ReLU sign bits of h1 / h2: row 2*layer + lane half, one word per sample
+  static constexpr int R_GEO = R_MASK + 4; // normalised sample coordinates (3 rows + pad)
+  static constexpr int R_PROD = R_GEO + 4;
+  static constexpr int REC_FLOATS = R_PROD + C::NC;   // rows of one tile; a tile is [REC_FLOATS][32 samples]
+};
+
+// record rows row0 + t*32 + rowmap(r,h) of the tile <- accumulator registers (lane = sample j)
+template <int NT>
+__device__ inline void rec_store(float* rt, int row0, const f32x16* v, int j, int h, bool on) {
+  if (!on) return;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rt[(size_t)(row0 + t * 32 + rowmap(r, 0) + 4 * h) * 32 + j] = v[t][r];
+}
+
+// REC = true (training): besides rgb the kernel leaves the tile-blocked records of the layer inputs (see
+// BwdCfg) so that the backward does not have to gather and run the forward chain a second time.
+template <class C, bool REC>
 __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm, const float* __restrict__ rays_o,
                                                       const float* __restrict__ rays_d,
                                                       const float* __restrict__ jitter,
@@ -357,7 +399,8 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
                                                       const int* __restrict__ offset, int R,
                                                       const int* __restrict__ eray, const int* __restrict__ esmp,
                                                       const float* __restrict__ vdir, float* __restrict__ rgb_s,
-                                                      int cap) {
+                                                      float* __restrict__ rec, int cap) {
+  typedef BwdCfg<C> B;
   extern __shared__ __align__(16) float smem[];
   const int total = min(offset[R], cap);
   const int ntiles = (total + 31) >> 5;
@@ -366,19 +409,55 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j_ = lane & 31, h_ = lane >> 5;
+  constexpr int HOFF = (C::KIND == JT_MLP_FEA) ? 0 : 12;
   for (int tile = blockIdx.x * 4 + wv; tile < ntiles; tile += gridDim.x * 4) {
     int j = j_, h = h_;  // see k_shade_bwd: keeps per-lane address math from being hoisted out of the loop
     asm volatile("" : "+v"(j), "+v"(h));
     const int e = tile * 32 + j;
     const bool on = e < total;
     const int ee = on ? e : total - 1;
+    float* rt = REC ? rec + (size_t)tile * B::REC_FLOATS * 32 : nullptr;
     EntryGeom g = entry_geom(D, rays_o, rays_d, jitter, zvals, tmin, eray, esmp, ee);
     float vd[3] = {vdir[(size_t)ee * 3], vdir[(size_t)ee * 3 + 1], vdir[(size_t)ee * 3 + 2]};
-    f32x16 facc = gather_basis<C>(D, smem, g.n, j, h);
+    if (REC && on && h == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        rt[(size_t)(B::R_VD + c) * 32 + j] = vd[c];
+        rt[(size_t)(B::R_GEO + c) * 32 + j] = g.n[c];
+      }
+    }
+    f32x16 facc = gather_basis<C, REC>(D, smem, g.n, j, h, rt, on);
+    if (REC) rec_store<1>(rt, B::R_F, &facc, j, h, on);
     Hidden<C> h1 = layer1<C>(smem, facc, vd, pm, j, h);
     relu_<C>(h1);
+    if (REC) {
+      unsigned mask1 = 0u;
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mask1 |= (h1.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
+      if (on) rt[(size_t)(B::R_MASK + h) * 32 + j] = __uint_as_float(mask1);
+      rec_store<C::MT>(rt, B::R_H1, h1.v, j, h, on);
+    }
     Hidden<C> h2 = layer2<C>(smem, h1, j, h);
     relu_<C>(h2);
+    if (REC) {
+      unsigned mask2 = 0u;
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mask2 |= (h2.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
+      if (on) rt[(size_t)(B::R_MASK + 2 + h) * 32 + j] = __uint_as_float(mask2);
+      rec_store<C::MT>(rt, B::R_MID + HOFF, h2.v, j, h, on);
+      if (C::KIND != JT_MLP_FEA) {
+        float pe[12];
+        view_pe(vd, pm, pe);
+        if (on && h == 0) {
+#pragma unroll
+          for (int k = 0; k < 12; ++k) rt[(size_t)(B::R_MID + k) * 32 + j] = pe[k];
+        }
+      }
+    }
     float o[3];
     layer3<C>(smem, h2, vd, pm, h, o);
     if (on && h == 0) {
@@ -408,38 +487,6 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
 __device__ inline void wave_lds_sync() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-}
-
-template <class C>
-struct BwdCfg {
-  static constexpr int TP_ROWS = 64;  // >= CA rows of product gradients; also the 2*16*64-float sin/cos stash
-  static constexpr int TP_LD = 33;
-  static constexpr int WAVE_FLOATS = TP_ROWS * TP_LD + 32 * 4 + 32 * 4;
-  static constexpr int NWAVE = 8;
-  static constexpr int LDS_FLOATS = C::LDS_FLOATS + NWAVE * WAVE_FLOATS;
-  static constexpr int PT = (C::CA + 31) / 32;  // M tiles of one plane's channels in the basis backward
-  // TILE-BLOCKED records handed to k_wgrad: rec[tile][row][32 samples]; every accumulator register goes
-  // out as one coalesced 128-byte-per-half store, no transposition (k_wgrad reads rows, one per lane)
-  static constexpr int R_G1 = 0;
-  static constexpr int R_G2 = R_G1 + C::HID;
-  static constexpr int R_H1 = R_G2 + C::HID;
-  static constexpr int R_MID = R_H1 + C::HID;
-  static constexpr int R_F = R_MID + C::IN3;
-  static constexpr int R_GF = R_F + 32;
-  static constexpr int R_GO = R_GF + 32;
-  static constexpr int R_VD = R_GO + 4;    // view direction (3 rows + pad)
-  static constexpr int R_PROD = R_VD + 4;
-  static constexpr int REC_FLOATS = R_PROD + C::NC;   // rows of one tile; a tile is [REC_FLOATS][32 samples]
-};
-
-// record rows row0 + t*32 + rowmap(r,h) of the tile <- accumulator registers (lane = sample j)
-template <int NT>
-__device__ inline void rec_store(float* rt, int row0, const f32x16* v, int j, int h, bool on) {
-  if (!on) return;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) rt[(size_t)(row0 + t * 32 + rowmap(r, 0) + 4 * h) * 32 + j] = v[t][r];
 }
 
 // rows = tile*32 + rowmap(r,h), column = sample j  ->  tp[row][j]
@@ -515,14 +562,8 @@ __device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, c
 
 template <class C>
 __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm, JtFactors G,
-                                                      const float* __restrict__ rays_o,
-                                                      const float* __restrict__ rays_d,
-                                                      const float* __restrict__ jitter,
-                                                      const float* __restrict__ zvals,
-                                                      const float* __restrict__ tmin,
                                                       const int* __restrict__ offset, int R,
-                                                      const int* __restrict__ eray, const int* __restrict__ esmp,
-                                                      const float* __restrict__ vdir,
+                                                      const float* __restrict__ rgb_s,
                                                       const float* __restrict__ g_rgb_s, float* __restrict__ g_xyz,
                                                       float* __restrict__ rec, int chunk_start, int chunk_cap,
                                                       int cap, int ablate) {
@@ -540,6 +581,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
   float* geo = tp + B::TP_ROWS * B::TP_LD;
   float* gxyz = geo + 32 * 4;
   const size_t RC = B::REC_FLOATS;
+  constexpr int HOFF = (C::KIND == JT_MLP_FEA) ? 0 : 12;
   for (int tile = blockIdx.x * B::NWAVE + wv; tile < ntiles; tile += gridDim.x * B::NWAVE) {
     // re-materialise the lane indices per tile: otherwise every per-lane LDS address / select that depends
     // on them is hoisted out of the tile loop as a loop invariant and the kernel spills hundreds of VGPRs
@@ -550,94 +592,39 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
     const int nlive = min(32, n_chunk - l0);
     const bool on = j < nlive;
     const bool onrec = on && !(ablate & 2);
-    float* rt = rec + (size_t)tile * RC * 32;  // this tile's record block
-    const int ee = on ? e : chunk_start + l0 + nlive - 1;
-    EntryGeom g = entry_geom(D, rays_o, rays_d, jitter, zvals, tmin, eray, esmp, ee);
-    float vd[3] = {vdir[(size_t)ee * 3], vdir[(size_t)ee * 3 + 1], vdir[(size_t)ee * 3 + 2]};
+    float* rt = rec + (size_t)tile * RC * 32;  // this tile's record block (layer inputs left by the forward)
+    const int jj = on ? j : nlive - 1;         // padding lanes mirror the last live sample
     if (h == 0) {
-      geo[j * 4 + 0] = g.n[0];
-      geo[j * 4 + 1] = g.n[1];
-      geo[j * 4 + 2] = g.n[2];
+      geo[j * 4 + 0] = rt[(size_t)(B::R_GEO + 0) * 32 + jj];
+      geo[j * 4 + 1] = rt[(size_t)(B::R_GEO + 1) * 32 + jj];
+      geo[j * 4 + 2] = rt[(size_t)(B::R_GEO + 2) * 32 + jj];
       gxyz[j * 4 + 0] = gxyz[j * 4 + 1] = gxyz[j * 4 + 2] = 0.f;
     }
-    // ---- forward recompute; the plane*line products go out as the PROD record, plane by plane ----
+    // basis_mat output of the forward (accumulator layout) and the ReLU sign bits of both hidden layers
     f32x16 facc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) facc[r] = 0.f;
-    {
-      const float* sb = smem + C::O_BASIS + j * C::LDB;
+    for (int r = 0; r < 16; ++r) facc[r] = rt[(size_t)(B::R_F + rowmap(r, 0) + 4 * h) * 32 + jj];
+    const unsigned mask1 = __float_as_uint(rt[(size_t)(B::R_MASK + h) * 32 + jj]);
+    const unsigned mask2 = __float_as_uint(rt[(size_t)(B::R_MASK + 2 + h) * 32 + jj]);
+    // sin / cos of the features, parked in the wave's LDS scratch for the layer-1 backward
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        PlaneTaps t = plane_taps(g.n[kM0[i]], g.n[kM1[i]], D.ph[i], D.pw[i], C::CA);
-        Axis l = axis_taps(g.n[kV[i]], D.ll[i]);
-        const float* P = D.aP[i];
-        const float* L = D.aL[i];
-#pragma unroll
-        for (int m = 0; m < C::NSLOT; ++m) {
-          const int q = 2 * m + h;
-          const bool live = q * 4 < C::CA;
-          const int c0 = live ? q * 4 : 0;
-          float4 a = ld4(P + t.o00 + c0), b = ld4(P + t.o10 + c0), c = ld4(P + t.o01 + c0), d = ld4(P + t.o11 + c0);
-          float4 u = ld4(L + l.c0 * C::CA + c0), v = ld4(L + l.c1 * C::CA + c0);
-          float pr[4];
-          pr[0] = (t.w00 * a.x + t.w10 * b.x + t.w01 * c.x + t.w11 * d.x) * (l.w0 * u.x + l.w1 * v.x);
-          pr[1] = (t.w00 * a.y + t.w10 * b.y + t.w01 * c.y + t.w11 * d.y) * (l.w0 * u.y + l.w1 * v.y);
-          pr[2] = (t.w00 * a.z + t.w10 * b.z + t.w01 * c.z + t.w11 * d.z) * (l.w0 * u.z + l.w1 * v.z);
-          pr[3] = (t.w00 * a.w + t.w10 * b.w + t.w01 * c.w + t.w11 * d.w) * (l.w0 * u.w + l.w1 * v.w);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            float bv = live ? pr[k] : 0.f;
-            if (live && onrec) rt[(size_t)(B::R_PROD + i * C::CA + c0 + k) * 32 + j] = pr[k];
-            float av = sb[i * C::CA + c0 + k];
-            facc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, facc, 0, 0, 0);
-          }
-          if (m & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    // Forward layers.  Each hidden activation is dropped as soon as the next layer has consumed it: its
-    // record goes out right away and only the ReLU sign bits (one register) survive for the backward.
-    constexpr int HOFF = (C::KIND == JT_MLP_FEA) ? 0 : 12;
-    unsigned mask1 = 0u, mask2 = 0u;
-    float o[3];
-    {
-      Hidden<C> h1 = layer1<C>(smem, facc, vd, pm, j, h, tp, lane);
-      relu_<C>(h1);
-#pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mask1 |= (h1.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
-      rec_store<C::MT>(rt, B::R_H1, h1.v, j, h, onrec);
-      Hidden<C> h2 = layer2<C>(smem, h1, j, h);
-      relu_<C>(h2);
-#pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mask2 |= (h2.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
-      rec_store<C::MT>(rt, B::R_MID + HOFF, h2.v, j, h, onrec);
-      layer3<C>(smem, h2, vd, pm, h, o);
-    }
-    if (C::KIND != JT_MLP_FEA) {
-      float pe[12];
-      view_pe(vd, pm, pe);
-      if (onrec && h == 0) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) rt[(size_t)(B::R_MID + k) * 32 + j] = pe[k];
-      }
+    for (int r = 0; r < 16; ++r) {
+      if (rowmap(r, 0) >= C::APP && rowmap(r, 1) >= C::APP) continue;
+      float sn, cs;
+      sincos_f(facc[r], &sn, &cs);
+      tp[(2 * r) * 64 + lane] = sn;
+      tp[(2 * r + 1) * 64 + lane] = cs;
     }
     // ---- output layer backward (VALU) ----
     float go[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      float rgb = 1.f / (1.f + expf(-o[c]));
+      const float rgb = rgb_s[(size_t)(on ? e : chunk_start + l0 + nlive - 1) * 3 + c];
       go[c] = on ? g_rgb_s[(size_t)e * 3 + c] * rgb * (1.f - rgb) : 0.f;
     }
     if (onrec && h == 0) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        rt[(size_t)(B::R_GO + c) * 32 + j] = go[c];
-        rt[(size_t)(B::R_VD + c) * 32 + j] = vd[c];
-      }
+      for (int c = 0; c < 3; ++c) rt[(size_t)(B::R_GO + c) * 32 + j] = go[c];
     }
     Hidden<C> G2;
 #pragma unroll
@@ -706,10 +693,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         if (rowmap(r, 0) >= C::APP && rowmap(r, 1) >= C::APP) continue;
-        float x = facc[r];
-        // sin/cos of this row were computed by the forward layer and parked in the wave's LDS scratch
-        // (keeping 30 of them in registers across the backward chain spilled to scratch memory)
-        (void)x;
+        // (keeping the 30 sin/cos values in registers across the backward chain spilled to scratch memory)
         const float sn = stash[(2 * r) * 64 + lane], cs = stash[(2 * r + 1) * 64 + lane];
         float dv;
         if (t == 0) dv = 1.f;
@@ -724,8 +708,6 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       if (rowmap(r, 0) + 4 * h >= C::APP) gf[r] = 0.f;
-    // records: F (basis_mat output) and GF
-    rec_store<1>(rt, B::R_F, &facc, j, h, onrec);
     rec_store<1>(rt, B::R_GF, &gf, j, h, onrec);
     // ---- basis_mat^T and the scatter, plane by plane ----
 #pragma unroll 1
@@ -987,20 +969,36 @@ extern "C" size_t jt_shade_workspace_bytes(const JtScene* scene, int n_entries_m
   return (kind == 0) ? WsLayout<CfgBlender>::bytes(n_entries_max) : WsLayout<CfgLlff>::bytes(n_entries_max);
 }
 
+template <class C, bool REC>
+static int launch_shade_fwd_t(const Dev& D, const MlpDev& M, const PeMask& pm, const float* rays_o,
+                              const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
+                              const int32_t* offset, int R, const int32_t* eray, const int32_t* esmp,
+                              const float* vdir, float* rgb_s, float* rec, int cap, hipStream_t st) {
+  const size_t lds = C::LDS_FLOATS * sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_fwd<C, REC>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  long tiles = ((long)cap + 31) / 32;
+  int blocks = (int)std::min<long>((tiles + 3) / 4, 512);
+  hipLaunchKernelGGL((k_shade_fwd<C, REC>), dim3(blocks), dim3(256), lds, st, D, M, pm, rays_o, rays_d, jitter, zvals,
+                     tmin, offset, R, eray, esmp, vdir, rgb_s, rec, cap);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
+// workspace != NULL: training forward, the records of the layer inputs are left in the workspace for
+// jt_shade_backward (which must be given the same workspace, untouched in between)
 template <class C>
 static int launch_shade_fwd(const Dev& D, const MlpDev& M, const PeMask& pm, const float* rays_o,
                             const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
                             const int32_t* offset, int R, const int32_t* eray, const int32_t* esmp,
-                            const float* vdir, float* rgb_s, int cap, hipStream_t st) {
-  const size_t lds = C::LDS_FLOATS * sizeof(float);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_fwd<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
-  long tiles = ((long)cap + 31) / 32;
-  int blocks = (int)std::min<long>((tiles + 3) / 4, 512);
-  hipLaunchKernelGGL(k_shade_fwd<C>, dim3(blocks), dim3(256), lds, st, D, M, pm, rays_o, rays_d, jitter, zvals, tmin,
-                     offset, R, eray, esmp, vdir, rgb_s, cap);
-  JT_LAUNCH_CHECK();
-  return JT_OK;
+                            const float* vdir, float* rgb_s, int cap, float* ws, size_t ws_bytes, hipStream_t st) {
+  if (ws) {
+    if (ws_bytes < WsLayout<C>::bytes(cap)) return JT_ERR_ARG;
+    return launch_shade_fwd_t<C, true>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, offset, R, eray, esmp, vdir,
+                                       rgb_s, ws, cap, st);
+  }
+  return launch_shade_fwd_t<C, false>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, offset, R, eray, esmp, vdir,
+                                      rgb_s, nullptr, cap, st);
 }
 
 extern "C" int jt_shade_forward(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp, const float* rays_o,
@@ -1024,16 +1022,16 @@ extern "C" int jt_shade_forward(const JtScene* scene, const JtFactors* factors, 
   hipStream_t st = (hipStream_t)stream;
   if (kind == 0)
     return launch_shade_fwd<CfgBlender>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, shade_offset, n_rays,
-                                        entry_ray, entry_smp, viewdirs, rgb_s, n_entries_max, st);
+                                        entry_ray, entry_smp, viewdirs, rgb_s, n_entries_max, (float*)workspace,
+                                        workspace_bytes, st);
   return launch_shade_fwd<CfgLlff>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, shade_offset, n_rays, entry_ray,
-                                   entry_smp, viewdirs, rgb_s, n_entries_max, st);
+                                   entry_smp, viewdirs, rgb_s, n_entries_max, (float*)workspace, workspace_bytes, st);
 }
 
 template <class C>
 static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, const JtFactors& G, const JtMlp& GM,
-                            const float* rays_o, const float* rays_d, const float* jitter, const float* zvals,
-                            const float* tmin, const int32_t* offset, int R, const int32_t* eray,
-                            const int32_t* esmp, const float* vdir, const float* g_rgb_s, float* g_xyz, int cap,
+                            const int32_t* offset, int R, const float* rgb_s, const float* g_rgb_s, float* g_xyz,
+                            int cap,
                             float* ws, size_t ws_bytes, int flags, hipStream_t st, hipStream_t aux,
                             hipEvent_t ev_fork, hipEvent_t ev_join) {
   typedef BwdCfg<C> B;
@@ -1058,9 +1056,8 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     const int start = ci * chunk, ccap = std::min(chunk, cap - start);
     long tiles = ((long)ccap + 31) / 32;
     int blocks = (int)std::min<long>((tiles + B::NWAVE - 1) / B::NWAVE, 256);
-    hipLaunchKernelGGL(k_shade_bwd<C>, dim3(blocks), dim3(512), lds, st, D, M, pm, G, rays_o, rays_d, jitter, zvals,
-                       tmin, offset, R, eray, esmp, vdir, g_rgb_s, g_xyz, recs + W::rec_floats_per_chunk() * ci,
-                       start, ccap, cap, ablate);
+    hipLaunchKernelGGL(k_shade_bwd<C>, dim3(blocks), dim3(512), lds, st, D, M, pm, G, offset, R, rgb_s, g_rgb_s,
+                       g_xyz, recs + W::rec_floats_per_chunk() * ci, start, ccap, cap, ablate);
     JT_LAUNCH_CHECK();
   }
   if (ablate & 4) return JT_OK;
@@ -1121,14 +1118,14 @@ extern "C" int jt_shade_backward(const JtScene* scene, const JtFactors* factors,
                                  const float* rays_o, const float* rays_d, const float* jitter, const float* zvals,
                                  const float* tmin, const int32_t* shade_offset, int n_rays,
                                  const int32_t* entry_ray, const int32_t* entry_smp, const float* viewdirs,
-                                 const float* g_rgb_s, const JtFactors* g_factors, const JtMlp* g_mlp,
+                                 const float* rgb_s, const float* g_rgb_s, const JtFactors* g_factors, const JtMlp* g_mlp,
                                  float* g_xyz_app, int n_entries_max, void* workspace, size_t workspace_bytes,
                                  int flags, void* stream, void* aux_stream, void* ev_fork, void* ev_join) {
   Dev D;
   int rc = make_dev(scene, factors, &D);
   if (rc) return rc;
   if (!factors || !mlp || !g_factors || !g_mlp || !rays_o || !rays_d || !tmin || !shade_offset || !entry_ray ||
-      !entry_smp || !viewdirs || !g_rgb_s || !g_xyz_app)
+      !entry_smp || !viewdirs || !rgb_s || !g_rgb_s || !g_xyz_app)
     return JT_ERR_ARG;
   if (!mlp->basis || !mlp->w1 || !mlp->b1 || !mlp->w2 || !mlp->b2 || !mlp->w3 || !mlp->b3) return JT_ERR_ARG;
   if (!g_mlp->basis || !g_mlp->w1 || !g_mlp->b1 || !g_mlp->w2 || !g_mlp->b2 || !g_mlp->w3 || !g_mlp->b3)
@@ -1144,12 +1141,11 @@ extern "C" int jt_shade_backward(const JtScene* scene, const JtFactors* factors,
   PeMask pm = pe_masks(scene->fea_pe_progress, scene->view_pe_progress, scene->fea_pe, scene->view_pe);
   hipStream_t st = (hipStream_t)stream;
   if (kind == 0)
-    return launch_shade_bwd<CfgBlender>(D, M, pm, *g_factors, *g_mlp, rays_o, rays_d, jitter, zvals, tmin,
-                                        shade_offset, n_rays, entry_ray, entry_smp, viewdirs, g_rgb_s, g_xyz_app,
+    return launch_shade_bwd<CfgBlender>(D, M, pm, *g_factors, *g_mlp, shade_offset, n_rays, rgb_s, g_rgb_s, g_xyz_app,
                                         n_entries_max, (float*)workspace, workspace_bytes, flags, st, (hipStream_t)aux_stream,
                                         (hipEvent_t)ev_fork, (hipEvent_t)ev_join);
-  return launch_shade_bwd<CfgLlff>(D, M, pm, *g_factors, *g_mlp, rays_o, rays_d, jitter, zvals, tmin, shade_offset,
-                                   n_rays, entry_ray, entry_smp, viewdirs, g_rgb_s, g_xyz_app, n_entries_max,
+  return launch_shade_bwd<CfgLlff>(D, M, pm, *g_factors, *g_mlp, shade_offset, n_rays, rgb_s, g_rgb_s, g_xyz_app,
+                                   n_entries_max,
                                    (float*)workspace, workspace_bytes, flags, st, (hipStream_t)aux_stream,
                                    (hipEvent_t)ev_fork, (hipEvent_t)ev_join);
 }

@@ -27,6 +27,7 @@ def _stream():
 
 _AUX = {}
 _WS = {}
+_WS_EPOCH = {}
 
 
 def _workspace(dev, name, nbytes):
@@ -38,6 +39,19 @@ def _workspace(dev, name, nbytes):
     if t is None or t.numel() < nbytes:
         _WS[key] = t = torch.empty(max(int(nbytes), 16), device=dev, dtype=torch.uint8)
     return t
+
+
+def _workspace_claim(dev, name):
+    """A new owner writes the named workspace: returns its ticket.  Whoever wants to READ what it left there
+    later compares the ticket with _workspace_owner()."""
+    key = (str(dev), name)
+    _WS_EPOCH[key] = _WS_EPOCH.get(key, 0) + 1
+    return _WS_EPOCH[key]
+
+
+def _workspace_owner(dev, name):
+    return _WS_EPOCH.get((str(dev), name), 0)
+
 
 # weight-gradient GEMMs on an auxiliary stream (overlaps the MFMA-bound GEMMs with the atomics-bound density
 # backward); JT_NO_AUX=1 keeps everything on one stream, e.g. for clean per-kernel profiles
@@ -240,9 +254,18 @@ class RenderRays(torch.autograd.Function):
             ctx.prod = prod
         else:
             mlp = _mlp_struct(*mlp_t)
+            if any(ctx.needs_input_grad):
+                # training: the forward leaves the layer inputs of every shaded sample in the (persistent)
+                # workspace; the backward consumes them instead of gathering / evaluating the chain again
+                nbytes = lib.jt_shade_workspace_bytes(scene, cap)
+                ws = _workspace(dev, "shade", nbytes)
+                ctx.ws_ticket = _workspace_claim(dev, "shade")
+                ws_args = (ptr(ws), nbytes)
+            else:
+                ws_args = (None, 0)
             check(lib.jt_shade_forward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
                                        ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(rgb_s),
-                                       cap, None, 0, st), "jt_shade_forward")
+                                       cap, *ws_args, st), "jt_shade_forward")
         rgb = torch.empty(R, 3, **f32)
         cmask = torch.empty(R, device=dev, dtype=torch.int32)
         check(lib.jt_composite_forward(scene, R, ptr(offset), ptr(sidx), ptr(weight), ptr(rgb_s), ptr(opacity),
@@ -300,9 +323,16 @@ class RenderRays(torch.autograd.Function):
             g_mlp = [torch.zeros_like(t) for t in mlp_t]
             mlp = _mlp_struct(*mlp_t)
             gm = _mlp_struct(*g_mlp)
-            # records of one chunk of shaded samples (consumed by the weight-gradient GEMMs chunk by chunk)
             nbytes = lib.jt_shade_workspace_bytes(scene, cap)
-            ws = _workspace(dev, "shade_bwd", nbytes)
+            ws = _workspace(dev, "shade", nbytes)
+            if _workspace_owner(dev, "shade") != ctx.ws_ticket:
+                # another render wrote the workspace since this one's forward (several forwards before one
+                # backward): put this call's records back
+                ctx.ws_ticket = _workspace_claim(dev, "shade")
+                check(lib.jt_shade_forward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
+                                           ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir),
+                                           ptr(torch.empty_like(rgb_s)), cap, ptr(ws), nbytes, st),
+                      "jt_shade_forward")
             if USE_AUX_STREAM:
                 aux, ev_fork, ev_join = _aux_stream(dev)
                 # the weight-gradient GEMMs read mlp_t / ws and write g_mlp on the auxiliary stream
@@ -314,8 +344,8 @@ class RenderRays(torch.autograd.Function):
             else:
                 h_aux = (None, None, None)
             check(lib.jt_shade_backward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
-                                        ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(g_rgb_s),
-                                        gfac, gm, ptr(g_xyz), cap, ptr(ws), nbytes, 0, st, *h_aux),
+                                        ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(rgb_s),
+                                        ptr(g_rgb_s), gfac, gm, ptr(g_xyz), cap, ptr(ws), nbytes, 0, st, *h_aux),
                   "jt_shade_backward")
         g_o = torch.empty(R, 3, **f32)
         g_d = torch.empty(R, 3, **f32)
@@ -693,9 +723,15 @@ class KernelProbe:
             torch.cuda.synchronize()
             return sorted(a.elapsed_time(b) for a, b in ev)[len(ev) // 2] * 1e-3
 
-        t_fwd = timed(lambda: check(lib.jt_shade_forward(
+        nbytes = lib.jt_shade_workspace_bytes(scene, max(n, 1))
+        ws = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8)
+        t_inf = timed(lambda: check(lib.jt_shade_forward(
             scene, fac, mlp, ptr(self.o), ptr(self.d), ptr(self.jitter), None, ptr(tmin), ptr(offset), R, ptr(eray),
             ptr(esmp), ptr(vdir), ptr(rgb_s), n, None, 0, st), "jt_shade_forward"))
+        # training forward: also leaves the layer-input records for the backward in the workspace
+        t_fwd = timed(lambda: check(lib.jt_shade_forward(
+            scene, fac, mlp, ptr(self.o), ptr(self.d), ptr(self.jitter), None, ptr(tmin), ptr(offset), R, ptr(eray),
+            ptr(esmp), ptr(vdir), ptr(rgb_s), n, ptr(ws), nbytes, st), "jt_shade_forward"))
         # one backward launch = one chunk of shaded samples
         nb = min(n, self.CHUNK)
         g_rgb_s = torch.rand(max(n, 1), 3, **f32)
@@ -704,12 +740,10 @@ class KernelProbe:
         gm_t = [torch.zeros_like(t) for t in mlp_t]
         gm = _mlp_struct(*gm_t)
         g_xyz = torch.empty(max(n, 1), 3, **f32)
-        nbytes = lib.jt_shade_workspace_bytes(scene, nb)
-        ws = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8)
         t_bwd = timed(lambda: check(lib.jt_shade_backward(
             scene, fac, mlp, ptr(self.o), ptr(self.d), ptr(self.jitter), None, ptr(tmin), ptr(offset), R, ptr(eray),
-            ptr(esmp), ptr(vdir), ptr(g_rgb_s), gfac, gm, ptr(g_xyz), nb, ptr(ws), nbytes, 1, st, None, None, None),
-            "jt_shade_backward"))
+            ptr(esmp), ptr(vdir), ptr(rgb_s), ptr(g_rgb_s), gfac, gm, ptr(g_xyz), nb, ptr(ws), nbytes, 1, st, None,
+            None, None), "jt_shade_backward"))
         peak = 8000.0
         bwd = nb * 2 * bytes_per / t_bwd / 1e9
         fwd = n * bytes_per / t_fwd / 1e9
@@ -717,8 +751,12 @@ class KernelProbe:
             "bound": "hbm", "kernel": "k_shade_bwd (one launch = one chunk of shaded samples, weight-gradient pass excluded)",
             "achieved": bwd, "peak": peak, "unit": "GB/s", "frac": bwd / peak, "traffic": None,
             "launch_ms": t_bwd * 1e3, "samples_per_launch": nb, "bytes_per_sample": 2 * bytes_per,
-            "forward": {"kernel": "k_shade_fwd (gather + basis + MLP, one launch)", "achieved": fwd, "peak": peak,
-                        "unit": "GB/s", "frac": fwd / peak, "launch_ms": t_fwd * 1e3, "samples_per_launch": n,
-                        "bytes_per_sample": bytes_per},
+            "forward": {"kernel": "k_shade_fwd<train> (gather + basis + MLP + layer-input records, one launch)",
+                        "achieved": fwd, "peak": peak, "unit": "GB/s", "frac": fwd / peak, "launch_ms": t_fwd * 1e3,
+                        "samples_per_launch": n, "bytes_per_sample": bytes_per},
+            "forward_inference": {"kernel": "k_shade_fwd<infer> (gather + basis + MLP, one launch)",
+                                  "achieved": n * bytes_per / t_inf / 1e9, "peak": peak, "unit": "GB/s",
+                                  "frac": n * bytes_per / t_inf / 1e9 / peak, "launch_ms": t_inf * 1e3,
+                                  "samples_per_launch": n, "bytes_per_sample": bytes_per},
             "in_box_samples": n_in_box, "shaded_samples": n,
         }
