@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--shade-impl", default="mfma", choices=["mfma", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--probe-only", action="store_true",
+                    help="run only the single-launch kernel probe (the target of the rocprofv3 --pmc passes)")
     return ap.parse_args()
 
 
@@ -166,6 +168,27 @@ def measure_roofline(model, opt, var, reps=20):
     return probe.run(reps)
 
 
+def pmc_traffic(roof):
+    """HBM-side bytes per launch of the probed kernels from the committed rocprofv3 --pmc passes
+    (profiles/round1_pmc_traffic.json, made by tools/pmc_traffic.py from separate FETCH_SIZE and WRITE_SIZE passes
+    over `bench.py --probe-only`; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters
+    cannot be read from inside the timed process, so the figure is the recorded bytes per shaded sample of the
+    same launch shape times the samples of the live launch; it is dropped (null) when the live launch differs
+    from the recorded one by more than 5 % in samples."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return {"traffic": None}
+    k = rec.get("k_shade_bwd")
+    n = roof.get("samples_per_launch")
+    if not k or not n or abs(k["samples_per_launch"] - n) > 0.05 * n:
+        return {"traffic": None}
+    return {"traffic": k["hbm_bytes_per_sample"] * n, "traffic_unit": "bytes/launch",
+            "traffic_source": "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+            "traffic_detail": rec}
+
+
 def main():
     args = parse()
     world, rank, local = setup_dist(args)
@@ -191,6 +214,10 @@ def main():
     res, S = nerf.resolution, nerf.n_samples
     # per-rank lattice offsets differ (different pixels per GPU); everything else is shared
     lattice_rng = np.random.RandomState(1000 + rank)
+    if args.probe_only:
+        from joint_tensorf_amd.options import Opt
+        print(json.dumps(measure_roofline(model, opt, Opt(dict(var_all)), reps=10)))
+        return
 
     rays_total = 0
 
@@ -278,6 +305,7 @@ def main():
             try:
                 from joint_tensorf_amd.options import Opt
                 out["roofline"] = measure_roofline(model, opt, Opt(dict(var_all)))
+                out["roofline"].update(pmc_traffic(out["roofline"]))
             except Exception as e:  # keep the bench line even if the probe is unavailable
                 out["roofline"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
