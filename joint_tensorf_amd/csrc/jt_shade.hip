@@ -16,6 +16,9 @@
 #include <cstdlib>
 
 #include "jt_common.h"
+#ifdef JT_EXP_DRY
+#define JT_FLUSH_COND(x) ((x) == 12345.678f)
+#endif
 #include "jt_walk.h"
 
 namespace jt {
@@ -355,7 +358,9 @@ static inline PeMask pe_masks(float fea_progress, float view_progress, int fea_p
 
 template <class C>
 struct BwdCfg {
-  static constexpr int TP_ROWS = 64;  // >= CA rows of product gradients; also the 2*16*64-float sin/cos stash
+  static constexpr int TP_ROWS = 64;  // 48 rows of product gradients + 32 step records of 16 words (jt_walk.h);
+                                      // also the 2*16*64-float sin/cos stash
+  static_assert(C::CA <= 48 && (TP_ROWS - 48) * 33 >= 32 * kRecWords, "LDS tile");
   static constexpr int TP_LD = 33;
   static constexpr int WAVE_FLOATS = TP_ROWS * TP_LD + 32 * 4 + 32 * 4;
   static constexpr int NWAVE = 8;
@@ -513,49 +518,46 @@ __device__ inline void tp_store_rows(const float* tp, float* rec, size_t ld, int
 
 // ---- channel-parallel scatter of one plane's product gradients ------------------------------------------
 // lanes: group = lane >> 4 (4 groups), cl = lane & 15.  Group g walks samples g*8 .. g*8+7 of the tile in
-// order (jt_walk.h); the taps of the next sample are loaded while the current one is accumulated.
+// order (jt_walk.h); the step records of the 32 samples (tap addresses, weights, cells) were computed once per
+// sample and sit in LDS; the factor values of the next sample are loaded while the current one is accumulated.
 template <class C>
-__device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, const float* tp, const float* geo,
-                                     float* gxyz, int nlive, int lane) {
+__device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, const float* tp, const float* recs,
+                                     float* gxyz, int lane) {
   constexpr int NCH = (C::CA + 15) / 16;
   const int grp = lane >> 4, cl = lane & 15;
-  const int H = D.ph[pl], W = D.pw[pl], L = D.ll[pl];
   const float* P = D.aP[pl];
   const float* Ln = D.aL[pl];
-  PlaneWalker<NCH, C::CA> wk;
-  wk.init(G.app_plane[pl], G.app_line[pl], H, W, L, cl);
+  RecWalker<NCH, C::CA> wk;
+  wk.init(G.app_plane[pl], G.app_line[pl], cl);
   const int m0 = kM0[pl], m1 = kM1[pl], mv = kV[pl];
-  TapVals<NCH> cur, nxt;
-  {
-    const float* n = geo + (grp * 8) * 4;
-    tap_load<NCH, C::CA>(cur, P, Ln, n[m0], n[m1], n[mv], H, W, L, cl);
-  }
-#pragma unroll 1
-  for (int q = 0; q < 8; ++q) {
+  // lanes 0..2 of a group add the x / y / line coordinate gradient of the step to gxyz[sample][axis]
+  const int my_axis = (cl == 0) ? m0 : (cl == 1) ? m1 : mv;
+  const float my_scale = ((cl == 0) ? 0.5f * (float)(D.pw[pl] - 1) : (cl == 1) ? 0.5f * (float)(D.ph[pl] - 1)
+                                                                                : 0.5f * (float)(D.ll[pl] - 1)) *
+                         D.inv[my_axis];
+  const float* rec0 = recs + (grp * 8) * kRecWords;
+  TapBuf<NCH> bufA, bufB;
+  auto step = [&](TapBuf<NCH>& tv, int q) {
     const int sidx = grp * 8 + q;
-    const bool on = sidx < nlive;
-    if (q < 7) {
-      const float* n = geo + (sidx + 1) * 4;
-      tap_load<NCH, C::CA>(nxt, P, Ln, n[m0], n[m1], n[mv], H, W, L, cl);
-    }
-    if (on) wk.advance(cur.t.ax.i0, cur.t.ay.i0, cur.l.i0);
+    const float* rec = rec0 + q * kRecWords;
+    wk.advance(rec);
     float g[NCH];
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-      const int c = cl + 16 * k;
-      g[k] = (on && c < C::CA) ? tp[c * 33 + sidx] : 0.f;
-    }
+    for (int k = 0; k < NCH; ++k) g[k] = wk.live[k] ? tp[(cl + 16 * k) * 33 + sidx] : 0.f;
     float aix = 0.f, aiy = 0.f, ail = 0.f;
-    wk.add(cur, g, aix, aiy, ail);
-    aix = group16_sum(aix);
-    aiy = group16_sum(aiy);
-    ail = group16_sum(ail);
-    if (on && cl == 0) {
-      gxyz[sidx * 4 + m0] += aix * cur.t.ax.scale * D.inv[m0];
-      gxyz[sidx * 4 + m1] += aiy * cur.t.ay.scale * D.inv[m1];
-      gxyz[sidx * 4 + mv] += ail * cur.l.scale * D.inv[mv];
-    }
-    if (q < 7) cur = nxt;
+    wk.add(tv, rec, g, aix, aiy, ail);
+    aix = row16_sum(aix);
+    aiy = row16_sum(aiy);
+    ail = row16_sum(ail);
+    if (cl < 3) atomicAdd(&gxyz[sidx * 4 + my_axis], ((cl == 0) ? aix : (cl == 1) ? aiy : ail) * my_scale);
+  };
+  wk.load(bufA, P, Ln, rec0);
+#pragma unroll 1
+  for (int q = 0; q < 8; q += 2) {
+    wk.load(bufB, P, Ln, rec0 + (q + 1) * kRecWords);
+    step(bufA, q);
+    if (q + 2 < 8) wk.load(bufA, P, Ln, rec0 + (q + 2) * kRecWords);
+    step(bufB, q + 1);
   }
   wk.finish();
 }
@@ -734,8 +736,14 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
           const int ch = T * 32 + rowmap(r, 0) + 4 * h;
           if (ch < C::CA) tp[ch * 33 + j] = gp[T][r];
         }
+      // step records of the tile's samples for this plane (one lane per sample), in the rows of tp past
+      // the product gradients
+      float* recs = tp + 48 * 33;
+      if (h == 0)
+        make_step_rec(geo[j * 4 + kM0[pl]], geo[j * 4 + kM1[pl]], geo[j * 4 + kV[pl]], D.ph[pl], D.pw[pl], D.ll[pl],
+                      C::CA, recs + j * kRecWords);
       wave_lds_sync();
-      if (!(ablate & 1)) scatter_plane<C>(D, G, pl, tp, geo, gxyz, nlive, lane);
+      if (!(ablate & 1)) scatter_plane<C>(D, G, pl, tp, recs, gxyz, lane);
       wave_lds_sync();
     }
     if (on && h == 0) {

@@ -1,0 +1,22 @@
+#!/bin/bash
+# usage: tools/pmc_sq.sh <tag> [bench args...]  -- SQ counters per kernel (own pass, kernel-trace only)
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp && export JT_NO_AUX=1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_SALU --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/sq_$tag -o k -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline "$@" > $GRAFT_REPO_ROOT/gpurun_out/sq_$tag.log 2>&1
+cd $GRAFT_REPO_ROOT
+python - <<'PY' gpurun_out/sq_$tag/k_counter_collection.csv
+import csv, sys
+from collections import defaultdict
+acc = defaultdict(lambda: defaultdict(float)); calls = defaultdict(set); dur = defaultdict(float)
+for r in csv.DictReader(open(sys.argv[1])):
+    nm = r["Kernel_Name"].replace("void ", "").split("(")[0][:44]
+    if "jt::" not in nm: continue
+    acc[nm][r["Counter_Name"]] += float(r["Counter_Value"])
+    if r["Dispatch_Id"] not in calls[nm]:
+        calls[nm].add(r["Dispatch_Id"]); dur[nm] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+cols = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_VMEM", "SQ_INSTS_SALU"]
+print("%-46s %5s %8s " % ("kernel", "calls", "avg_us") + " ".join("%12s" % c[3:] for c in cols))
+for nm in sorted(acc, key=lambda k: -dur[k])[:12]:
+    n = len(calls[nm])
+    print("%-46s %5d %8.1f " % (nm, n, dur[nm] / n) + " ".join("%12.0f" % (acc[nm][c] / n) for c in cols))
+PY
