@@ -35,8 +35,8 @@ __global__ __launch_bounds__(256) void k_app_gather_fwd(Dev D, const float* __re
     const int e = item / 3, pl = item - e * 3;
     float n[3], z;
     entry_point(D, rays_o, rays_d, jitter, zvals, tmin, eray[e], esmp[e], n, &z);
-    PlaneTaps t = plane_taps(n[kM0[pl]], n[kM1[pl]], D.ph[pl], D.pw[pl], C);
-    Axis l = axis_taps(n[kV[pl]], D.ll[pl]);
+    PlaneTaps t = plane_taps(n[kM0(pl)], n[kM1(pl)], D.ph[pl], D.pw[pl], C);
+    Axis l = axis_taps(n[kV(pl)], D.ll[pl]);
     const float* P = D.aP[pl];
     const float* L = D.aL[pl];
     float* out = prod + (size_t)e * (3 * C) + pl * C;
@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void k_app_gather_bwd(Dev D, JtFactors G, cons
     const int e = on ? item / 3 : 0, pl = on ? item - e * 3 : 0;
     float n[3], z;
     entry_point(D, rays_o, rays_d, jitter, zvals, tmin, eray[e], esmp[e], n, &z);
-    PlaneTaps t = plane_taps(n[kM0[pl]], n[kM1[pl]], D.ph[pl], D.pw[pl], C);
-    Axis l = axis_taps(n[kV[pl]], D.ll[pl]);
+    PlaneTaps t = plane_taps(n[kM0(pl)], n[kM1(pl)], D.ph[pl], D.pw[pl], C);
+    Axis l = axis_taps(n[kV(pl)], D.ll[pl]);
     const float* P = D.aP[pl];
     const float* L = D.aL[pl];
     float* gP = G.app_plane[pl];
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_app_gather_bwd(Dev D, JtFactors G, cons
       ail += __shfl_xor(ail, o);
     }
     if (on && ch == 0) {
-      const int m0 = kM0[pl], m1 = kM1[pl], v = kV[pl];
+      const int m0 = kM0(pl), m1 = kM1(pl), v = kV(pl);
       atomicAdd(g_xyz + (size_t)e * 3 + m0, aix * t.ax.scale * D.inv[m0]);
       atomicAdd(g_xyz + (size_t)e * 3 + m1, aiy * t.ay.scale * D.inv[m1]);
       atomicAdd(g_xyz + (size_t)e * 3 + v, ail * l.scale * D.inv[v]);

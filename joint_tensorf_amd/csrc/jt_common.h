@@ -11,9 +11,9 @@
 namespace jt {
 
 // matMode / vecMode of the reference (tensorBase.py:405-406)
-__device__ __constant__ const int kM0[3] = {0, 0, 1};
-__device__ __constant__ const int kM1[3] = {1, 2, 2};
-__device__ __constant__ const int kV[3] = {2, 1, 0};
+__host__ __device__ constexpr int kM0(int i) { return i == 2 ? 1 : 0; }  // {0, 0, 1}
+__host__ __device__ constexpr int kM1(int i) { return i == 0 ? 1 : 2; }  // {1, 2, 2}
+__host__ __device__ constexpr int kV(int i) { return 2 - i; }            // {2, 1, 0}
 
 struct Dev {
   float lo[3], hi[3], inv[3];  // inv = 2/(hi-lo)  (tensorBase.py:481)

@@ -18,8 +18,8 @@ __device__ inline float density_feature(const Dev& D, const float n[3]) {
   const int C = D.Cd;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    PlaneTaps t = plane_taps(n[kM0[i]], n[kM1[i]], D.ph[i], D.pw[i], C);
-    Axis l = axis_taps(n[kV[i]], D.ll[i]);
+    PlaneTaps t = plane_taps(n[kM0(i)], n[kM1(i)], D.ph[i], D.pw[i], C);
+    Axis l = axis_taps(n[kV(i)], D.ll[i]);
     const float* P = D.dP[i];
     const float* L = D.dL[i];
     const int l0 = l.c0 * C, l1 = l.c1 * C;
@@ -415,6 +415,10 @@ __global__ __launch_bounds__(256) void k_march_bwd_scan(Dev D, const float* __re
 }
 
 constexpr int kWalkRun = 32;  // listed samples per 16-lane group
+constexpr int kWalkSub = 8;   // samples whose step records are built at a time
+constexpr int kWalkRecW = 3 * kRecWords + 4;  // per sample: three plane records + (g_feat, z, -, -)
+
+__device__ inline int sel3(int i, int a, int b, int c) { return i == 0 ? a : (i == 1 ? b : c); }
 
 template <int CD>
 __global__ __launch_bounds__(256) void k_march_bwd_walk(Dev D, JtFactors G, const float* __restrict__ rays_o,
@@ -427,8 +431,9 @@ __global__ __launch_bounds__(256) void k_march_bwd_walk(Dev D, JtFactors G, cons
                                                         const int* __restrict__ nvalid, int runs_per_ray,
                                                         float* __restrict__ g_rays_o, float* __restrict__ g_rays_d) {
   constexpr int NCH = (CD + 15) / 16;
-  const int cl = threadIdx.x & 15;
-  const long item = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  __shared__ __align__(16) float s_rec[16][kWalkSub * kWalkRecW];
+  const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const long item = (long)blockIdx.x * 16 + grp;
   const int ray = (int)(item / runs_per_ray);
   const int run = (int)(item - (long)ray * runs_per_ray);
   if (ray >= R) return;
@@ -439,68 +444,80 @@ __global__ __launch_bounds__(256) void k_march_bwd_walk(Dev D, JtFactors G, cons
   Ray r;
   load_ray(D, rays_o, rays_d, jitter, tmin_in, ray, r);
   const size_t row = (size_t)ray * D.S;
-  PlaneWalker<NCH, CD> wk[3];
+  float* rec = s_rec[grp];
+  RecWalker<NCH, CD> wk[3];
 #pragma unroll
-  for (int pl = 0; pl < 3; ++pl) wk[pl].init(G.density_plane[pl], G.density_line[pl], D.ph[pl], D.pw[pl], D.ll[pl], cl);
-  TapVals<NCH> cur[3], nxt[3];
-  float zc, zn = 0.f, gc, gn = 0.f;
-  {
-    const int i = vlist[row + k0];
-    zc = sample_z(D, r, zvals, i);
-    gc = gfeat[row + i];
-    float p[3], n[3];
-    sample_point(D, r, zc, p);
-    normalize(D, p, n);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-      tap_load<NCH, CD>(cur[pl], D.dP[pl], D.dL[pl], n[kM0[pl]], n[kM1[pl]], n[kV[pl]], D.ph[pl], D.pw[pl], D.ll[pl], cl);
-  }
+  for (int pl = 0; pl < 3; ++pl) wk[pl].init(G.density_plane[pl], G.density_line[pl], cl);
   float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
-  for (int k = k0; k < k1; ++k) {
-    if (k + 1 < k1) {  // prefetch the next listed sample
-      const int i = vlist[row + k + 1];
-      zn = sample_z(D, r, zvals, i);
-      gn = gfeat[row + i];
+
+  for (int kb = k0; kb < k1; kb += kWalkSub) {
+    const int ns = min(kWalkSub, k1 - kb);
+    // step records of the next kWalkSub listed samples: one lane per (sample, plane) pair; samples past the end
+    // of the run mirror the last live one with a zero gradient (a no-op for the walker)
+    for (int pp = cl; pp < 3 * kWalkSub; pp += 16) {
+      const int smp = pp & (kWalkSub - 1), pl = pp / kWalkSub;
+      const int i = vlist[row + kb + min(smp, ns - 1)];
+      const float z = sample_z(D, r, zvals, i);
       float p[3], n[3];
-      sample_point(D, r, zn, p);
+      sample_point(D, r, z, p);
       normalize(D, p, n);
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        tap_load<NCH, CD>(nxt[pl], D.dP[pl], D.dL[pl], n[kM0[pl]], n[kM1[pl]], n[kV[pl]], D.ph[pl], D.pw[pl], D.ll[pl],
-                          cl);
+      const float n0 = pl == 0 ? n[kM0(0)] : (pl == 1 ? n[kM0(1)] : n[kM0(2)]);
+      const float n1 = pl == 0 ? n[kM1(0)] : (pl == 1 ? n[kM1(1)] : n[kM1(2)]);
+      const float n2 = pl == 0 ? n[kV(0)] : (pl == 1 ? n[kV(1)] : n[kV(2)]);
+      make_step_rec(n0, n1, n2, sel3(pl, D.ph[0], D.ph[1], D.ph[2]), sel3(pl, D.pw[0], D.pw[1], D.pw[2]),
+                    sel3(pl, D.ll[0], D.ll[1], D.ll[2]), CD, rec + smp * kWalkRecW + pl * kRecWords);
+      if (pl == 0) {
+        rec[smp * kWalkRecW + 3 * kRecWords] = (smp < ns) ? gfeat[row + i] : 0.f;
+        rec[smp * kWalkRecW + 3 * kRecWords + 1] = z;
+      }
     }
-    float gn3[3] = {0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // plane by plane over the sub-run (one walker's taps in flight at a time keeps the register count down)
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
-      wk[pl].advance(cur[pl].t.ax.i0, cur[pl].t.ay.i0, cur[pl].l.i0);
-      float g[NCH];
+      const float* rp = rec + pl * kRecWords;
+      const float sx = 0.5f * (float)(D.pw[pl] - 1) * D.inv[kM0(pl)], sy = 0.5f * (float)(D.ph[pl] - 1) * D.inv[kM1(pl)],
+                  sl = 0.5f * (float)(D.ll[pl] - 1) * D.inv[kV(pl)];
+      TapBuf<NCH> bufA, bufB;
+      auto step = [&](TapBuf<NCH>& tv, int q) {
+        const float* rq = rp + q * kWalkRecW;
+        const float gc = rec[q * kWalkRecW + 3 * kRecWords], zc = rec[q * kWalkRecW + 3 * kRecWords + 1];
+        wk[pl].advance(rq);
+        float g[NCH];
 #pragma unroll
-      for (int q = 0; q < NCH; ++q) g[q] = (cl + 16 * q < CD) ? gc : 0.f;
-      float aix = 0.f, aiy = 0.f, ail = 0.f;
-      wk[pl].add(cur[pl], g, aix, aiy, ail);
-      gn3[kM0[pl]] += aix * cur[pl].t.ax.scale;
-      gn3[kM1[pl]] += aiy * cur[pl].t.ay.scale;
-      gn3[kV[pl]] += ail * cur[pl].l.scale;
+        for (int k = 0; k < NCH; ++k) g[k] = wk[pl].live[k] ? gc : 0.f;
+        float aix = 0.f, aiy = 0.f, ail = 0.f;
+        wk[pl].add(tv, rq, g, aix, aiy, ail);
+        // per-lane partials (its channels); reduced over the group at the end
+        aix *= sx;
+        aiy *= sy;
+        ail *= sl;
+        go[kM0(pl)] += aix;
+        gd[kM0(pl)] += aix * zc;
+        go[kM1(pl)] += aiy;
+        gd[kM1(pl)] += aiy * zc;
+        go[kV(pl)] += ail;
+        gd[kV(pl)] += ail * zc;
+      };
+      wk[pl].load(bufA, D.dP[pl], D.dL[pl], rp);
+#pragma unroll 1
+      for (int q = 0; q < kWalkSub; q += 2) {
+        wk[pl].load(bufB, D.dP[pl], D.dL[pl], rp + (q + 1) * kWalkRecW);
+        step(bufA, q);
+        if (q + 2 < kWalkSub) wk[pl].load(bufA, D.dP[pl], D.dL[pl], rp + (q + 2) * kWalkRecW);
+        step(bufB, q + 1);
+      }
     }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float gx = gn3[a] * D.inv[a];  // per-lane partial (its channels); reduced over the group at the end
-      go[a] += gx;
-      gd[a] += gx * zc;
-    }
-    if (k + 1 < k1) {
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) cur[pl] = nxt[pl];
-      zc = zn;
-      gc = gn;
-    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
   }
 #pragma unroll
   for (int pl = 0; pl < 3; ++pl) wk[pl].finish();
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    go[a] = group16_sum(go[a]);
-    gd[a] = group16_sum(gd[a]);
+    go[a] = row16_sum(go[a]);
+    gd[a] = row16_sum(gd[a]);
   }
   if (cl < 3) atomicAdd(g_rays_o + ray * 3 + cl, cl == 0 ? go[0] : cl == 1 ? go[1] : go[2]);
   else if (cl < 6) atomicAdd(g_rays_d + ray * 3 + (cl - 3), cl == 3 ? gd[0] : cl == 4 ? gd[1] : gd[2]);

@@ -154,8 +154,8 @@ __device__ inline f32x16 gather_basis(const Dev& D, const float* s, const float 
   const float* sb = s + C::O_BASIS + j * C::LDB;  // this lane's basis row (A operand: unit a = j)
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    PlaneTaps t = plane_taps(n[kM0[i]], n[kM1[i]], D.ph[i], D.pw[i], C::CA);
-    Axis l = axis_taps(n[kV[i]], D.ll[i]);
+    PlaneTaps t = plane_taps(n[kM0(i)], n[kM1(i)], D.ph[i], D.pw[i], C::CA);
+    Axis l = axis_taps(n[kV(i)], D.ll[i]);
     const float* P = D.aP[i];
     const float* L = D.aL[i];
 #pragma unroll
@@ -529,7 +529,7 @@ __device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, c
   const float* Ln = D.aL[pl];
   RecWalker<NCH, C::CA> wk;
   wk.init(G.app_plane[pl], G.app_line[pl], cl);
-  const int m0 = kM0[pl], m1 = kM1[pl], mv = kV[pl];
+  const int m0 = kM0(pl), m1 = kM1(pl), mv = kV(pl);
   // lanes 0..2 of a group add the x / y / line coordinate gradient of the step to gxyz[sample][axis]
   const int my_axis = (cl == 0) ? m0 : (cl == 1) ? m1 : mv;
   const float my_scale = ((cl == 0) ? 0.5f * (float)(D.pw[pl] - 1) : (cl == 1) ? 0.5f * (float)(D.ph[pl] - 1)
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
       // the product gradients
       float* recs = tp + 48 * 33;
       if (h == 0)
-        make_step_rec(geo[j * 4 + kM0[pl]], geo[j * 4 + kM1[pl]], geo[j * 4 + kV[pl]], D.ph[pl], D.pw[pl], D.ll[pl],
+        make_step_rec(geo[j * 4 + kM0(pl)], geo[j * 4 + kM1(pl)], geo[j * 4 + kV(pl)], D.ph[pl], D.pw[pl], D.ll[pl],
                       C::CA, recs + j * kRecWords);
       wave_lds_sync();
       if (!(ablate & 1)) scatter_plane<C>(D, G, pl, tp, recs, gxyz, lane);
