@@ -456,16 +456,24 @@ __global__ __launch_bounds__(256) void k_march_bwd_walk(Dev D, JtFactors G, cons
     // of the run mirror the last live one with a zero gradient (a no-op for the walker)
     for (int pp = cl; pp < 3 * kWalkSub; pp += 16) {
       const int smp = pp & (kWalkSub - 1), pl = pp / kWalkSub;
-      const int i = vlist[row + kb + min(smp, ns - 1)];
-      const float z = sample_z(D, r, zvals, i);
-      float p[3], n[3];
+      const int kk = kb + min(smp, ns - 1);
+      const bool has_prev = (smp < ns) && (kk > k0);
+      const int i = vlist[row + kk], ip = vlist[row + (has_prev ? kk - 1 : kk)];
+      const float z = sample_z(D, r, zvals, i), zp = sample_z(D, r, zvals, ip);
+      float p[3], n[3], q[3], m[3];
       sample_point(D, r, z, p);
       normalize(D, p, n);
+      sample_point(D, r, zp, q);
+      normalize(D, q, m);
       const float n0 = pl == 0 ? n[kM0(0)] : (pl == 1 ? n[kM0(1)] : n[kM0(2)]);
       const float n1 = pl == 0 ? n[kM1(0)] : (pl == 1 ? n[kM1(1)] : n[kM1(2)]);
       const float n2 = pl == 0 ? n[kV(0)] : (pl == 1 ? n[kV(1)] : n[kV(2)]);
-      make_step_rec(n0, n1, n2, sel3(pl, D.ph[0], D.ph[1], D.ph[2]), sel3(pl, D.pw[0], D.pw[1], D.pw[2]),
-                    sel3(pl, D.ll[0], D.ll[1], D.ll[2]), CD, rec + smp * kWalkRecW + pl * kRecWords);
+      const float m0 = pl == 0 ? m[kM0(0)] : (pl == 1 ? m[kM0(1)] : m[kM0(2)]);
+      const float m1 = pl == 0 ? m[kM1(0)] : (pl == 1 ? m[kM1(1)] : m[kM1(2)]);
+      const float m2 = pl == 0 ? m[kV(0)] : (pl == 1 ? m[kV(1)] : m[kV(2)]);
+      make_step_rec(n0, n1, n2, m0, m1, m2, has_prev, sel3(pl, D.ph[0], D.ph[1], D.ph[2]),
+                    sel3(pl, D.pw[0], D.pw[1], D.pw[2]), sel3(pl, D.ll[0], D.ll[1], D.ll[2]), CD,
+                    rec + smp * kWalkRecW + pl * kRecWords);
       if (pl == 0) {
         rec[smp * kWalkRecW + 3 * kRecWords] = (smp < ns) ? gfeat[row + i] : 0.f;
         rec[smp * kWalkRecW + 3 * kRecWords + 1] = z;

@@ -358,7 +358,7 @@ static inline PeMask pe_masks(float fea_progress, float view_progress, int fea_p
 
 template <class C>
 struct BwdCfg {
-  static constexpr int TP_ROWS = 64;  // 48 rows of product gradients + 32 step records of 16 words (jt_walk.h);
+  static constexpr int TP_ROWS = 68;  // 48 rows of product gradients + 32 step records (jt_walk.h);
                                       // also the 2*16*64-float sin/cos stash
   static_assert(C::CA <= 48 && (TP_ROWS - 48) * 33 >= 32 * kRecWords, "LDS tile");
   static constexpr int TP_LD = 33;
@@ -551,14 +551,24 @@ __device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, c
     ail = row16_sum(ail);
     if (cl < 3) atomicAdd(&gxyz[sidx * 4 + my_axis], ((cl == 0) ? aix : (cl == 1) ? aiy : ail) * my_scale);
   };
+  // the factor values are fetched two steps ahead of their use (three rotating buffers, steps fully unrolled)
+  TapBuf<NCH> bufC;
   wk.load(bufA, P, Ln, rec0);
-#pragma unroll 1
-  for (int q = 0; q < 8; q += 2) {
-    wk.load(bufB, P, Ln, rec0 + (q + 1) * kRecWords);
-    step(bufA, q);
-    if (q + 2 < 8) wk.load(bufA, P, Ln, rec0 + (q + 2) * kRecWords);
-    step(bufB, q + 1);
-  }
+  wk.load(bufB, P, Ln, rec0 + kRecWords);
+  wk.load(bufC, P, Ln, rec0 + 2 * kRecWords);
+  step(bufA, 0);
+  wk.load(bufA, P, Ln, rec0 + 3 * kRecWords);
+  step(bufB, 1);
+  wk.load(bufB, P, Ln, rec0 + 4 * kRecWords);
+  step(bufC, 2);
+  wk.load(bufC, P, Ln, rec0 + 5 * kRecWords);
+  step(bufA, 3);
+  wk.load(bufA, P, Ln, rec0 + 6 * kRecWords);
+  step(bufB, 4);
+  wk.load(bufB, P, Ln, rec0 + 7 * kRecWords);
+  step(bufC, 5);
+  step(bufA, 6);
+  step(bufB, 7);
   wk.finish();
 }
 
@@ -739,9 +749,12 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
       // step records of the tile's samples for this plane (one lane per sample), in the rows of tp past
       // the product gradients
       float* recs = tp + 48 * 33;
-      if (h == 0)
-        make_step_rec(geo[j * 4 + kM0(pl)], geo[j * 4 + kM1(pl)], geo[j * 4 + kV(pl)], D.ph[pl], D.pw[pl], D.ll[pl],
-                      C::CA, recs + j * kRecWords);
+      if (h == 0) {
+        const int jp = (j & 7) ? j - 1 : j;  // previous sample of the same 8-sample run
+        make_step_rec(geo[j * 4 + kM0(pl)], geo[j * 4 + kM1(pl)], geo[j * 4 + kV(pl)], geo[jp * 4 + kM0(pl)],
+                      geo[jp * 4 + kM1(pl)], geo[jp * 4 + kV(pl)], (j & 7) != 0, D.ph[pl], D.pw[pl], D.ll[pl], C::CA,
+                      recs + j * kRecWords);
+      }
       wave_lds_sync();
       if (!(ablate & 1)) scatter_plane<C>(D, G, pl, tp, recs, gxyz, lane);
       wave_lds_sync();

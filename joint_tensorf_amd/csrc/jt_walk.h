@@ -194,40 +194,80 @@ struct PlaneWalker {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Step records.  The geometry of a (sample, plane) pair -- tap addresses, weights, cell ids -- is the same
-// for every channel, so it is computed ONCE by one lane (make_step_rec) and parked in LDS as 16 words;
-// the channel lanes of the walker read it back as broadcast LDS loads instead of redoing ~60 VALU
-// instructions of index arithmetic per lane.
-//   word 0..3  byte offsets of the plane taps (x0,y0) (x1,y0) (x0,y1) (x1,y1), clamped into the plane
-//        4..5  byte offsets of the two line taps, clamped
-//        6     cell x | cell y << 16   (int16 each)
-//        7     line cell | in-range bits << 16  (bit0..3 plane taps in the order above, bit 4..5 line taps)
-//        8..11 plane tap weights (zero when the tap is out of range), 12..13 line tap weights
-//        14,15 fractional parts fx, fy
+// Step records.  The geometry of a (sample, plane) pair -- tap addresses, weights, which texels the walk
+// leaves -- is the same for every channel, so it is computed ONCE by one lane (make_step_rec) and parked in
+// LDS as kRecWords words; the channel lanes of the walker read it back as broadcast LDS loads instead of
+// redoing ~100 VALU instructions of index arithmetic and cell bookkeeping per lane.
+//
+// Accumulator slots.  The four texels of a plane cell are kept in four accumulators indexed by the PARITY of
+// the texel coordinates, slot = (X & 1) + 2 (Y & 1) (line: slot = Z & 1).  The texels of any cell have
+// distinct parities, and when the walk steps to a neighbouring cell the texels that stay keep their slot --
+// nothing is ever moved between accumulators; the slots whose texel is left behind are flushed (one float
+// atomic per channel) and start over for the texel that takes their place.  Which slots to flush follows
+// from the previous sample's cell, so the record carries it as a bit mask.
+//   word 0..3   byte offsets of the texels of the plane cell in slot order, clamped into the plane
+//        4..5   byte offsets of the two line taps in slot order, clamped
+//        6      bits 0..3 / 4..5: plane / line slot holds an in-range texel;
+//               bits 8..11 / 12..13: plane / line slot must be flushed before this sample is accumulated
+//        7      +-1: sign that turns (line slot 1 - line slot 0) into (tap 1 - tap 0)
+//        8..11  tap weights in slot order (zero when the tap is out of range), 12..13 line tap weights
+//        14..17 coefficients of d(plane value)/d(ix, iy) in slot terms:
+//               d/dix = cxA (s1 - s0) + cxB (s3 - s2),  d/diy = cyA (s2 - s0) + cyB (s3 - s1)
 // ---------------------------------------------------------------------------------------------
-constexpr int kRecWords = 16;
+constexpr int kRecWords = 20;
 
-__device__ inline void make_step_rec(float gx, float gy, float gl, int H, int W, int LL, int CA, float* rec) {
-  const PlaneTaps t = plane_taps(gx, gy, H, W, CA);
-  const Axis l = axis_taps(gl, LL);
-  unsigned bits = 0u;
-  bits |= (t.ax.m0 * t.ay.m0 != 0.f) ? 1u : 0u;
-  bits |= (t.ax.m1 * t.ay.m0 != 0.f) ? 2u : 0u;
-  bits |= (t.ax.m0 * t.ay.m1 != 0.f) ? 4u : 0u;
-  bits |= (t.ax.m1 * t.ay.m1 != 0.f) ? 8u : 0u;
-  bits |= (l.m0 != 0.f) ? 16u : 0u;
-  bits |= (l.m1 != 0.f) ? 32u : 0u;
-  uint4 o = make_uint4((unsigned)t.o00 * 4u, (unsigned)t.o10 * 4u, (unsigned)t.o01 * 4u, (unsigned)t.o11 * 4u);
-  uint4 m = make_uint4((unsigned)(l.c0 * CA) * 4u, (unsigned)(l.c1 * CA) * 4u,
-                       ((unsigned)t.ax.i0 & 0xffffu) | ((unsigned)t.ay.i0 << 16),
-                       ((unsigned)l.i0 & 0xffffu) | (bits << 16));
-  *reinterpret_cast<uint4*>(rec) = o;
-  *reinterpret_cast<uint4*>(rec + 4) = m;
-  *reinterpret_cast<float4*>(rec + 8) = make_float4(t.w00, t.w10, t.w01, t.w11);
-  *reinterpret_cast<float4*>(rec + 12) = make_float4(l.w0, l.w1, t.ax.f, t.ay.f);
+template <class T>
+__device__ inline void swap_if(T& a, T& b, bool c) {
+  const T t = c ? b : a;
+  b = c ? a : b;
+  a = t;
 }
 
-// factor values at the six taps of one (sample, plane) for the lane's channels cl, cl+16, ...
+// cell of a normalised coordinate along an axis of `size` texels (the i0 of axis_taps)
+__device__ inline int axis_cell(float g, int size) { return (int)floorf(((g + 1.f) * 0.5f) * (float)(size - 1)); }
+
+// (gx, gy, gl): normalised coordinates of the sample on the plane axes / the line axis; (pgx, pgy, pgl) those
+// of the previous sample of the run (has_prev = false for the first sample of a run: nothing to flush)
+__device__ inline void make_step_rec(float gx, float gy, float gl, float pgx, float pgy, float pgl, bool has_prev,
+                                     int H, int W, int LL, int CA, float* rec) {
+  const PlaneTaps t = plane_taps(gx, gy, H, W, CA);
+  const Axis l = axis_taps(gl, LL);
+  const int cx = t.ax.i0, cy = t.ay.i0, cz = l.i0;
+  const bool px = cx & 1, py = cy & 1, pz = cz & 1;
+  unsigned o0 = (unsigned)t.o00 * 4u, o1 = (unsigned)t.o10 * 4u, o2 = (unsigned)t.o01 * 4u, o3 = (unsigned)t.o11 * 4u;
+  float w0 = t.w00, w1 = t.w10, w2 = t.w01, w3 = t.w11;
+  unsigned b0 = (t.ax.m0 * t.ay.m0 != 0.f), b1 = (t.ax.m1 * t.ay.m0 != 0.f), b2 = (t.ax.m0 * t.ay.m1 != 0.f),
+           b3 = (t.ax.m1 * t.ay.m1 != 0.f);
+  // slot sx + 2 sy holds corner (sx ^ px) + 2 (sy ^ py)
+  swap_if(o0, o1, px); swap_if(o2, o3, px); swap_if(w0, w1, px); swap_if(w2, w3, px); swap_if(b0, b1, px); swap_if(b2, b3, px);
+  swap_if(o0, o2, py); swap_if(o1, o3, py); swap_if(w0, w2, py); swap_if(w1, w3, py); swap_if(b0, b2, py); swap_if(b1, b3, py);
+  unsigned l0 = (unsigned)(l.c0 * CA) * 4u, l1 = (unsigned)(l.c1 * CA) * 4u;
+  float lw0 = l.w0, lw1 = l.w1;
+  unsigned lb0 = (l.m0 != 0.f), lb1 = (l.m1 != 0.f);
+  swap_if(l0, l1, pz); swap_if(lw0, lw1, pz); swap_if(lb0, lb1, pz);
+  unsigned bits = b0 | (b1 << 1) | (b2 << 2) | (b3 << 3) | (lb0 << 4) | (lb1 << 5);
+  if (has_prev) {
+    const int qx = axis_cell(pgx, W), qy = axis_cell(pgy, H), qz = axis_cell(pgl, LL);
+    // texel of parity s in the previous cell: q + ((s - q) & 1); it stays iff it is c or c + 1
+    const int x0 = qx + ((0 - qx) & 1), x1 = qx + ((1 - qx) & 1);
+    const int y0 = qy + ((0 - qy) & 1), y1 = qy + ((1 - qy) & 1);
+    const int z0 = qz + ((0 - qz) & 1), z1 = qz + ((1 - qz) & 1);
+    const unsigned fx0 = (x0 != cx) && (x0 != cx + 1), fx1 = (x1 != cx) && (x1 != cx + 1);
+    const unsigned fy0 = (y0 != cy) && (y0 != cy + 1), fy1 = (y1 != cy) && (y1 != cy + 1);
+    const unsigned fz0 = (z0 != cz) && (z0 != cz + 1), fz1 = (z1 != cz) && (z1 != cz + 1);
+    bits |= ((fx0 | fy0) << 8) | ((fx1 | fy0) << 9) | ((fx0 | fy1) << 10) | ((fx1 | fy1) << 11) | (fz0 << 12) |
+            (fz1 << 13);
+  }
+  const float wy0 = 1.f - t.ay.f, wy1 = t.ay.f, wx0 = 1.f - t.ax.f, wx1 = t.ax.f;
+  const float sgx = px ? -1.f : 1.f, sgy = py ? -1.f : 1.f;
+  *reinterpret_cast<uint4*>(rec) = make_uint4(o0, o1, o2, o3);
+  *reinterpret_cast<uint4*>(rec + 4) = make_uint4(l0, l1, bits, __float_as_uint(pz ? -1.f : 1.f));
+  *reinterpret_cast<float4*>(rec + 8) = make_float4(w0, w1, w2, w3);
+  *reinterpret_cast<float4*>(rec + 12) = make_float4(lw0, lw1, sgx * (py ? wy1 : wy0), sgx * (py ? wy0 : wy1));
+  *reinterpret_cast<float2*>(rec + 16) = make_float2(sgy * (px ? wx1 : wx0), sgy * (px ? wx0 : wx1));
+}
+
+// factor values at the six taps of one (sample, plane), slot order, for the lane's channels cl, cl+16, ...
 template <int NCH>
 struct TapBuf {
   float a[NCH], b[NCH], c[NCH], d[NCH], u[NCH], v[NCH];
@@ -249,10 +289,9 @@ __device__ inline float row16_sum(float v) {
 // Run-length accumulator of one plane + its line, driven by step records.
 template <int NCH, int CA>
 struct RecWalker {
-  float acc[4][NCH];  // corners (0,0) (1,0) (0,1) (1,1) of the current cell
-  float accl[2][NCH];
-  int cx, cy, cz;
-  unsigned o[4], lo[2];  // byte offsets of the current cell's texels (from its step record)
+  float acc[4][NCH];   // plane accumulators, parity slots
+  float accl[2][NCH];  // line accumulators, parity slots
+  unsigned o[4], lo[2];  // byte offsets of the texels the slots currently stand for
   unsigned ck[NCH];      // byte offset of the lane's k-th channel inside a texel (0 for a padding lane)
   bool live[NCH];
   float* gP;
@@ -261,7 +300,6 @@ struct RecWalker {
   __device__ inline void init(float* gP_, float* gL_, int cl) {
     gP = gP_;
     gL = gL_;
-    cx = cy = cz = -1000000;
 #pragma unroll
     for (int c = 0; c < 4; ++c) o[c] = 0u;
     lo[0] = lo[1] = 0u;
@@ -295,79 +333,19 @@ struct RecWalker {
       a[k] = 0.f;
     }
   }
-  // move the register window to the cell of `rec`
+  // flush the slots whose texel the walk leaves with this sample, then adopt the sample's texels
   __device__ inline void advance(const float* rec) {
-    const uint2 cw = *reinterpret_cast<const uint2*>(rec + 6);
-    const int nx = (int)(short)(cw.x & 0xffffu), ny = (int)cw.x >> 16, nz = (int)(short)(cw.y & 0xffffu);
-    if (nx != cx || ny != cy) {
-      if (ny == cy && nx == cx + 1) {
-        flush(gP, o[0], acc[0]);
-        flush(gP, o[2], acc[2]);
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-          acc[0][k] = acc[1][k];
-          acc[2][k] = acc[3][k];
-          acc[1][k] = acc[3][k] = 0.f;
-        }
-      } else if (ny == cy && nx == cx - 1) {
-        flush(gP, o[1], acc[1]);
-        flush(gP, o[3], acc[3]);
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-          acc[1][k] = acc[0][k];
-          acc[3][k] = acc[2][k];
-          acc[0][k] = acc[2][k] = 0.f;
-        }
-      } else if (nx == cx && ny == cy + 1) {
-        flush(gP, o[0], acc[0]);
-        flush(gP, o[1], acc[1]);
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-          acc[0][k] = acc[2][k];
-          acc[1][k] = acc[3][k];
-          acc[2][k] = acc[3][k] = 0.f;
-        }
-      } else if (nx == cx && ny == cy - 1) {
-        flush(gP, o[2], acc[2]);
-        flush(gP, o[3], acc[3]);
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-          acc[2][k] = acc[0][k];
-          acc[3][k] = acc[1][k];
-          acc[0][k] = acc[1][k] = 0.f;
-        }
-      } else {
-        flush(gP, o[0], acc[0]);
-        flush(gP, o[1], acc[1]);
-        flush(gP, o[2], acc[2]);
-        flush(gP, o[3], acc[3]);
-      }
-      cx = nx;
-      cy = ny;
-    }
-    if (nz != cz) {
-      if (nz == cz + 1) {
-        flush(gL, lo[0], accl[0]);
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-          accl[0][k] = accl[1][k];
-          accl[1][k] = 0.f;
-        }
-      } else if (nz == cz - 1) {
-        flush(gL, lo[1], accl[1]);
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-          accl[1][k] = accl[0][k];
-          accl[0][k] = 0.f;
-        }
-      } else {
-        flush(gL, lo[0], accl[0]);
-        flush(gL, lo[1], accl[1]);
-      }
-      cz = nz;
+    const uint4 rl = *reinterpret_cast<const uint4*>(rec + 4);
+    const unsigned bits = rl.z;
+    if (bits & 0x3f00u) {
+      if (bits & 0x100u) flush(gP, o[0], acc[0]);
+      if (bits & 0x200u) flush(gP, o[1], acc[1]);
+      if (bits & 0x400u) flush(gP, o[2], acc[2]);
+      if (bits & 0x800u) flush(gP, o[3], acc[3]);
+      if (bits & 0x1000u) flush(gL, lo[0], accl[0]);
+      if (bits & 0x2000u) flush(gL, lo[1], accl[1]);
     }
     const uint4 ro = *reinterpret_cast<const uint4*>(rec);
-    const uint2 rl = *reinterpret_cast<const uint2*>(rec + 4);
     o[0] = ro.x;
     o[1] = ro.y;
     o[2] = ro.z;
@@ -381,9 +359,11 @@ struct RecWalker {
   __device__ inline void add(TapBuf<NCH>& tv, const float* rec, const float g[NCH], float& aix, float& aiy,
                              float& ail) {
     const float4 w = *reinterpret_cast<const float4*>(rec + 8);
-    const float4 x = *reinterpret_cast<const float4*>(rec + 12);  // lw0, lw1, fx, fy
-    const unsigned bits = reinterpret_cast<const unsigned*>(rec)[7] >> 16;
-    if (bits != 0x3fu) {  // a tap outside the factor (exactly on the far border): its value counts as zero
+    const float4 x = *reinterpret_cast<const float4*>(rec + 12);  // lw0, lw1, cxA, cxB
+    const float2 y = *reinterpret_cast<const float2*>(rec + 16);  // cyA, cyB
+    const unsigned bits = reinterpret_cast<const unsigned*>(rec)[6];
+    const float sgz = rec[7];
+    if ((bits & 0x3fu) != 0x3fu) {  // a tap outside the factor (exactly on the far border): its value counts as zero
 #pragma unroll
       for (int k = 0; k < NCH; ++k) {
         if (!(bits & 1u)) tv.a[k] = 0.f;
@@ -394,7 +374,6 @@ struct RecWalker {
         if (!(bits & 32u)) tv.v[k] = 0.f;
       }
     }
-    const float fx = x.z, fy = x.w, gx1 = 1.f - fx, gy1 = 1.f - fy;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const float pv = w.x * tv.a[k] + w.y * tv.b[k] + w.z * tv.c[k] + w.w * tv.d[k];
@@ -406,9 +385,9 @@ struct RecWalker {
       acc[3][k] += w.w * gpv;
       accl[0][k] += x.x * glv;
       accl[1][k] += x.y * glv;
-      aix += gpv * ((tv.b[k] - tv.a[k]) * gy1 + (tv.d[k] - tv.c[k]) * fy);
-      aiy += gpv * ((tv.c[k] - tv.a[k]) * gx1 + (tv.d[k] - tv.b[k]) * fx);
-      ail += glv * (tv.v[k] - tv.u[k]);
+      aix += gpv * (x.z * (tv.b[k] - tv.a[k]) + x.w * (tv.d[k] - tv.c[k]));
+      aiy += gpv * (y.x * (tv.c[k] - tv.a[k]) + y.y * (tv.d[k] - tv.b[k]));
+      ail += glv * (sgz * (tv.v[k] - tv.u[k]));
     }
   }
   __device__ inline void finish() {
