@@ -795,15 +795,22 @@ __device__ inline float pe_pick(int b, float x, float sn, float cs, float m0, fl
                                                                                     : (1.f - 2.f * sn * sn) * m1;
 }
 
-// the 16 samples of parity h of one record row (zeros beyond nl live samples or for a dead row)
-__device__ inline void load_row_parity(const float* __restrict__ row, bool live, int h, int nl, float out[16]) {
+// the 16 samples [16 h, 16 h + 16) of one record row (zeros for a dead row): four 16-byte loads
+__device__ inline void load_row_half(const float* __restrict__ row, bool live, int h, float out[16]) {
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    float4 v = live ? ld4(row + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float e0 = h ? v.y : v.x, e1 = h ? v.w : v.z;
-    out[2 * q] = (4 * q + h < nl) ? e0 : 0.f;
-    out[2 * q + 1] = (4 * q + 2 + h < nl) ? e1 : 0.f;
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = live ? ld4(row + 16 * h + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    out[4 * q] = v.x;
+    out[4 * q + 1] = v.y;
+    out[4 * q + 2] = v.z;
+    out[4 * q + 3] = v.w;
   }
+}
+
+// zero the samples past the nl live ones of a partial tile
+__device__ inline void mask_tail(float v[16], int h, int nl) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] = (16 * h + q < nl) ? v[q] : 0.f;
 }
 
 template <int MT, int NT, int XF>
@@ -832,49 +839,107 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ rec, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   }
-  for (int t = t_begin; t < t_end; ++t) {
-    const float* rt = rec + (size_t)t * rec_rows * 32;
-    const int nl = min(32, n - t * 32);
-    float av[MT][16];
+  // The contraction runs over the samples of a tile in any order: lane half h takes samples 16 h .. 16 h + 15
+  // (MFMA step q pairs sample q with sample 16 + q), so a lane reads 64 contiguous bytes of its unit's row.
+  // Rows are fetched one step ahead of the MFMAs that consume them (next B row, or the next tile's A rows).
+  const size_t tstride = (size_t)rec_rows * 32;
+  auto loadA = [&](int t, float (*dst)[16]) {
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
       const int c = a * 32 + m;
-      load_row_parity(rt + (size_t)(a_row0 + min(c, M - 1)) * 32, c < M, h, nl, av[a]);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) asum[a] += av[a][q];
+      load_row_half(rec + (size_t)t * tstride + (size_t)(a_row0 + min(c, M - 1)) * 32, c < M, h, dst[a]);
     }
-    if (XF == 0) {
+  };
+  float av[MT][16], an[MT][16];
+  if (XF == 0) {
+    auto loadB = [&](int t, int b, float* dst) {
+      const int c = b * 32 + m;
+      load_row_half(rec + (size_t)t * tstride + (size_t)(b_row0 + min(c, N - 1)) * 32, c < N, h, dst);
+    };
+    float bv[16], bn[16];
+    if (t_begin < t_end) {
+      loadA(t_begin, av);
+      loadB(t_begin, 0, bv);
+    }
+    for (int t = t_begin; t < t_end; ++t) {
+      const int nl = min(32, n - t * 32);
 #pragma unroll
       for (int b = 0; b < NT; ++b) {
-        const int c = b * 32 + m;
-        float bv[16];
-        load_row_parity(rt + (size_t)(b_row0 + min(c, N - 1)) * 32, c < N, h, nl, bv);
+        if (b + 1 < NT) {
+          loadB(t, b + 1, bn);
+        } else if (t + 1 < t_end) {
+          loadA(t + 1, an);
+          loadB(t + 1, 0, bn);
+        }
+        if (b == 0) {
+          if (nl < 32) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a) mask_tail(av[a], h, nl);
+          }
+#pragma unroll
+          for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) asum[a] += av[a][q];
+        }
+        if (nl < 32) mask_tail(bv, h, nl);  // never-written record slots may hold anything, 0 * NaN is NaN
 #pragma unroll
         for (int q = 0; q < 16; ++q)
 #pragma unroll
           for (int a = 0; a < MT; ++a)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][q], bv[q], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bv[q] = bn[q];
       }
-    } else {
-      const bool feat = m < APP, view = (XF == 1) && !feat && (m < APP + 3);
-      const int srow = feat ? f_row0 + m : vd_row0 + (view ? m - APP : 0);
-      float x[16], sn[16], cs[16];
-      load_row_parity(rt + (size_t)srow * 32, feat || view, h, nl, x);
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) av[a][q] = an[a][q];
+    }
+  } else {
+    const bool feat = m < APP, view = (XF == 1) && !feat && (m < APP + 3);
+    const int srow = feat ? f_row0 + m : vd_row0 + (view ? m - APP : 0);
+    const float m0 = view ? pm.v0 : pm.f0, m1 = view ? pm.v1 : pm.f1;
+    const bool live = feat || view;
+    float x[16], xn[16];
+    if (t_begin < t_end) {
+      loadA(t_begin, av);
+      load_row_half(rec + (size_t)t_begin * tstride + (size_t)srow * 32, live, h, x);
+    }
+    for (int t = t_begin; t < t_end; ++t) {
+      const int nl = min(32, n - t * 32);
+      if (t + 1 < t_end) {
+        loadA(t + 1, an);
+        load_row_half(rec + (size_t)(t + 1) * tstride + (size_t)srow * 32, live, h, xn);
+      }
+      if (nl < 32) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a) mask_tail(av[a], h, nl);
+        mask_tail(x, h, nl);  // never-written record slots may hold anything, 0 * NaN is NaN
+      }
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asum[a] += av[a][q];
+      float sn[16], cs[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) sincos_f(x[q], &sn[q], &cs[q]);
-      const float m0 = view ? pm.v0 : pm.f0, m1 = view ? pm.v1 : pm.f1;
-      const bool live = feat || view;
 #pragma unroll
       for (int b = 0; b < NT; ++b) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const bool sok = (2 * q + h) < nl;  // x is 0 beyond nl, but cos(0) = 1: mask explicitly
-          const float bv = (live && sok) ? pe_pick<XF>(b, x[q], sn[q], cs[q], m0, m1) : 0.f;
+          // the A operand is zero past nl, so the (finite) encoding of a padding sample never contributes
+          const float bv = live ? pe_pick<XF>(b, x[q], sn[q], cs[q], m0, m1) : 0.f;
 #pragma unroll
           for (int a = 0; a < MT; ++a)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][q], bv, acc[a][b], 0, 0, 0);
         }
       }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) x[q] = xn[q];
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) av[a][q] = an[a][q];
     }
   }
   // epilogue: sum the four waves' tiles through LDS and park the block's partial result in its slab
@@ -968,7 +1033,7 @@ static int shade_kind(const JtScene* s) {
 // on an auxiliary stream, concurrently with whatever the caller enqueues next on the main stream (the
 // density backward: atomics / VALU bound, while the GEMMs are MFMA bound).
 static const int kChunkEntries = 1 << 20;
-static const int kWgradBlocks = 256;
+static const int kWgradBlocks = 512;
 
 template <class C>
 struct WsLayout {
