@@ -47,10 +47,16 @@ def setup_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("JT_BENCH_SINGLE_DEVICE") == "1":
+        local = 0  # functional test of the N > 1 path on a one-GPU box (with JT_DIST_BACKEND=gloo)
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("JT_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     return world, rank, local
