@@ -494,6 +494,112 @@ def resolve_blur(progress, schedule_density, schedule_color, mode, random_scale=
 
 
 # ----------------------------------------------------------------------------------------------
+# N1  evaluation: camera pre-alignment, test-time pose optimisation, sliced eval render
+#                                     camera.py:342-366, model/bat.py:212-292,354-367, model/nerf.py:525-548,728-740
+# ----------------------------------------------------------------------------------------------
+def camera_centers(pose):
+    """world position of the camera centre of world->camera poses [...,3,4]  (camera.cam2world of the origin)."""
+    R, t = pose[..., :3], pose[..., 3:]
+    return (-R.transpose(-1, -2) @ t)[..., 0]
+
+
+def rotation_distance(R1, R2, eps=1e-7):
+    """camera.py:342-347."""
+    Rd = R1 @ R2.transpose(-2, -1)
+    trace = Rd[..., 0, 0] + Rd[..., 1, 1] + Rd[..., 2, 2]
+    return ((trace - 1) / 2).clamp(-1 + eps, 1 - eps).acos()
+
+
+def procrustes_analysis(X0, X1):
+    """camera.py:349-366: similarity (t0, t1, s0, s1, R) with X1 -> X0: (X1 - t1) / s1 @ R.T * s0 + t0."""
+    t0 = X0.mean(dim=0, keepdim=True)
+    t1 = X1.mean(dim=0, keepdim=True)
+    X0c, X1c = X0 - t0, X1 - t1
+    s0 = (X0c ** 2).sum(dim=-1).mean().sqrt()
+    s1 = (X1c ** 2).sum(dim=-1).mean().sqrt()
+    # same LAPACK driver as the reference's Tensor.svd: with few (coplanar) cameras the smallest singular
+    # vector's sign is the routine's choice
+    U, S, V = torch.svd(((X0c / s0).t() @ (X1c / s1)).double(), some=True)
+    R = (U @ V.t()).float()
+    if R.det() < 0:
+        R[2] *= -1
+    return dict(t0=t0[0], t1=t1[0], s0=s0, s1=s1, R=R)
+
+
+def prealign_cameras(pose, pose_GT):
+    """model/bat.py:212-228: align the optimised training cameras with the ground truth up to a similarity."""
+    center_pred, center_GT = camera_centers(pose), camera_centers(pose_GT)
+    sim3 = procrustes_analysis(center_GT, center_pred)
+    center_aligned = (center_pred - sim3["t1"]) / sim3["s1"] @ sim3["R"].t() * sim3["s0"] + sim3["t0"]
+    R_aligned = pose[..., :3] @ sim3["R"].t()
+    t_aligned = (-R_aligned @ center_aligned[..., None])[..., 0]
+    return torch.cat([R_aligned, t_aligned[..., None]], -1), sim3
+
+
+def camera_alignment_error(pose_aligned, pose_GT):
+    """model/bat.py:230-238: per-view rotation angle [rad] and translation distance."""
+    return (rotation_distance(pose_aligned[..., :3], pose_GT[..., :3]),
+            (pose_aligned[..., 3] - pose_GT[..., 3]).norm(dim=-1))
+
+
+def eval_pose(sim3, pose, pose_refine_test=None):
+    """model/bat.py:354-367: a held-out GT pose moved into the optimised coordinate system (inverse of the
+    similarity above), optionally followed by the test-time refinement."""
+    center = camera_centers(pose)
+    center_aligned = (center - sim3["t0"]) / sim3["s0"] @ sim3["R"] * sim3["s1"] + sim3["t1"]
+    R_aligned = pose[..., :3] @ sim3["R"]
+    t_aligned = (-R_aligned @ center_aligned[..., None])[..., 0]
+    out = torch.cat([R_aligned, t_aligned[..., None]], -1)
+    if pose_refine_test is not None:
+        out = compose_pair(pose_refine_test, out)
+    return out
+
+
+def test_time_optim(cfg, params, sim3, pose, image, intr_inv, H, W, n_rays, N_samples, offsets, lr, lr_test,
+                    lr_test_end, iters, white_bg=True, view_pe_progress=1.0, fea_pe_progress=1.0):
+    """model/bat.py:265-292 for one held-out view of the Blender configuration (no blur at test time):
+    Adam on a fresh se3 [1,6] against the photometric loss of a ray lattice (offsets = the np.random.randint
+    draws, two per iteration).  Returns (se3, pose_refine_test, trace of se3 before each step, trace of
+    loss.render).  Reproduced quirk: the reference refreshes `var.pose_refine_test` at the TOP of every iteration
+    only (bat.py:284), so the eval render that follows (nerf.py:539) sees the refinement from before the last
+    Adam step; `pose_refine_test` is that stale transform."""
+    se3 = torch.zeros(1, 6, requires_grad=True)
+    opt = torch.optim.Adam([dict(params=[se3], lr=lr)])
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=(lr_test_end / lr_test) ** (1.0 / iters))
+    img = image.view(1, 3, H * W).permute(0, 2, 1)
+    tr_se3, tr_loss = [], []
+    pose_refine_test = None
+    for it in range(iters):
+        opt.zero_grad()
+        pose_refine_test = se3_to_SE3(se3)
+        p = eval_pose(sim3, pose, pose_refine_test)
+        ray_idx, _, _, _ = rand_grid_ray_idx(H, W, n_rays, 1, offsets[2 * it], offsets[2 * it + 1])
+        center, ray = rays_for_pixels(p, intr_inv, ray_idx, W)
+        rgb, _, _ = render(cfg, params, center.reshape(-1, 3), ray.reshape(-1, 3), N_samples, white_bg=white_bg,
+                           view_pe_progress=view_pe_progress, fea_pe_progress=fea_pe_progress)
+        loss = render_loss(rgb.view(1, -1, 3), img[:, ray_idx])
+        tr_se3.append(se3.detach().clone())
+        tr_loss.append(float(loss.detach()))
+        loss.backward()
+        opt.step()
+        sched.step()
+    return se3.detach(), pose_refine_test.detach(), torch.stack(tr_se3), tr_loss
+
+
+def render_by_slices(cfg, params, pose, intr_inv, H, W, n_rays, N_samples, **kw):
+    """model/nerf.py:728-740: full image in slices of n_rays pixels."""
+    outs = [[], [], []]
+    with torch.no_grad():
+        for c in range(0, H * W, n_rays):
+            ray_idx = torch.arange(c, min(c + n_rays, H * W))
+            center, ray = rays_for_pixels(pose, intr_inv, ray_idx, W)
+            r = render(cfg, params, center.reshape(-1, 3), ray.reshape(-1, 3), N_samples, **kw)
+            for o, v in zip(outs, r):
+                o.append(v.view(pose.shape[0], len(ray_idx), -1))
+    return [torch.cat(o, 1) for o in outs]
+
+
+# ----------------------------------------------------------------------------------------------
 # A14  losses                        model/tensorf.py:96-142, base.py:259-261, tensoRF.py:212-228
 # ----------------------------------------------------------------------------------------------
 def mse_nanmean(pred, label):

@@ -83,3 +83,55 @@ def test_lattice_and_schedule_helpers():
     assert S == [221, 349, 550, 872, 1000]
     assert abs(O.interp_schedule(0.05, [0.3, 0.15, 0.07] + [0.0] * 8) - 0.225) < 1e-9
     assert O.resolve_blur(0.9, [0.3, 0.15, 0.07] + [0.0] * 8, [0.3, 0.15, 0.07] + [0.0] * 8, "train", 1.0) == (None, None)
+
+
+# ---- N1: evaluation path (camera pre-alignment, test-time pose optimisation, sliced eval render) -------------
+def _eval_fx():
+    return Fixture("blender_test_optim")
+
+
+def _sim3_of(fx):
+    return dict(t0=fx.t("sim3.t0"), t1=fx.t("sim3.t1"), s0=fx.t("sim3.s0"), s1=fx.t("sim3.s1"), R=fx.t("sim3.R"))
+
+
+def test_prealign_cameras_golden():
+    fx = _eval_fx()
+    pose = O.compose_pair(fx.t("param.pose_noise"), fx.t("in.pose_gt"))
+    pose = O.compose_pair(O.se3_to_SE3(fx.t("param.se3_refine.weight")), pose)
+    assert torch.allclose(pose, fx.t("mid.pose_all"), atol=2e-6)
+    aligned, sim3 = O.prealign_cameras(pose, fx.t("in.pose_gt"))
+    ref = _sim3_of(fx)
+    for k in ("t0", "t1", "s0", "s1", "R"):
+        assert torch.allclose(sim3[k], ref[k], atol=2e-6), k
+    assert torch.allclose(aligned, fx.t("mid.pose_aligned"), atol=5e-6)
+    eR, et = O.camera_alignment_error(aligned, fx.t("in.pose_gt"))
+    assert torch.allclose(eR, fx.t("err.R"), atol=2e-4)  # acos near 0 amplifies round-off
+    assert torch.allclose(et, fx.t("err.t"), atol=5e-6)
+
+
+def test_test_time_optim_and_eval_render_golden():
+    fx = _eval_fx()
+    m = fx.meta
+    cfg = fx.cfg()
+    params = fx.params(requires_grad=False)
+    sim3 = _sim3_of(fx)
+    call = m["forward_calls_optim"][0]
+    se3, pose_refine_test, tr_se3, tr_loss = O.test_time_optim(
+        cfg, params, sim3, fx.t("in.test_pose"), fx.t("in.test_image"), fx.t("in.intr_inv"), m["H"], m["W"],
+        m["n_rays"], m["N_samples"], m["np_randint"], m["lr_pose"], m["lr_pose_test"], m["lr_pose_test_end"],
+        m["test_iter"], white_bg=call["white_bg"], view_pe_progress=call["view_pe_progress"],
+        fea_pe_progress=call["fea_pe_progress"])
+    assert np.allclose(tr_loss, fx.arrays["trace.loss_render"], atol=2e-6)
+    # Adam normalises the gradient: every step moves each coordinate by ~lr, so the trace is a sign test of
+    # the pose gradient and a value test of the optimiser arithmetic
+    assert torch.allclose(tr_se3, fx.t("trace.se3"), atol=2e-6)
+    assert torch.allclose(se3, fx.t("out.se3_refine_test"), atol=2e-6)
+    # the eval render uses the refinement from before the last step (reference quirk, see O.test_time_optim)
+    pose = O.eval_pose(sim3, fx.t("in.test_pose"), pose_refine_test)
+    rgb, depth, acc = O.render_by_slices(cfg, params, pose, fx.t("in.intr_inv"), m["H"], m["W"], m["n_rays"],
+                                         m["N_samples"], white_bg=m["forward_call_eval"]["white_bg"])
+    assert torch.allclose(rgb, fx.t("out.rgb"), atol=2e-6)
+    assert torch.allclose(depth, fx.t("out.depth"), atol=2e-5)
+    assert torch.allclose(acc, fx.t("out.opacity"), atol=2e-6)
+    psnr = -10 * O.mse_nanmean(rgb.view(-1, m["H"], m["W"], 3).permute(0, 3, 1, 2), fx.t("in.test_image")).log10()
+    assert abs(float(psnr) - float(fx.arrays["out.psnr"])) < 1e-4

@@ -364,6 +364,114 @@ def run_case(bat, camera, opt, graph, var, mode, it, progress, out_path, llff=Fa
           "size=%.0f KB" % (os.path.getsize(out_path) / 1024))
 
 
+def eval_case(bat, camera, opt, graph, var, out_path, test_iter=4, seed=21):
+    """N1: Procrustes pre-alignment of the optimised training cameras, a short test-time
+    photometric pose optimisation of one held-out view and the sliced full-image render + PSNR, all run by
+    the reference's own bat.Model methods (model/bat.py:205-292, model/nerf.py:525-548)."""
+    import types
+    import json
+    import model.tensorf as ref_tensorf
+    import model.tensorf_repr.tensorBase as tB
+    import model.tensorf_repr.batBase as bB
+
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    opt.optim.test_iter = test_iter
+    graph.eval()
+    graph.it = 5
+    graph.nerf.progress.data.fill_(0.9)
+    n_views = var.pose.shape[0]
+    # all training poses as bat.Model.get_all_training_poses composes them (model/bat.py:197-210)
+    with torch.no_grad():
+        pose_GT = var.pose
+        pose = camera.pose.compose([graph.pose_noise, pose_GT])
+        pose = camera.pose.compose([camera.lie.se3_to_SE3(graph.se3_refine.weight), pose])
+    me = types.SimpleNamespace(graph=graph, it=graph.it)
+    me.summarize_loss = types.MethodType(ref_tensorf.Model.summarize_loss, me)
+    pose_aligned, sim3 = bat.Model.prealign_cameras(me, opt, pose, pose_GT)
+    err = bat.Model.evaluate_camera_alignment(me, opt, pose_aligned, pose_GT)
+    graph.sim3 = sim3
+    # one held-out view
+    g = torch.Generator().manual_seed(seed + 1)
+    eye = 4.0 * np.array([np.cos(1.1) * np.cos(0.6), np.sin(1.1) * np.cos(0.6), np.sin(0.6)])
+    tvar = EasyDict(idx=torch.arange(1), pose=torch.tensor(look_at_pose(eye))[None], intr=var.intr[:1],
+                    intr_inv=var.intr_inv[:1], image=torch.rand(1, 3, opt.H, opt.W, generator=g))
+    rec = Recorder()
+    rec.install(tB, bB)
+    trace_se3, trace_loss = [], []
+    orig_compute = graph.compute_loss
+
+    def compute_spy(opt_, v, mode=None):
+        out = orig_compute(opt_, v, mode=mode)
+        if mode == "test-optim":
+            trace_se3.append(v.se3_refine_test.detach().clone())
+            trace_loss.append(float(out.render.detach()))
+        return out
+
+    graph.compute_loss = compute_spy
+    tf = graph.nerf.tensorf
+    calls = []
+    orig_forward = tf.forward
+
+    def forward_spy(opt_, **kw):
+        calls.append({k: (None if v is None else (v if isinstance(v, (bool, int, float, str)) else None))
+                      for k, v in kw.items() if not isinstance(v, torch.Tensor)})
+        return orig_forward(opt_, **kw)
+
+    tf.forward = forward_spy
+    try:
+        v = bat.Model.evaluate_test_time_photometric_optim(me, opt, EasyDict(tvar))
+        with torch.no_grad():
+            v = graph.forward(opt, v, mode="eval")
+            rgb_map = v.rgb.view(-1, opt.H, opt.W, 3).permute(0, 3, 1, 2)
+            psnr = -10 * graph.MSE_loss(rgb_map, v.image).log10().item()
+    finally:
+        rec.uninstall()
+        graph.compute_loss = orig_compute
+        tf.forward = orig_forward
+    out = {}
+    out.update(state_np(graph))
+    out["in.pose_gt"] = var.pose.numpy()
+    out["in.test_pose"] = tvar.pose.numpy()
+    out["in.test_image"] = tvar.image.numpy()
+    out["in.intr"] = tvar.intr.numpy()
+    out["in.intr_inv"] = tvar.intr_inv.numpy()
+    out["mid.pose_all"] = pose.numpy()
+    out["mid.pose_aligned"] = pose_aligned.numpy()
+    out["sim3.t0"] = sim3.t0.numpy()
+    out["sim3.t1"] = sim3.t1.numpy()
+    out["sim3.s0"] = np.float32(sim3.s0)
+    out["sim3.s1"] = np.float32(sim3.s1)
+    out["sim3.R"] = sim3.R.numpy()
+    out["err.R"] = err.R.numpy()
+    out["err.t"] = err.t.numpy()
+    out["trace.se3"] = torch.stack(trace_se3).numpy()      # value BEFORE the step of iteration k
+    out["trace.loss_render"] = np.array(trace_loss, dtype=np.float32)
+    out["out.se3_refine_test"] = v.se3_refine_test.detach().numpy()
+    out["out.rgb"] = v.rgb.numpy()
+    out["out.depth"] = v.depth.numpy()
+    out["out.opacity"] = v.opacity.numpy()
+    out["out.psnr"] = np.float32(psnr)
+    meta = dict(test_iter=test_iter, H=opt.H, W=opt.W, it=graph.it, progress=0.9, n_rays=int(opt.nerf.n_rays),
+                forward_calls_optim=calls[:test_iter], forward_call_eval=calls[-1], n_forward_calls=len(calls),
+                aabb=[float(x) for x in tf.aabb.view(-1).tolist()], near_far=[float(tf.near_far[0]), float(tf.near_far[1])],
+                stepSize=float(tf.stepSize), step_ratio=float(tf.step_ratio), density_shift=float(tf.density_shift),
+                distance_scale=float(tf.distance_scale), fea2denseAct=str(tf.fea2denseAct),
+                rayMarch_weight_thres=float(tf.rayMarch_weight_thres), shadingMode=str(tf.shadingMode),
+                view_pe=int(tf.view_pe), fea_pe=int(tf.fea_pe), ndc_near_plane=1.0, llff=False,
+                TV_density_weight=float(opt.loss_weight.TV_density), TV_color_weight=float(opt.loss_weight.TV_color),
+                test_photo=bool(opt.optim.test_photo),
+                lr_pose=float(opt.optim.lr_pose), lr_pose_test=float(opt.optim.lr_pose_test),
+                lr_pose_test_end=float(opt.optim.lr_pose_test_end), np_randint=rec.np_randint, np_choice=rec.np_choice,
+                ray_sampling_strategy=str(opt.nerf.ray_sampling_strategy), yaml=str(opt.yaml),
+                gridSize=[int(x) for x in tf.gridSize.tolist()], N_samples=int(graph.nerf.n_samples),
+                L1_weight=float(opt.loss_weight.L1.init))
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(out_path, **out)
+    print("wrote", out_path, "psnr=%.3f" % psnr, "se3_test=", v.se3_refine_test.detach().numpy().round(6).tolist(),
+          "loss trace", [round(x, 6) for x in trace_loss])
+
+
 def known_answers(camera, kernels, bat, out_path):
     """Known-answer vectors for the small pure functions on the path."""
     import model.tensorf_repr.bateRF as bateRF
@@ -442,6 +550,11 @@ def main():
              out_path=os.path.join(outdir, "blender_train_dense.npz"))
     run_case(bat, camera, opt, graph, var, "train", it=4, progress=0.1,
              out_path=os.path.join(outdir, "blender_train_dense_blur.npz"))
+    # N1: camera pre-alignment, test-time pose optimisation and the sliced eval render (semi-transparent field)
+    with torch.no_grad():
+        for p in graph.nerf.tensorf.density_plane:
+            p.mul_(22.0 / 40.0)
+    eval_case(bat, camera, opt, graph, var, os.path.join(outdir, "blender_test_optim.npz"))
 
     # all_view_rand_rays variant (config C1 uses it)
     opt2 = make_opt(options, "bat_blender_VM", H=40, W=40, n_voxel_init=14 ** 3,
