@@ -172,7 +172,8 @@ int jt_composite_forward(const JtScene* scene, int n_rays, const int32_t* shade_
  * jt_composite_backward: g_rgb [R][3] -> g_rgb_s [n][3] (= weight * g_rgb masked by clamp).
  * jt_app_gather_backward: g_prod [n][3*Ca] -> += g_factors.app_*, g_xyz_app [n][3] (overwritten).
  * jt_march_backward: density + transmittance backward:
- *   += g_factors.density_*; g_rays_o, g_rays_d [R][3] overwritten (include the app path's
+ *   += g_factors.density_* (g_factors may be NULL: gradients w.r.t. the rays only); g_rays_o, g_rays_d
+ *   [R][3] overwritten (include the app path's
  *   coordinate gradients read from g_xyz_app).  g_opacity [R] may be NULL.  workspace: caller-provided,
  *   jt_march_backward_workspace_bytes(scene, n_rays) bytes (per-sample density gradients + run lists). */
 int jt_composite_backward(const JtScene* scene, int n_rays, const int32_t* shade_offset,
@@ -200,7 +201,9 @@ size_t jt_march_backward_workspace_bytes(const JtScene* scene, int n_rays);
  * Replaces compute_appfeature + basis_mat + MLPRender_Fea[_WeakView].forward and their autograd.
  *   forward : rgb_s [n][3]; with workspace != NULL (training) it also leaves the per-sample layer inputs
  *             (products, basis output, hidden activations, ReLU masks, sample coordinates) in the workspace
- *   backward: g_rgb_s [n][3] -> += g_factors.app_*, += g_mlp.*, g_xyz_app [n][3] (overwritten); consumes the
+ *   backward: g_rgb_s [n][3] -> += g_factors.app_*, += g_mlp.*, g_xyz_app [n][3] (overwritten); g_factors and /
+ *             or g_mlp may be NULL when that group of gradients is not wanted (test-time pose optimisation,
+ *             model/bat.py:265-292, only needs g_xyz_app); consumes the
  *             records the forward of the SAME samples left in `workspace` (the autograd tape of the chain:
  *             nothing is gathered or evaluated twice) and the forward's rgb_s
  * workspace: jt_shade_workspace_bytes(scene, n_entries_max) bytes, caller-provided; forward with

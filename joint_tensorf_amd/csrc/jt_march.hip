@@ -637,15 +637,17 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
   Dev D;
   int rc = make_dev(scene, factors, &D);
   if (rc) return rc;
-  if (!factors || !g_factors || !rays_o || !rays_d || !sigma_feat || !weight || !tmin || !shade_offset ||
+  if (!factors || !rays_o || !rays_d || !sigma_feat || !weight || !tmin || !shade_offset ||
       !shade_idx || !clamp_mask || !g_rgb || !g_rays_o || !g_rays_d || !workspace || n_rays < 1)
     return JT_ERR_ARG;
   for (int a = 0; a < 3; ++a)
-    if (!g_factors->density_plane[a] || !g_factors->density_line[a]) return JT_ERR_ARG;
+    if (g_factors && (!g_factors->density_plane[a] || !g_factors->density_line[a])) return JT_ERR_ARG;
   if (D.ndc && !zvals) return JT_ERR_ARG;
   if ((rc = check_density_shape(D))) return rc;
   size_t o_vlist, o_nvalid;
   if (workspace_bytes < march_bwd_ws_layout(D.S, n_rays, &o_vlist, &o_nvalid)) return JT_ERR_ARG;
+  JtFactors no_grads = {};  // g_factors == NULL: gradients w.r.t. the rays only (the walk writes no factor gradient)
+  const JtFactors& GF = g_factors ? *g_factors : no_grads;
   float* gfeat = reinterpret_cast<float*>(workspace);
   uint16_t* vlist = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + o_vlist);
   int* nvalid = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + o_nvalid);
@@ -664,15 +666,15 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
   const int blocks = (int)((items + 15) / 16);
   if (D.Cd <= 16) {
     if (D.Cd == 16)
-      hipLaunchKernelGGL(k_march_bwd_walk<16>, dim3(blocks), dim3(256), 0, st, D, *g_factors, rays_o, rays_d, jitter,
+      hipLaunchKernelGGL(k_march_bwd_walk<16>, dim3(blocks), dim3(256), 0, st, D, GF, rays_o, rays_d, jitter,
                          zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d);
     else if (D.Cd == 8)
-      hipLaunchKernelGGL(k_march_bwd_walk<8>, dim3(blocks), dim3(256), 0, st, D, *g_factors, rays_o, rays_d, jitter,
+      hipLaunchKernelGGL(k_march_bwd_walk<8>, dim3(blocks), dim3(256), 0, st, D, GF, rays_o, rays_d, jitter,
                          zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d);
     else
       return JT_ERR_UNSUPPORTED;
   } else if (D.Cd == 32) {
-    hipLaunchKernelGGL(k_march_bwd_walk<32>, dim3(blocks), dim3(256), 0, st, D, *g_factors, rays_o, rays_d, jitter,
+    hipLaunchKernelGGL(k_march_bwd_walk<32>, dim3(blocks), dim3(256), 0, st, D, GF, rays_o, rays_d, jitter,
                        zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d);
   } else {
     return JT_ERR_UNSUPPORTED;

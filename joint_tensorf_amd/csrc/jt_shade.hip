@@ -1033,6 +1033,7 @@ static int shade_kind(const JtScene* s) {
 // on an auxiliary stream, concurrently with whatever the caller enqueues next on the main stream (the
 // density backward: atomics / VALU bound, while the GEMMs are MFMA bound).
 static const int kChunkEntries = 1 << 20;
+static const int kNoGradRecords = 1 << 8;  // internal flag of launch_shade_bwd
 static const int kWgradBlocks = 512;
 
 template <class C>
@@ -1134,7 +1135,8 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   const size_t cstride = W::slab_floats_per_chunk();
   const int nb = kWgradBlocks;
   const char* abl_env = getenv("JT_ABLATE");  // profiling only: 1 = no scatter, 2 = no records, 4 = no wgrad
-  const int ablate = (abl_env ? atoi(abl_env) : 0) | ((flags & JT_SHADE_SKIP_WGRAD) ? 4 : 0);
+  const int ablate = (abl_env ? atoi(abl_env) : 0) | ((flags & JT_SHADE_SKIP_WGRAD) ? 4 : 0) |
+                     ((flags & kNoGradRecords) ? 2 : 0);
   constexpr int NT3 = W::NT3, NT1 = W::NT1, NTB = W::NTB;
   constexpr int XF1 = (C::KIND == JT_MLP_FEA) ? 1 : 2;
   // ---- per-sample backward of every chunk on the main stream ----
@@ -1210,14 +1212,20 @@ extern "C" int jt_shade_backward(const JtScene* scene, const JtFactors* factors,
   Dev D;
   int rc = make_dev(scene, factors, &D);
   if (rc) return rc;
-  if (!factors || !mlp || !g_factors || !g_mlp || !rays_o || !rays_d || !tmin || !shade_offset || !entry_ray ||
+  if (!factors || !mlp || !rays_o || !rays_d || !tmin || !shade_offset || !entry_ray ||
       !entry_smp || !viewdirs || !rgb_s || !g_rgb_s || !g_xyz_app)
     return JT_ERR_ARG;
   if (!mlp->basis || !mlp->w1 || !mlp->b1 || !mlp->w2 || !mlp->b2 || !mlp->w3 || !mlp->b3) return JT_ERR_ARG;
-  if (!g_mlp->basis || !g_mlp->w1 || !g_mlp->b1 || !g_mlp->w2 || !g_mlp->b2 || !g_mlp->w3 || !g_mlp->b3)
+  // g_factors == NULL / g_mlp == NULL: that group of gradients is not wanted (pose-only backward)
+  if (g_mlp && (!g_mlp->basis || !g_mlp->w1 || !g_mlp->b1 || !g_mlp->w2 || !g_mlp->b2 || !g_mlp->w3 || !g_mlp->b3))
     return JT_ERR_ARG;
   for (int a = 0; a < 3; ++a)
-    if (!g_factors->app_plane[a] || !g_factors->app_line[a]) return JT_ERR_ARG;
+    if (g_factors && (!g_factors->app_plane[a] || !g_factors->app_line[a])) return JT_ERR_ARG;
+  JtFactors no_fac = {};
+  JtMlp no_mlp = {};
+  if (!g_mlp) flags |= JT_SHADE_SKIP_WGRAD | kNoGradRecords;  // nobody will read the gradient records
+  const JtFactors& GFr = g_factors ? *g_factors : no_fac;
+  const JtMlp& GMr = g_mlp ? *g_mlp : no_mlp;
   if (D.ndc && !zvals) return JT_ERR_ARG;
   const int kind = shade_kind(scene);
   if (kind < 0) return JT_ERR_UNSUPPORTED;
@@ -1227,10 +1235,10 @@ extern "C" int jt_shade_backward(const JtScene* scene, const JtFactors* factors,
   PeMask pm = pe_masks(scene->fea_pe_progress, scene->view_pe_progress, scene->fea_pe, scene->view_pe);
   hipStream_t st = (hipStream_t)stream;
   if (kind == 0)
-    return launch_shade_bwd<CfgBlender>(D, M, pm, *g_factors, *g_mlp, shade_offset, n_rays, rgb_s, g_rgb_s, g_xyz_app,
+    return launch_shade_bwd<CfgBlender>(D, M, pm, GFr, GMr, shade_offset, n_rays, rgb_s, g_rgb_s, g_xyz_app,
                                         n_entries_max, (float*)workspace, workspace_bytes, flags, st, (hipStream_t)aux_stream,
                                         (hipEvent_t)ev_fork, (hipEvent_t)ev_join);
-  return launch_shade_bwd<CfgLlff>(D, M, pm, *g_factors, *g_mlp, shade_offset, n_rays, rgb_s, g_rgb_s, g_xyz_app,
+  return launch_shade_bwd<CfgLlff>(D, M, pm, GFr, GMr, shade_offset, n_rays, rgb_s, g_rgb_s, g_xyz_app,
                                    n_entries_max,
                                    (float*)workspace, workspace_bytes, flags, st, (hipStream_t)aux_stream,
                                    (hipEvent_t)ev_fork, (hipEvent_t)ev_join);

@@ -324,11 +324,12 @@ struct RecWalker {
       tv.v[k] = ldb(L, rl.y + ck[k]);
     }
   }
-  // out-of-range texels never receive anything (their weights are zero), so a clamped address is fine
+  // out-of-range texels never receive anything (their weights are zero), so a clamped address is fine.
+  // base == nullptr: the caller does not want factor gradients (pose-only backward), nothing is written.
   __device__ inline void flush(float* base, unsigned off, float* a) {
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-      if (live[k] && JT_FLUSH_COND(a[k]))
+      if (base != nullptr && live[k] && JT_FLUSH_COND(a[k]))
         atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (off + ck[k])), a[k]);
       a[k] = 0.f;
     }

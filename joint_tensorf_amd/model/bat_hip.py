@@ -406,3 +406,120 @@ class Model(torch.nn.Module):
     def after_iteration(self, opt, it):
         """the part of nerf.Model.train's loop body that follows train_iteration (model/nerf.py:258-260)."""
         self.graph.nerf.update_schedule(opt, it)
+
+    # ---- evaluation (SURVEY 8(f) N1) ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def get_all_training_poses(self, opt, pose_GT=None):
+        """model/bat.py:197-210: (optimised poses, ground-truth poses) of all training views.  `pose_GT` [N,3,4]
+        is what the reference reads from its dataset object (self.train_data.get_all_camera_poses)."""
+        g = self.graph
+        if pose_GT is None:
+            pose_GT = self.train_data.get_all_camera_poses(opt)
+        pose_GT = pose_GT.to(opt.device, dtype=torch.float32)
+        if opt.data.dataset == "blender":
+            noise = g.pose_noise if opt.camera.noise else None
+            pose = ops.train_pose(g.se3_refine.weight.detach(), noise, pose_GT)
+        else:
+            pose = ops.train_pose(g.se3_refine.weight.detach(), None, g.pose_eye)
+        return pose, pose_GT
+
+    @staticmethod
+    def _camera_centers(pose):
+        R, t = pose[..., :3], pose[..., 3:]
+        return (-R.transpose(-1, -2) @ t)[..., 0]
+
+    @staticmethod
+    def procrustes_analysis(X0, X1):
+        """camera.py:349-366.  The 3x3 SVD runs in double on the host with the routine the reference calls."""
+        t0, t1 = X0.mean(dim=0, keepdim=True), X1.mean(dim=0, keepdim=True)
+        X0c, X1c = X0 - t0, X1 - t1
+        s0 = (X0c ** 2).sum(dim=-1).mean().sqrt()
+        s1 = (X1c ** 2).sum(dim=-1).mean().sqrt()
+        U, S, V = torch.svd(((X0c / s0).t() @ (X1c / s1)).double().cpu(), some=True)
+        R = (U @ V.t()).float()
+        if R.det() < 0:
+            R[2] *= -1
+        return Opt(t0=t0[0], t1=t1[0], s0=s0, s1=s1, R=R.to(X0.device))
+
+    @torch.no_grad()
+    def prealign_cameras(self, opt, pose, pose_GT):
+        """model/bat.py:212-228."""
+        center_pred, center_GT = self._camera_centers(pose), self._camera_centers(pose_GT)
+        try:
+            sim3 = self.procrustes_analysis(center_GT, center_pred)
+        except Exception:
+            print("warning: SVD did not converge...")
+            sim3 = Opt(t0=0, t1=0, s0=1, s1=1, R=torch.eye(3, device=opt.device, dtype=torch.float32))
+        center_aligned = (center_pred - sim3.t1) / sim3.s1 @ sim3.R.t() * sim3.s0 + sim3.t0
+        R_aligned = pose[..., :3] @ sim3.R.t()
+        t_aligned = (-R_aligned @ center_aligned[..., None])[..., 0]
+        return torch.cat([R_aligned, t_aligned[..., None]], -1), sim3
+
+    @torch.no_grad()
+    def evaluate_camera_alignment(self, opt, pose_aligned, pose_GT, eps=1e-7):
+        """model/bat.py:230-238 (+ camera.rotation_distance, camera.py:342-347)."""
+        Rd = pose_aligned[..., :3] @ pose_GT[..., :3].transpose(-2, -1)
+        trace = Rd[..., 0, 0] + Rd[..., 1, 1] + Rd[..., 2, 2]
+        R_error = ((trace - 1) / 2).clamp(-1 + eps, 1 - eps).acos()
+        t_error = (pose_aligned[..., 3] - pose_GT[..., 3]).norm(dim=-1)
+        return Opt(R=R_error, t=t_error)
+
+    @torch.enable_grad()
+    def evaluate_test_time_photometric_optim(self, opt, var):
+        """model/bat.py:265-292: a fresh se3 [1,6] absorbs the remaining pose error of one held-out view.
+        The scene is frozen for the duration, so the renderer's backward takes its pose-only route (no factor
+        or weight gradients are formed; the reference forms and discards them)."""
+        g = self.graph
+        var.se3_refine_test = torch.nn.Parameter(torch.zeros(1, 6, device=opt.device))
+        kw = dict(fused=True) if str(opt.device).startswith("cuda") else {}
+        optim_pose = torch.optim.Adam([dict(params=[var.se3_refine_test], lr=opt.optim.lr_pose)], **kw)
+        gamma = (opt.optim.lr_pose_test_end / opt.optim.lr_pose_test) ** (1.0 / opt.optim.test_iter)
+        sched_pose = torch.optim.lr_scheduler.ExponentialLR(optim_pose, gamma=gamma)
+        frozen = [p for p in g.parameters() if p.requires_grad]
+        for p in frozen:
+            p.requires_grad_(False)
+        eye = torch.eye(3, 4, device=opt.device)
+        try:
+            for it in range(opt.optim.test_iter):
+                g.nerf.test_time_progress_host = it / opt.optim.test_iter
+                g.nerf.test_time_progress.data.fill_(it / opt.optim.test_iter)
+                optim_pose.zero_grad()
+                var.pose_refine_test = ops.train_pose(var.se3_refine_test, None, eye)  # se3_to_SE3 (camera.py:81-99)
+                var = g.forward(opt, var, mode="test-optim")
+                loss = g.compute_loss(opt, var, mode="test-optim")
+                loss = self.summarize_loss(opt, var, loss)
+                loss.all.backward()
+                optim_pose.step()
+                sched_pose.step()
+        finally:
+            for p in frozen:
+                p.requires_grad_(True)
+        # NOTE (reproduced): var.pose_refine_test is refreshed at the top of an iteration only, so the eval render
+        # that follows sees the refinement from before the last Adam step (model/bat.py:284, model/nerf.py:539)
+        return var
+
+    @torch.no_grad()
+    def evaluate_view(self, opt, var, eps=1e-10):
+        """The per-view body of nerf.Model.evaluate_full (model/nerf.py:534-548): optional test-time pose
+        optimisation, the sliced full-image render and PSNR.  SSIM / LPIPS need packages outside this build."""
+        g = self.graph
+        g.eval()
+        if opt.model in ("barf", "bat", "bat_hip") and opt.optim.test_photo:
+            var = self.evaluate_test_time_photometric_optim(opt, var)
+        var = g.forward(opt, var, mode="eval")
+        invdepth = var.depth if opt.camera.ndc else 1 / (var.depth / var.opacity + eps)
+        rgb_map = var.rgb.view(-1, opt.H, opt.W, 3).permute(0, 3, 1, 2)
+        invdepth_map = invdepth.view(-1, opt.H, opt.W, 1).permute(0, 3, 1, 2)
+        psnr = -10 * g.MSE_loss(rgb_map, var.image).log10().item()
+        return Opt(psnr=psnr, rgb_map=rgb_map, invdepth_map=invdepth_map, var=var)
+
+    def evaluate_full(self, opt, test_views, pose_GT=None):
+        """model/bat.py:241-263 + model/nerf.py:525-572 on an iterable of per-view batches (idx, pose, intr,
+        intr_inv, image): camera alignment errors, then PSNR per held-out view."""
+        self.graph.eval()
+        pose, pose_GT = self.get_all_training_poses(opt, pose_GT)
+        pose_aligned, self.graph.sim3 = self.prealign_cameras(opt, pose, pose_GT)
+        error = self.evaluate_camera_alignment(opt, pose_aligned, pose_GT)
+        res = [self.evaluate_view(opt, Opt(dict(v))) for v in test_views]
+        return Opt(R_error=error.R, t_error=error.t, views=res,
+                   psnr=float(np.mean([r.psnr for r in res])) if res else float("nan"))

@@ -296,14 +296,22 @@ class RenderRays(torch.autograd.Function):
         g_rgb_s = torch.empty(cap_alloc, 3, **f32)
         check(lib.jt_composite_backward(scene, R, ptr(offset), ptr(eray), ptr(esmp), ptr(weight), ptr(cmask),
                                         ptr(g_rgb), ptr(g_rgb_s), cap, st), "jt_composite_backward")
-        # gradient buffers (channel-last storage, zero-initialised: the kernels accumulate with atomics)
-        gdp = [torch.zeros_like(t) for t in sdp]
-        gdl = [torch.zeros_like(t) for t in sdl]
-        gap = [torch.zeros_like(t) for t in sap]
-        gal = [torch.zeros_like(t) for t in sal]
-        gfac = _factors_struct(gdp, gdl, gap, gal)
+        # which groups of gradients autograd wants (test-time pose optimisation needs the rays' only)
+        nig = ctx.needs_input_grad
+        want_fac = any(nig[5:17])
+        want_mlp = any(nig[17:24])
+        if want_fac:
+            # gradient buffers (channel-last storage, zero-initialised: the kernels accumulate with atomics)
+            gdp = [torch.zeros_like(t) for t in sdp]
+            gdl = [torch.zeros_like(t) for t in sdl]
+            gap = [torch.zeros_like(t) for t in sap]
+            gal = [torch.zeros_like(t) for t in sal]
+            gfac = _factors_struct(gdp, gdl, gap, gal)
+        else:
+            gfac = None
         g_xyz = torch.empty(cap_alloc, 3, **f32)
         join = None
+        g_mlp = [None] * 7
         if cfg.shade_impl == "torch":
             g_mlp = [torch.zeros_like(t) for t in mlp_t]
             if n > 0:
@@ -316,13 +324,18 @@ class RenderRays(torch.autograd.Function):
                 g_mlp = list(grads[1:])
             else:
                 g_prod = torch.zeros(1, 3 * cfg.n_comp_app, **f32)
+            gfac_app = gfac if gfac is not None else _factors_struct(
+                None, None, [torch.zeros_like(t) for t in sap], [torch.zeros_like(t) for t in sal])
             check(lib.jt_app_gather_backward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
-                                             ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(g_prod), gfac,
+                                             ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(g_prod), gfac_app,
                                              ptr(g_xyz), cap, st), "jt_app_gather_backward")
         else:
-            g_mlp = [torch.zeros_like(t) for t in mlp_t]
             mlp = _mlp_struct(*mlp_t)
-            gm = _mlp_struct(*g_mlp)
+            if want_mlp:
+                g_mlp = [torch.zeros_like(t) for t in mlp_t]
+                gm = _mlp_struct(*g_mlp)
+            else:
+                gm = None
             nbytes = lib.jt_shade_workspace_bytes(scene, cap)
             ws = _workspace(dev, "shade", nbytes)
             if _workspace_owner(dev, "shade") != ctx.ws_ticket:
@@ -333,7 +346,7 @@ class RenderRays(torch.autograd.Function):
                                            ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir),
                                            ptr(torch.empty_like(rgb_s)), cap, ptr(ws), nbytes, st),
                       "jt_shade_forward")
-            if USE_AUX_STREAM:
+            if USE_AUX_STREAM and want_mlp:
                 aux, ev_fork, ev_join = _aux_stream(dev)
                 # the weight-gradient GEMMs read mlp_t / ws and write g_mlp on the auxiliary stream
                 for t in list(mlp_t) + g_mlp + [offset]:
@@ -357,7 +370,7 @@ class RenderRays(torch.autograd.Function):
                                     ptr(mws), mws_bytes, st), "jt_march_backward")
         if join is not None:
             torch.cuda.current_stream().wait_event(join)  # weight gradients done before anyone reads them
-        g_factors = [factor_logical(t) for t in gdp + gdl + gap + gal]
+        g_factors = [factor_logical(t) for t in gdp + gdl + gap + gal] if want_fac else [None] * 12
         out = [None, g_o, g_d, None, None] + g_factors + list(g_mlp)
         return tuple(out)
 

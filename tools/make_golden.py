@@ -391,6 +391,22 @@ def eval_case(bat, camera, opt, graph, var, out_path, test_iter=4, seed=21):
     pose_aligned, sim3 = bat.Model.prealign_cameras(me, opt, pose, pose_GT)
     err = bat.Model.evaluate_camera_alignment(me, opt, pose_aligned, pose_GT)
     graph.sim3 = sim3
+    # The three fixture cameras are coplanar once centred, so the rotation above is decided by round-off in its
+    # null direction: fine as an INPUT of the test-time optimisation below, useless as a known answer.  The
+    # known answer for the alignment itself uses seven cameras at different heights.
+    ga = torch.Generator().manual_seed(seed + 7)
+    pgt7 = torch.tensor(np.stack([look_at_pose(4.0 * np.array([np.cos(0.9 * i) * np.cos(0.25 * i - 0.6),
+                                                                np.sin(0.9 * i) * np.cos(0.25 * i - 0.6),
+                                                                np.sin(0.25 * i - 0.6)])) for i in range(7)]))
+    with torch.no_grad():
+        p7 = camera.pose.compose([camera.lie.se3_to_SE3(torch.randn(7, 6, generator=ga) * 0.15), pgt7])
+        # a global similarity on top, as joint optimisation leaves the scene in its own gauge
+        gR = camera.lie.se3_to_SE3(torch.tensor([[0.3, -0.2, 0.5, 0.0, 0.0, 0.0]]))[0, :, :3]
+        c7 = camera.cam2world(torch.zeros(1, 1, 3), p7)[:, 0] * 1.3 @ gR.t() + torch.tensor([0.2, -0.1, 0.3])
+        R7 = p7[..., :3] @ gR.t()
+        p7 = camera.pose(R=R7, t=(-R7 @ c7[..., None])[..., 0])
+    aligned7, sim7 = bat.Model.prealign_cameras(me, opt, p7, pgt7)
+    err7 = bat.Model.evaluate_camera_alignment(me, opt, aligned7, pgt7)
     # one held-out view
     g = torch.Generator().manual_seed(seed + 1)
     eye = 4.0 * np.array([np.cos(1.1) * np.cos(0.6), np.sin(1.1) * np.cos(0.6), np.sin(0.6)])
@@ -445,6 +461,16 @@ def eval_case(bat, camera, opt, graph, var, out_path, test_iter=4, seed=21):
     out["sim3.R"] = sim3.R.numpy()
     out["err.R"] = err.R.numpy()
     out["err.t"] = err.t.numpy()
+    out["align.pose"] = p7.numpy()
+    out["align.pose_gt"] = pgt7.numpy()
+    out["align.pose_aligned"] = aligned7.numpy()
+    out["align.sim3.t0"] = sim7.t0.numpy()
+    out["align.sim3.t1"] = sim7.t1.numpy()
+    out["align.sim3.s0"] = np.float32(sim7.s0)
+    out["align.sim3.s1"] = np.float32(sim7.s1)
+    out["align.sim3.R"] = sim7.R.numpy()
+    out["align.err.R"] = err7.R.numpy()
+    out["align.err.t"] = err7.t.numpy()
     out["trace.se3"] = torch.stack(trace_se3).numpy()      # value BEFORE the step of iteration k
     out["trace.loss_render"] = np.array(trace_loss, dtype=np.float32)
     out["out.se3_refine_test"] = v.se3_refine_test.detach().numpy()
