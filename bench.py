@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--stage", type=int, default=-1,
                     help="grid stage of the yaml's upsampling schedule (0 = initial grid, -1 = final grid)")
     ap.add_argument("--n-rays", type=int, default=0, help="override opt.nerf.n_rays (0 = yaml schedule value)")
+    ap.add_argument("--n-voxel-final", type=int, default=0,
+                    help="override train_schedule.n_voxel_final (e.g. 27000000 = the 300^3 of the parent yaml "
+                         "options/tensorf_blender_VM.yaml that BASELINE.json's configs[1] text quotes)")
     ap.add_argument("--shade-impl", default="mfma", choices=["mfma", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -206,6 +209,8 @@ def main():
     torch.manual_seed(0)
     np.random.seed(1234)  # host draws (blur scale) identical on every rank
     opt = make_options(args.config, device=dev, shade_impl=args.shade_impl)
+    if args.n_voxel_final:
+        opt.train_schedule.n_voxel_final = args.n_voxel_final
     stage, it0 = stage_setup(opt, args.stage)
     if it0 < opt.train_schedule.change_n_rays_after_n_iters:
         opt.nerf.n_rays = opt.train_schedule.n_rays_init

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Throughput of the evaluation path on one GPU (BASELINE.json configs[4] shape): full-image sliced render of one
+view at the final grid, and test-time photometric pose optimisation steps (pose-only backward).
+usage: python tools/eval_bench.py [--size 800] [--samples 1024] [--test-iters 50]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=800)
+    ap.add_argument("--samples", type=int, default=1024)
+    ap.add_argument("--test-iters", type=int, default=50)
+    ap.add_argument("--reps", type=int, default=3)
+    args = ap.parse_args()
+    sys.argv = [sys.argv[0]]
+    import bench
+    from joint_tensorf_amd.options import make_options, Opt
+    from joint_tensorf_amd.synthetic import make_views
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    opt = make_options("bat_blender_VM", device=dev, data=dict(image_size=[args.size, args.size]),
+                       nerf=dict(sample_intvs=args.samples), optim=dict(test_iter=args.test_iters))
+    stage, it0 = bench.stage_setup(opt, -1)
+    opt.nerf.n_rays = opt.train_schedule.n_rays_rest
+    model = bench.build_model(opt, it0, int(opt.data.num_views))
+    views = make_views(opt, int(opt.data.num_views), seed=0, device=dev)
+    pose, pose_GT = model.get_all_training_poses(opt, views["pose"])
+    _, model.graph.sim3 = model.prealign_cameras(opt, pose, pose_GT)
+    tv = make_views(opt, 1, seed=5, device=dev)
+    var = Opt(dict(tv))
+    var.idx = torch.arange(1, device=dev)
+    g = model.graph
+    g.eval()
+    old_photo = opt.optim.test_photo
+    opt.optim.test_photo = False
+    with torch.no_grad():
+        g.forward(opt, Opt(dict(var)), mode="eval")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            out = g.forward(opt, Opt(dict(var)), mode="eval")
+        torch.cuda.synchronize()
+        t_render = (time.perf_counter() - t0) / args.reps
+    opt.optim.test_photo = old_photo
+    torch.cuda.synchronize()
+    model.evaluate_test_time_photometric_optim(opt, Opt(dict(var)))  # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    v = model.evaluate_test_time_photometric_optim(opt, Opt(dict(var)))
+    torch.cuda.synchronize()
+    t_opt = (time.perf_counter() - t0) / args.test_iters
+    rays = args.size * args.size
+    print(json.dumps({
+        "eval_render": {"image": [args.size, args.size], "samples_per_ray": int(g.nerf.n_samples),
+                        "grid": g.nerf.tensorf.gridSize.tolist(), "ms_per_image": t_render * 1e3,
+                        "rays_per_s": rays / t_render, "Msamples_per_s": rays * g.nerf.n_samples / t_render / 1e6},
+        "test_time_optim": {"rays_per_iter": int(v.rgb.shape[1]), "ms_per_iter": t_opt * 1e3,
+                            "iters": args.test_iters, "backward": "pose-only (no factor / weight gradients)"}}))
+
+
+if __name__ == "__main__":
+    main()
