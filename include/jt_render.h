@@ -255,14 +255,16 @@ int jt_render_loss_backward(const float* rgb, const float* image, const int64_t*
 /* All regularisers of one scene in one call (replaces the loop bodies of model/tensorf.py:127-130):
  *   out3 = { density_L1(), TV_loss_density(TVLoss()), TV_loss_app(TVLoss()) }   (tensoRF.py:212-228).
  * plane_hw_line[9] = {H_i, W_i, L_i} for i = 0..2; scratch36: 36 floats of device scratch.
- * backward: g3 = dL/d out3 on the device; ADDS the gradients into g_factors (density planes + lines always,
- * appearance planes when with_tv_app != 0; with_tv_density is informational -- its coefficient is on the
- * device and zero when the term is unused). */
+ * with_tv_density / with_tv_app == 0: that TV term has weight zero in the run; it is not evaluated and out3
+ * carries 0 for it (the L1 term is always evaluated).
+ * backward: g3 = dL/d out3 on the device; writes (accumulate == 0) or adds (accumulate != 0) the gradients of
+ * the density planes + lines, and of the appearance planes when with_tv_app != 0, into g_factors. */
 int jt_reg_losses_forward(const JtFactors* factors, const int32_t* plane_hw_line, int n_comp_density,
-                          int n_comp_app, float* scratch36, float* out3, void* stream);
+                          int n_comp_app, int with_tv_density, int with_tv_app, float* scratch36, float* out3,
+                          void* stream);
 int jt_reg_losses_backward(const JtFactors* factors, const int32_t* plane_hw_line, int n_comp_density,
                            int n_comp_app, const float* g3, int with_tv_density, int with_tv_app,
-                           const JtFactors* g_factors, float* scratch36, void* stream);
+                           const JtFactors* g_factors, int accumulate, float* scratch36, void* stream);
 
 #ifdef __cplusplus
 }

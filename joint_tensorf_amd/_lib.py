@@ -67,8 +67,8 @@ SIGNATURES = {
     "jt_shade_workspace_bytes": (ctypes.c_size_t, [SP, I]),
     "jt_render_loss_forward": (I, [P, P, P, P, I, I, I, F, F, P, P, P]),
     "jt_render_loss_backward": (I, [P, P, P, P, I, I, I, F, F, P, P, P, P]),
-    "jt_reg_losses_forward": (I, [FP, P, I, I, P, P, P]),
-    "jt_reg_losses_backward": (I, [FP, P, I, I, P, I, I, FP, P, P]),
+    "jt_reg_losses_forward": (I, [FP, P, I, I, I, I, P, P, P]),
+    "jt_reg_losses_backward": (I, [FP, P, I, I, P, I, I, FP, I, P, P]),
     "jt_factor_reg_forward": (I, [P, I, I, I, P, P]),
     "jt_factor_reg_backward": (I, [P, I, I, I, P, P, I, P]),
     "jt_shade_forward": (I, [SP, FP, MP, P, P, P, P, P, P, I, P, P, P, P, I, P, ctypes.c_size_t, P]),

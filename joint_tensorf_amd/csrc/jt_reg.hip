@@ -10,6 +10,7 @@ namespace jt {
 __device__ inline float4 ld4z(const float* p, bool ok) { return ok ? ld4(p) : make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // out[0] += sum |x| ; out[1] += sum (down - x)^2 ; out[2] += sum (right - x)^2
+template <bool TV>
 __global__ __launch_bounds__(256) void k_factor_reg_fwd(const float* __restrict__ x, int H, int W, int C,
                                                         float* __restrict__ out) {
   __shared__ float red[4][3];
@@ -23,12 +24,12 @@ __global__ __launch_bounds__(256) void k_factor_reg_fwd(const float* __restrict_
     const float* p = x + tex * C + c4 * 4;
     const float4 v = ld4(p);
     s0 += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
-    if (yy + 1 < H) {
+    if (TV && yy + 1 < H) {
       const float4 d = ld4(p + (long)W * C);
       const float a = d.x - v.x, b = d.y - v.y, c = d.z - v.z, e = d.w - v.w;
       s1 += a * a + b * b + c * c + e * e;
     }
-    if (xx + 1 < W) {
+    if (TV && xx + 1 < W) {
       const float4 r = ld4(p + C);
       const float a = r.x - v.x, b = r.y - v.y, c = r.z - v.z, e = r.w - v.w;
       s2 += a * a + b * b + c * c + e * e;
@@ -99,7 +100,7 @@ extern "C" int jt_factor_reg_forward(const float* x, int H, int W, int C, float*
   if (C % 4) return JT_ERR_UNSUPPORTED;
   long total = (long)H * W * (C / 4);
   int blocks = (int)min((total + 255) / 256, 1024L);
-  hipLaunchKernelGGL(k_factor_reg_fwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, H, W, C, out3);
+  hipLaunchKernelGGL(k_factor_reg_fwd<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, H, W, C, out3);
   JT_LAUNCH_CHECK();
   return JT_OK;
 }
@@ -189,7 +190,8 @@ static int reg_set(const JtFactors* f, const JtFactors* g, const int32_t* hw, in
 }
 
 extern "C" int jt_reg_losses_forward(const JtFactors* factors, const int32_t* plane_hw_line, int n_comp_density,
-                                     int n_comp_app, float* scratch36, float* out3, void* stream) {
+                                     int n_comp_app, int with_tv_density, int with_tv_app, float* scratch36,
+                                     float* out3, void* stream) {
   RegSet S;
   int rc = reg_set(factors, nullptr, plane_hw_line, n_comp_density, n_comp_app, &S);
   if (rc) return rc;
@@ -197,10 +199,16 @@ extern "C" int jt_reg_losses_forward(const JtFactors* factors, const int32_t* pl
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(scratch36, 0, 36 * sizeof(float), st) != hipSuccess) return JT_ERR_ARG;
   for (int i = 0; i < 9; ++i) {  // app lines (9-11) enter no regulariser
+    // a TV term whose weight is zero is not evaluated (it reads every texel three times): out3 carries 0 for it
+    const bool tv = (i < 3 && with_tv_density) || (i >= 6 && with_tv_app);
+    if (i >= 6 && !tv) continue;  // appearance planes only enter TV_color
     const RegTensor& t = S.t[i];
     long total = (long)t.H * t.W * (t.C / 4);
-    int blocks = (int)min((total + 255) / 256, 1024L);
-    hipLaunchKernelGGL(k_factor_reg_fwd, dim3(blocks), dim3(256), 0, st, t.x, t.H, t.W, t.C, scratch36 + i * 3);
+    int blocks = (int)min((total + 255) / 256, 2048L);
+    if (tv)
+      hipLaunchKernelGGL(k_factor_reg_fwd<true>, dim3(blocks), dim3(256), 0, st, t.x, t.H, t.W, t.C, scratch36 + i * 3);
+    else
+      hipLaunchKernelGGL(k_factor_reg_fwd<false>, dim3(blocks), dim3(256), 0, st, t.x, t.H, t.W, t.C, scratch36 + i * 3);
     JT_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(k_reg_combine, dim3(1), dim3(64), 0, st, (const float*)scratch36, S, out3);
@@ -210,7 +218,7 @@ extern "C" int jt_reg_losses_forward(const JtFactors* factors, const int32_t* pl
 
 extern "C" int jt_reg_losses_backward(const JtFactors* factors, const int32_t* plane_hw_line, int n_comp_density,
                                       int n_comp_app, const float* g3, int with_tv_density, int with_tv_app,
-                                      const JtFactors* g_factors, float* scratch36, void* stream) {
+                                      const JtFactors* g_factors, int accumulate, float* scratch36, void* stream) {
   RegSet S;
   int rc = reg_set(factors, g_factors, plane_hw_line, n_comp_density, n_comp_app, &S);
   if (rc) return rc;
@@ -228,7 +236,7 @@ extern "C" int jt_reg_losses_backward(const JtFactors* factors, const int32_t* p
     long total = (long)t.H * t.W * (t.C / 4);
     int blocks = (int)min((total + 255) / 256, 2048L);
     hipLaunchKernelGGL(k_factor_reg_bwd, dim3(blocks), dim3(256), 0, st, t.x, t.H, t.W, t.C,
-                       (const float*)(scratch36 + i * 3), t.g, 1);
+                       (const float*)(scratch36 + i * 3), t.g, accumulate ? 1 : 0);
     JT_LAUNCH_CHECK();
   }
   return JT_OK;

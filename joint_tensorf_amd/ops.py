@@ -529,8 +529,8 @@ class RegLosses(torch.autograd.Function):
         scratch = torch.empty(36, device=dev, dtype=torch.float32)
         out = torch.empty(3, device=dev, dtype=torch.float32)
         Cd, Ca = st_[0][0].shape[2], st_[2][0].shape[2]
-        check(lib.jt_reg_losses_forward(fac, hw_arr, Cd, Ca, ptr(scratch), ptr(out), _stream()),
-              "jt_reg_losses_forward")
+        check(lib.jt_reg_losses_forward(fac, hw_arr, Cd, Ca, int(bool(with_tv_density)), int(bool(with_tv_app)),
+                                        ptr(scratch), ptr(out), _stream()), "jt_reg_losses_forward")
         ctx.saved = (st_, hw, Cd, Ca, bool(with_tv_density), bool(with_tv_app))
         return out
 
@@ -540,14 +540,15 @@ class RegLosses(torch.autograd.Function):
         dev = st_[0][0].device
         hw_arr = (ctypes.c_int32 * 9)(*hw)
         fac = _factors_struct(*st_)
-        gd = [torch.zeros_like(t) for t in st_[0]]
-        gl = [torch.zeros_like(t) for t in st_[1]]
-        ga = [torch.zeros_like(t) for t in st_[2]] if wa else [None] * 3
+        # every element is written (accumulate = 0): no zero fill of the 31 MB / 123 MB buffers
+        gd = [torch.empty_like(t) for t in st_[0]]
+        gl = [torch.empty_like(t) for t in st_[1]]
+        ga = [torch.empty_like(t) for t in st_[2]] if wa else [None] * 3
         gfac = _factors_struct(gd, gl, ga if wa else st_[2], st_[3])  # unused slots just need a non-null pointer
         scratch = torch.empty(36, device=dev, dtype=torch.float32)
         g3c = g3.contiguous().float()
-        check(lib.jt_reg_losses_backward(fac, hw_arr, Cd, Ca, ptr(g3c), int(wd), int(wa), gfac, ptr(scratch), _stream()),
-              "jt_reg_losses_backward")
+        check(lib.jt_reg_losses_backward(fac, hw_arr, Cd, Ca, ptr(g3c), int(wd), int(wa), gfac, 0, ptr(scratch),
+                                         _stream()), "jt_reg_losses_backward")
         grads = [factor_logical(t) for t in gd] + [factor_logical(t) for t in gl] + \
                 [factor_logical(t) if t is not None else None for t in ga] + [None] * 3
         return (None, None) + tuple(grads)

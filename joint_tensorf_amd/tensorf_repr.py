@@ -199,15 +199,17 @@ class BAT_VMSplit(torch.nn.Module):
     # The three regularisers are evaluated together by one ABI call (ops.reg_losses -> jt_reg_losses_*): one
     # pass over each factor, and one autograd node instead of ~150 tiny elementwise / reduce launches.  The
     # result is cached per forward call so that density_L1 / TV_loss_density / TV_loss_app share it.
-    # `reg_with_tv` = (density, app): whether the TV terms will receive a gradient (their loss weight is
-    # non-zero); the values are computed either way.
+    # `reg_with_tv` = (density, app): whether the TV terms are wanted.  Graph.compute_loss clears a flag when the
+    # term's loss weight is zero: the term is then not evaluated (a TV pass reads every texel three times) and
+    # reads 0 -- the reference evaluates it for its log line only.
     reg_with_tv = (True, True)
 
     def _reg(self):
         if not self.density_plane[0].is_cuda:
             raise RuntimeError("joint_tensorf_amd computes regularisers on the GPU only")
         cache = self.__dict__.setdefault("_reg_cache", {})
-        key = (tuple(p._version for p in list(self.density_plane) + list(self.app_plane)), torch.is_grad_enabled())
+        key = (tuple(p._version for p in list(self.density_plane) + list(self.app_plane)), torch.is_grad_enabled(),
+               tuple(self.reg_with_tv))
         if cache.get("key") != key:
             cache["key"] = key
             cache["val"] = ops.reg_losses(list(self.density_plane), list(self.density_line), list(self.app_plane),
