@@ -70,6 +70,20 @@ def _aux_stream(dev):
     return _AUX[key]
 
 
+def _zeros_flat(groups):
+    """Zero tensors shaped like the tensors of `groups` (a list of lists), carved out of ONE flat buffer: one fill
+    launch instead of one per tensor (19 per backward).  Offsets are rounded up to 16 bytes."""
+    flat_n, plan = 0, []
+    for grp in groups:
+        for t in grp:
+            plan.append((flat_n, t))
+            flat_n += (t.numel() + 3) // 4 * 4
+    ref = groups[0][0]
+    flat = torch.zeros(flat_n, device=ref.device, dtype=ref.dtype)
+    it = iter(plan)
+    return [[flat[o:o + t.numel()].view(t.shape) for (o, t) in (next(it) for _ in grp)] for grp in groups]
+
+
 def factor_storage(p):
     """logical [1,C,H,W] -> contiguous [H,W,C] tensor (no copy if p is stored channel-last)."""
     x = p.detach()[0].permute(1, 2, 0)
@@ -300,12 +314,13 @@ class RenderRays(torch.autograd.Function):
         nig = ctx.needs_input_grad
         want_fac = any(nig[5:17])
         want_mlp = any(nig[17:24])
+        fused_mlp_zero = want_fac and want_mlp and cfg.shade_impl != "torch"
         if want_fac:
             # gradient buffers (channel-last storage, zero-initialised: the kernels accumulate with atomics)
-            gdp = [torch.zeros_like(t) for t in sdp]
-            gdl = [torch.zeros_like(t) for t in sdl]
-            gap = [torch.zeros_like(t) for t in sap]
-            gal = [torch.zeros_like(t) for t in sal]
+            if fused_mlp_zero:
+                gdp, gdl, gap, gal, g_mlp_z = _zeros_flat([sdp, sdl, sap, sal, mlp_t])
+            else:
+                gdp, gdl, gap, gal = _zeros_flat([sdp, sdl, sap, sal])
             gfac = _factors_struct(gdp, gdl, gap, gal)
         else:
             gfac = None
@@ -332,7 +347,7 @@ class RenderRays(torch.autograd.Function):
         else:
             mlp = _mlp_struct(*mlp_t)
             if want_mlp:
-                g_mlp = [torch.zeros_like(t) for t in mlp_t]
+                g_mlp = g_mlp_z if fused_mlp_zero else [torch.zeros_like(t) for t in mlp_t]
                 gm = _mlp_struct(*g_mlp)
             else:
                 gm = None
