@@ -132,6 +132,19 @@ int jt_blur_forward(const float* in, float* out, float* tmp, int H, int W, int C
 int jt_blur_backward(const float* g_out, float* g_in, float* tmp, int H, int W, int C, const float* taps,
                      int n_taps, void* stream);
 
+/* The same for up to 12 factors at once (all VM factors of a scene: BAT_VMSplit.forward blurs every plane and
+ * line before rendering, bateRF.py:41-130): two launches per direction instead of three per factor.  For the
+ * backward `in` is g_out and `out` is g_in. */
+typedef struct JtBlurItem {
+  const float* in;
+  float* out;
+  float* tmp;        /* H*W*C floats scratch for planes, may be NULL for lines */
+  const float* taps;
+  int32_t H, W, C, n_taps;
+} JtBlurItem;
+int jt_blur_batch_forward(const JtBlurItem* items, int n_items, void* stream);
+int jt_blur_batch_backward(const JtBlurItem* items, int n_items, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Staged renderer (forward).  Replaces BatBase.forward (batBase.py:44-165) and everything it
  * calls: sample_ray / sample_ray_ndc (tensorBase.py:554-612), compute_densityfeature

@@ -41,6 +41,12 @@ class JtMlp(ctypes.Structure):
                 ("b3", ctypes.c_void_p)]
 
 
+class JtBlurItem(ctypes.Structure):
+    _fields_ = [("in_", ctypes.c_void_p), ("out", ctypes.c_void_p), ("tmp", ctypes.c_void_p),
+                ("taps", ctypes.c_void_p), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("C", ctypes.c_int32),
+                ("n_taps", ctypes.c_int32)]
+
+
 # every symbol include/jt_render.h declares (tests/test_abi.py checks header <-> this table <-> .so)
 P = ctypes.c_void_p
 I = ctypes.c_int
@@ -69,6 +75,8 @@ SIGNATURES = {
     "jt_render_loss_backward": (I, [P, P, P, P, I, I, I, F, F, P, P, P, P]),
     "jt_reg_losses_forward": (I, [FP, P, I, I, I, I, P, P, P]),
     "jt_reg_losses_backward": (I, [FP, P, I, I, P, I, I, FP, I, P, P]),
+    "jt_blur_batch_forward": (I, [P, I, P]),
+    "jt_blur_batch_backward": (I, [P, I, P]),
     "jt_factor_reg_forward": (I, [P, I, I, I, P, P]),
     "jt_factor_reg_backward": (I, [P, I, I, I, P, P, I, P]),
     "jt_shade_forward": (I, [SP, FP, MP, P, P, P, P, P, P, I, P, P, P, P, I, P, ctypes.c_size_t, P]),

@@ -13,7 +13,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import JtFactors, JtMlp, JtScene, check, lib, ptr
+from ._lib import JtBlurItem, JtFactors, JtMlp, JtScene, check, lib, ptr
 
 MAT_MODE = ((0, 1), (0, 2), (1, 2))
 VEC_MODE = (2, 1, 0)
@@ -444,46 +444,57 @@ class BlurFactors(torch.autograd.Function):
     autograd overhead, which is what bounds the early (small-grid, blur-on) stages."""
 
     @staticmethod
+    def _items(srcs, dsts, tmps, shapes, taps):
+        arr = (JtBlurItem * len(srcs))()
+        for k, (a, b, t, (H, W, C), tp) in enumerate(zip(srcs, dsts, tmps, shapes, taps)):
+            arr[k].in_, arr[k].out, arr[k].tmp, arr[k].taps = ptr(a), ptr(b), ptr(t), ptr(tp)
+            arr[k].H, arr[k].W, arr[k].C, arr[k].n_taps = H, W, C, tp.numel()
+        return arr
+
+    @staticmethod
     def forward(ctx, taps_density, taps_color, *factors):
-        st = _stream()
-        outs, meta = [], []
         td = taps_density.detach().contiguous().float()
         tc = taps_color.detach().contiguous().float()
+        srcs, outs, tmps, shapes, taps, meta = [], [], [], [], [], []
         for i, x in enumerate(factors):
             is_plane = (i % 6) < 3          # order: dP0-2, dL0-2, aP0-2, aL0-2
-            taps = td if i < 6 else tc
             xs = factor_storage(x)
             H, W, C = xs.shape
             if is_plane and W > 1:
-                H, W = W, H
-                xs = xs.reshape(H, W, C)
-            out = torch.empty_like(xs)
-            tmp = torch.empty_like(xs) if (H > 1 and W > 1) else None
-            check(lib.jt_blur_forward(ptr(xs), ptr(out), ptr(tmp), H, W, C, ptr(taps), taps.numel(), st),
-                  "jt_blur_forward")
-            outs.append(factor_logical(out))
-            meta.append((tuple(x.shape[2:]), i < 6))
-        ctx.meta = meta
+                H, W = W, H                 # the reference's reshape quirk: same memory, axes exchanged
+            srcs.append(xs)
+            outs.append(torch.empty_like(xs))
+            tmps.append(torch.empty_like(xs) if (H > 1 and W > 1) else None)
+            shapes.append((H, W, C))
+            taps.append(td if i < 6 else tc)
+            meta.append((tuple(xs.shape), i < 6))
+        check(lib.jt_blur_batch_forward(BlurFactors._items(srcs, outs, tmps, shapes, taps), len(srcs), _stream()),
+              "jt_blur_batch_forward")
+        ctx.meta = (meta, shapes)
         ctx.save_for_backward(td, tc)
-        return tuple(outs)
+        return tuple(factor_logical(o.view(sh)) for o, sh in zip(outs, shapes))
 
     @staticmethod
     def backward(ctx, *gs):
         td, tc = ctx.saved_tensors
-        st = _stream()
-        grads = []
-        for g, (in_hw, dens) in zip(gs, ctx.meta):
+        meta, shapes = ctx.meta
+        srcs, gins, tmps, shp, taps, idx = [], [], [], [], [], []
+        for i, (g, (in_shape, dens), (H, W, C)) in enumerate(zip(gs, meta, shapes)):
             if g is None:
-                grads.append(None)
                 continue
-            taps = td if dens else tc
             gsx = factor_storage(g)
-            H, W, C = gsx.shape
-            gin = torch.empty_like(gsx)
-            tmp = torch.empty_like(gsx) if (H > 1 and W > 1) else None
-            check(lib.jt_blur_backward(ptr(gsx), ptr(gin), ptr(tmp), H, W, C, ptr(taps), taps.numel(), st),
-                  "jt_blur_backward")
-            grads.append(factor_logical(gin.reshape(in_hw[0], in_hw[1], C)))
+            srcs.append(gsx)
+            gins.append(torch.empty_like(gsx))
+            tmps.append(torch.empty_like(gsx) if (H > 1 and W > 1) else None)
+            shp.append((H, W, C))
+            taps.append(td if dens else tc)
+            idx.append(i)
+        grads = [None] * len(gs)
+        if srcs:
+            check(lib.jt_blur_batch_backward(BlurFactors._items(srcs, gins, tmps, shp, taps), len(srcs), _stream()),
+                  "jt_blur_batch_backward")
+            for i, gin in zip(idx, gins):
+                grads[i] = factor_logical(gin.view(meta[i][0]))
         return (None, None) + tuple(grads)
 
 
