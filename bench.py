@@ -34,6 +34,9 @@ def parse():
     ap.add_argument("--config", default="bat_blender_VM")
     ap.add_argument("--stage", type=int, default=-1,
                     help="grid stage of the yaml's upsampling schedule (0 = initial grid, -1 = final grid)")
+    ap.add_argument("--it", type=int, default=-1,
+                    help="start iteration inside the chosen stage (default: stage start; the final stage starts "
+                         "after the blur schedule ends, use e.g. --it 9000 for the blurred part of it)")
     ap.add_argument("--n-rays", type=int, default=0, help="override opt.nerf.n_rays (0 = yaml schedule value)")
     ap.add_argument("--n-voxel-final", type=int, default=0,
                     help="override train_schedule.n_voxel_final (e.g. 27000000 = the 300^3 of the parent yaml "
@@ -94,11 +97,19 @@ def build_model(opt, it0, n_views):
     return model
 
 
+OVERLAP = os.environ.get("JT_DIST_OVERLAP", "1") != "0"
+
+
 def allreduce_grads(model, world):
     if world == 1:
         return
     from joint_tensorf_amd import dist as jdist
-    jdist.allreduce_gradients(list(model.graph.parameters()), world)
+    if OVERLAP:
+        # the renderer's backward has already reduced the scene gradients (ops.set_data_parallel); what left
+        # through the rays -- the pose refinements -- is reduced here
+        jdist.allreduce_gradients([model.graph.se3_refine.weight], world)
+    else:
+        jdist.allreduce_gradients(list(model.graph.parameters()), world)
 
 
 def cpu_baseline(opt_name, seconds_budget=24.0):
@@ -212,6 +223,8 @@ def main():
     if args.n_voxel_final:
         opt.train_schedule.n_voxel_final = args.n_voxel_final
     stage, it0 = stage_setup(opt, args.stage)
+    if args.it >= 0:
+        it0 = args.it
     if it0 < opt.train_schedule.change_n_rays_after_n_iters:
         opt.nerf.n_rays = opt.train_schedule.n_rays_init
     else:
@@ -220,6 +233,10 @@ def main():
         opt.nerf.n_rays = args.n_rays
     n_views = int(opt.data.num_views)
     model = build_model(opt, it0, n_views)
+    if world > 1 and OVERLAP:
+        from joint_tensorf_amd import ops as jops
+        jops.set_data_parallel(world)
+        model.render_loss_scale = 1.0 / world
     var_all = make_views(opt, n_views, seed=0, device=dev)
     nerf = model.graph.nerf
     res, S = nerf.resolution, nerf.n_samples
@@ -231,6 +248,7 @@ def main():
         return
 
     rays_total = 0
+    grad_sums = []
 
     def one_step():
         nonlocal rays_total
@@ -246,8 +264,20 @@ def main():
         np.random.set_state(state)
         loss = g.compute_loss(opt, var, mode="train")
         loss = model.summarize_loss(opt, var, loss)
-        (loss.all / world).backward()
+        if OVERLAP:
+            loss.all.backward()  # render term already scaled by 1 / world (model.render_loss_scale)
+        else:
+            (loss.all / world).backward()
         allreduce_grads(model, world)
+        if os.environ.get("JT_BENCH_CHECKSUM") == "1":
+            with torch.no_grad():
+                tf = model.graph.nerf.tensorf
+                grad_sums.append({
+                    "density": float(sum(p.grad.double().abs().sum() for p in tf.density_plane)),
+                    "app": float(sum(p.grad.double().abs().sum() for p in tf.app_plane)),
+                    "mlp": float(sum(p.grad.double().abs().sum() for p in tf.renderModule.weights())),
+                    "basis": float(tf.basis_mat.weight.grad.double().abs().sum()),
+                    "se3": float(model.graph.se3_refine.weight.grad.double().abs().sum())})
         model.optim.step()
         model.optim.zero_grad()
         it = model.it
@@ -312,6 +342,15 @@ def main():
                 "shade_impl": args.shade_impl,
             },
         }
+        if os.environ.get("JT_BENCH_CHECKSUM") == "1":  # validation of the N > 1 paths against each other
+            with torch.no_grad():
+                tf = model.graph.nerf.tensorf
+                out["grad_checksum_first_step"] = grad_sums[0] if grad_sums else None
+                out["param_checksum"] = {
+                    "density": float(sum(p.double().abs().sum() for p in tf.density_plane)),
+                    "app": float(sum(p.double().abs().sum() for p in tf.app_plane)),
+                    "mlp": float(sum(p.double().abs().sum() for p in tf.renderModule.weights())),
+                    "se3": float(model.graph.se3_refine.weight.double().abs().sum())}
         if world == 1 and not args.no_roofline:
             try:
                 from joint_tensorf_amd.options import Opt

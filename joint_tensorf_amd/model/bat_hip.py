@@ -366,6 +366,8 @@ class Model(torch.nn.Module):
         """model/tensorf.py:31-47 (linear weights; the finiteness asserts would force a host sync per
         iteration and are left to the caller)."""
         total = 0.0
+        # ray-sharded data parallelism: only the photometric term is a mean over the (global) ray batch
+        render_scale = float(getattr(self, "render_loss_scale", 1.0))
         for key in loss:
             assert key in opt.loss_weight, f"loss {key} not in opt.loss_weight"
             if key == "L1":
@@ -374,6 +376,8 @@ class Model(torch.nn.Module):
                 total = total + w * loss["L1"]
             elif opt.loss_weight[key] is not None:
                 w = float(opt.loss_weight[key])
+                if key == "render":
+                    w *= render_scale
                 if w != 0.0:
                     total = total + w * loss[key]
         loss.update(all=total)

@@ -70,18 +70,40 @@ def _aux_stream(dev):
     return _AUX[key]
 
 
-def _zeros_flat(groups):
+def _zeros_flat(groups, with_flat=False):
     """Zero tensors shaped like the tensors of `groups` (a list of lists), carved out of ONE flat buffer: one fill
-    launch instead of one per tensor (19 per backward).  Offsets are rounded up to 16 bytes."""
-    flat_n, plan = 0, []
+    launch instead of one per tensor (19 per backward).  Offsets are rounded up to 16 bytes.  with_flat: also
+    return the flat buffer and the [start, end) float span of every group (contiguous: one collective each)."""
+    flat_n, plan, spans = 0, [], []
     for grp in groups:
+        start = flat_n
         for t in grp:
             plan.append((flat_n, t))
             flat_n += (t.numel() + 3) // 4 * 4
+        spans.append((start, flat_n))
     ref = groups[0][0]
     flat = torch.zeros(flat_n, device=ref.device, dtype=ref.dtype)
     it = iter(plan)
-    return [[flat[o:o + t.numel()].view(t.shape) for (o, t) in (next(it) for _ in grp)] for grp in groups]
+    views = [[flat[o:o + t.numel()].view(t.shape) for (o, t) in (next(it) for _ in grp)] for grp in groups]
+    return (views, flat, spans) if with_flat else views
+
+
+# ---- ray-sharded data parallelism (SURVEY 8(e)) --------------------------------------------------------------
+# With set_data_parallel(world) the renderer's backward SUM-all-reduces its own gradients as soon as each group
+# is final -- appearance factors right after the shade backward, density factors after the density walk, MLP /
+# basis after the weight-gradient GEMMs -- so the collectives (RCCL, asynchronous on their own stream) overlap
+# the kernels that are still running.  Callers scale the RENDER loss by 1 / world; the regularisers are the
+# same on every rank and are neither scaled nor reduced.  Gradients that leave through the rays (poses) are the
+# caller's to reduce (dist.allreduce_gradients).
+_DP = {"world": 1, "group": None}
+
+
+def set_data_parallel(world, group=None):
+    _DP["world"], _DP["group"] = int(world), group
+
+
+def data_parallel_world():
+    return _DP["world"]
 
 
 def factor_storage(p):
@@ -318,15 +340,23 @@ class RenderRays(torch.autograd.Function):
         if want_fac:
             # gradient buffers (channel-last storage, zero-initialised: the kernels accumulate with atomics)
             if fused_mlp_zero:
-                gdp, gdl, gap, gal, g_mlp_z = _zeros_flat([sdp, sdl, sap, sal, mlp_t])
+                (gdp, gdl, gap, gal, g_mlp_z), gflat, spans = _zeros_flat([sdp, sdl, sap, sal, mlp_t], with_flat=True)
             else:
-                gdp, gdl, gap, gal = _zeros_flat([sdp, sdl, sap, sal])
+                (gdp, gdl, gap, gal), gflat, spans = _zeros_flat([sdp, sdl, sap, sal], with_flat=True)
             gfac = _factors_struct(gdp, gdl, gap, gal)
         else:
             gfac = None
         g_xyz = torch.empty(cap_alloc, 3, **f32)
         join = None
         g_mlp = [None] * 7
+        dp_works = []
+        dp = _DP["world"] > 1 and fused_mlp_zero
+        if _DP["world"] > 1 and not dp and (want_fac or want_mlp):
+            raise RuntimeError("data-parallel render backward needs the fused path with all scene gradients wanted")
+
+        def dp_reduce(lo, hi):
+            import torch.distributed as dist
+            dp_works.append(dist.all_reduce(gflat[lo:hi], op=dist.ReduceOp.SUM, group=_DP["group"], async_op=True))
         if cfg.shade_impl == "torch":
             g_mlp = [torch.zeros_like(t) for t in mlp_t]
             if n > 0:
@@ -375,6 +405,8 @@ class RenderRays(torch.autograd.Function):
                                         ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(rgb_s),
                                         ptr(g_rgb_s), gfac, gm, ptr(g_xyz), cap, ptr(ws), nbytes, 0, st, *h_aux),
                   "jt_shade_backward")
+            if dp:
+                dp_reduce(spans[2][0], spans[3][1])  # appearance planes + lines are final
         g_o = torch.empty(R, 3, **f32)
         g_d = torch.empty(R, 3, **f32)
         mws_bytes = lib.jt_march_backward_workspace_bytes(scene, R)
@@ -383,8 +415,14 @@ class RenderRays(torch.autograd.Function):
                                     ptr(sigma_feat), ptr(weight), ptr(tmin), ptr(offset), ptr(sidx), ptr(rgb_s),
                                     ptr(cmask), ptr(g_rgb), ptr(g_op), ptr(g_xyz), gfac, ptr(g_o), ptr(g_d),
                                     ptr(mws), mws_bytes, st), "jt_march_backward")
+        if dp:
+            dp_reduce(spans[0][0], spans[1][1])  # density planes + lines are final
         if join is not None:
             torch.cuda.current_stream().wait_event(join)  # weight gradients done before anyone reads them
+        if dp:
+            dp_reduce(spans[4][0], spans[4][1])  # basis + MLP
+            for w in dp_works:
+                w.wait()  # stream-level: whoever consumes the gradients next runs behind the collectives
         g_factors = [factor_logical(t) for t in gdp + gdl + gap + gal] if want_fac else [None] * 12
         out = [None, g_o, g_d, None, None] + g_factors + list(g_mlp)
         return tuple(out)
