@@ -530,3 +530,61 @@ class Model(torch.nn.Module):
         res = [self.evaluate_view(opt, Opt(dict(v))) for v in test_views]
         return Opt(R_error=error.R, t_error=error.t, views=res,
                    psnr=float(np.mean([r.psnr for r in res])) if res else float("nan"))
+
+    # ---- 2-D blur cache of the supervising images + edge masks ----------------------------------
+    @torch.no_grad()
+    def process_GT_images(self, opt, images=None):
+        """model/nerf.py:57-113: {scale: blurred GT images}; `images` [n,3,H,W] is what the reference reads from
+        self.train_data.all.image.  The 201-tap separable blur runs on the factor-blur kernel (ops.blur_images)."""
+        if images is None:
+            images = self.train_data.all.image
+        images = images.to(opt.device, dtype=torch.float32)
+        scales = opt.c2f_alternate_2D_scale_pool if opt.c2f_alternate_2D_mode == "sample" else [0.0, 1.0]
+        if opt.blur_2d_mode != "uniform-gaussian":
+            raise NotImplementedError("blur_2d_mode %s (the BAT yamls use uniform-gaussian)" % opt.blur_2d_mode)
+        out = dict()
+        for sc in scales:
+            blur_param = np.float32(interp_schedule(float(self.it / opt.max_iter), opt.blur_2d_c2f_schedule)) * np.float32(sc)
+            kernel_width = float(blur_param * np.float32((opt.W + opt.H) / 2))
+            if kernel_width < 0.01:
+                out[sc] = images
+            else:
+                taps = ops.gaussian_taps(kernel_width, opt.blur_2d_c2f_kernel_size, opt.device)
+                out[sc] = ops.blur_images(images, taps)
+        return out
+
+    @torch.no_grad()
+    def get_edge_mask(self, opt, blurred_gt_cached_images):
+        """model/nerf.py:115-149: Sobel magnitude of the channel-summed blurred image; hard mask = magnitude above
+        hard_edge_mask_mean_thresh x its per-image mean (uint8 [n, H*W]), soft mask = magnitude / per-image max."""
+        F = torch.nn.functional
+        dev = opt.device
+        Kx = torch.tensor([[1., 0., -1.], [2., 0., -2.], [1., 0., -1.]], device=dev)[None, None].expand(1, 3, -1, -1)
+        Ky = torch.tensor([[1., 2., 1.], [0., 0., 0.], [-1., -2., -1.]], device=dev)[None, None].expand(1, 3, -1, -1)
+        masks = dict()
+        for sc, img in blurred_gt_cached_images.items():
+            n = img.shape[0]
+            x = F.pad(img, (1, 1, 1, 1), mode="replicate")
+            GG = torch.sqrt(F.conv2d(x, Kx) ** 2 + F.conv2d(x, Ky) ** 2).view(n, opt.H * opt.W)
+            if _has(opt, "soft_edge_mask") and opt.soft_edge_mask:
+                masks[sc] = GG / GG.max(dim=1, keepdim=True)[0]
+            else:
+                thresh = opt.hard_edge_mask_mean_thresh if _has(opt, "hard_edge_mask_mean_thresh") else 1.25
+                masks[sc] = (GG > GG.mean(dim=1, keepdim=True) * thresh).to(torch.uint8)
+        return masks
+
+    def select_supervision(self, opt, images=None):
+        """The per-iteration choice of nerf.Model.train (model/nerf.py:172-176, 209-227): refresh the caches every
+        500 iterations, then draw the blur scale of this iteration's supervising images; the edge masks come from
+        opt.edge_mask_use_scale.  Returns (train_images, train_edge_masks, scale)."""
+        if not (_has(opt, "blur_2d") and opt.blur_2d):
+            return (images if images is not None else self.train_data.all.image), None, None
+        if self.it % 500 == 0 or not hasattr(self, "blurred_gt_cached_images"):
+            self.blurred_gt_cached_images = self.process_GT_images(opt, images)
+            self.blurred_edge_masks = self.get_edge_mask(opt, self.blurred_gt_cached_images)
+        if _has(opt, "c2f_alternate_2D_blur") and opt.c2f_alternate_2D_blur:
+            sc = np.random.choice(opt.c2f_alternate_2D_scale_pool)
+            train_images = self.blurred_gt_cached_images[sc]
+            key = opt.edge_mask_use_scale if _has(opt, "edge_mask_use_scale") else sc
+            return train_images, self.blurred_edge_masks[key], sc
+        return self.blurred_gt_cached_images[1.0], self.blurred_edge_masks[1.0], 1.0

@@ -725,6 +725,21 @@ def ray_gen(pose, intr_inv, intr, ray_idx, image_w, ndc=False, ndc_near=1.0):
     return RayGen.apply(pose, intr_inv, intr, ray_idx, image_w, ndc, ndc_near)
 
 
+def blur_images(images, taps):
+    """Separable replicate-padded blur (along W, then H) of a batch of images [n, c, H, W] with one tap vector:
+    the 2-D GT blur of nerf.Model.process_GT_images (model/nerf.py:98-110) on the factor-blur kernel.  All n*c
+    image planes ride the channel axis of one channel-last [H][W][n*c] tensor (padded to a multiple of 4)."""
+    n, c, H, W = images.shape
+    C = (n * c + 3) // 4 * 4
+    x = images.new_zeros(H, W, C)
+    x[:, :, :n * c] = images.reshape(n * c, H, W).permute(1, 2, 0)
+    taps = taps.detach().contiguous().float()
+    out, tmp = torch.empty_like(x), torch.empty_like(x)
+    check(lib.jt_blur_forward(ptr(x), ptr(out), ptr(tmp), H, W, C, ptr(taps), taps.numel(), _stream()),
+          "jt_blur_forward")
+    return out[:, :, :n * c].permute(2, 0, 1).reshape(n, c, H, W).contiguous()
+
+
 def gaussian_taps(sigma_vox, kernel_size, device):
     """kernels.get_gaussian_kernel (kernels.py:16-22): un-normalised taps clamped at 1, K even -> K+1 taps."""
     s = max(float(sigma_vox), 0.0001)

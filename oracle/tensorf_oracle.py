@@ -600,6 +600,48 @@ def render_by_slices(cfg, params, pose, intr_inv, H, W, n_rays, N_samples, **kw)
 
 
 # ----------------------------------------------------------------------------------------------
+# N3  2-D blur cache of the supervising images + Sobel edge masks           model/nerf.py:57-149
+# ----------------------------------------------------------------------------------------------
+def process_gt_images(images, progress, schedule, scales, kernel_size, mode="uniform-gaussian"):
+    """{scale: images} (model/nerf.py:57-113): separable replicate-padded correlation along W then H with the
+    taps of gaussian_kernel(width) where width = interp(progress) * scale * (W + H) / 2; widths below 0.01
+    leave the images untouched."""
+    assert mode == "uniform-gaussian"
+    n, _, H, W = images.shape
+    out = {}
+    for sc in scales:
+        width = torch.tensor(interp_schedule(float(progress), schedule)) * sc * (W + H) / 2
+        if width < 0.01:
+            out[sc] = images
+            continue
+        k = gaussian_kernel(width, kernel_size).float().view(1, 1, -1)
+        pad = (kernel_size // 2, kernel_size // 2)
+        x = images.reshape(n * 3, H, W)
+        x = F.conv1d(F.pad(x, pad, mode="replicate"), k.expand(H, 1, -1), groups=H)
+        x = x.permute(0, 2, 1)
+        x = F.conv1d(F.pad(x, pad, mode="replicate"), k.expand(W, 1, -1), groups=W)
+        out[sc] = x.permute(0, 2, 1).reshape(n, 3, H, W).contiguous()
+    return out
+
+
+def edge_masks(blurred, thresh=1.25, soft=False):
+    """{scale: mask [n, H*W]} (model/nerf.py:115-149): Sobel magnitude of the channel-summed image, hard mask =
+    magnitude > thresh * its per-image mean (uint8), soft mask = magnitude / its per-image max."""
+    Kx = torch.tensor([[1., 0., -1.], [2., 0., -2.], [1., 0., -1.]])[None, None].expand(1, 3, -1, -1)
+    Ky = torch.tensor([[1., 2., 1.], [0., 0., 0.], [-1., -2., -1.]])[None, None].expand(1, 3, -1, -1)
+    out = {}
+    for sc, img in blurred.items():
+        n = img.shape[0]
+        x = F.pad(img, (1, 1, 1, 1), mode="replicate")
+        GG = torch.sqrt(F.conv2d(x, Kx) ** 2 + F.conv2d(x, Ky) ** 2).view(n, -1)
+        if soft:
+            out[sc] = GG / GG.max(dim=1, keepdim=True)[0]
+        else:
+            out[sc] = (GG > GG.mean(dim=1, keepdim=True) * thresh).to(torch.uint8)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
 # A14  losses                        model/tensorf.py:96-142, base.py:259-261, tensoRF.py:212-228
 # ----------------------------------------------------------------------------------------------
 def mse_nanmean(pred, label):

@@ -118,3 +118,36 @@ def test_test_time_optim_and_eval_render():
     assert np.median(d) < 1e-5 and (d < 5e-5).mean() > 0.6 and d.max() < 0.05  # measured: 1e-7, 0.74
     psnr2 = -10 * float(g.MSE_loss(var2.rgb.view(-1, m["H"], m["W"], 3).permute(0, 3, 1, 2), var2.image).log10())
     assert abs(psnr2 - float(fx.arrays["out.psnr"])) < 0.01
+
+
+def test_gt_blur_cache_and_edge_masks():
+    """SURVEY 8(f) N3 through bat_hip.Model: the 201-tap 2-D blur of the supervising images on the HIP blur kernel
+    and the Sobel edge masks against the reference fixture."""
+    from joint_tensorf_amd.model import bat_hip
+    from joint_tensorf_amd.options import make_options
+    fx = Fixture("gt_blur_edge")
+    m = fx.meta
+    opt = make_options("bat_blender_VM", device="cuda", data=dict(image_size=[m["H"], m["W"]]),
+                       train_schedule=dict(n_voxel_init=14 ** 3))
+    assert list(opt.blur_2d_c2f_schedule) == m["blur_2d_c2f_schedule"] and opt.blur_2d_c2f_kernel_size == 201
+    model = bat_hip.Model(opt)
+    model.it = m["it"]
+    images = fx.t("in.images", "cuda")
+    blurred = model.process_GT_images(opt, images)
+    assert sorted(blurred.keys()) == m["scales"]
+    for sc in m["scales"]:
+        np.testing.assert_allclose(blurred[sc].cpu().numpy(), fx.arrays["blur.%g" % sc], atol=3e-6, err_msg=str(sc))
+    masks = model.get_edge_mask(opt, blurred)
+    for sc in m["scales"]:
+        got, ref = masks[sc].cpu().numpy(), fx.arrays["mask.%g" % sc]
+        assert got.dtype == np.uint8 and got.shape == ref.shape
+        assert (got != ref).mean() < 2e-3, sc  # pixels within round-off of the threshold may flip
+    # the per-iteration choice: caches are (re)built on multiples of 500 and re-used in between
+    model.it = 1000
+    np.random.seed(3)
+    img, mask, sc = model.select_supervision(opt, images)
+    assert sc in m["scales"] and img.shape == images.shape and mask.shape == (images.shape[0], m["H"] * m["W"])
+    cache = model.blurred_gt_cached_images
+    model.it = 1001
+    model.select_supervision(opt, images)
+    assert model.blurred_gt_cached_images is cache

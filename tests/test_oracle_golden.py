@@ -136,3 +136,19 @@ def test_test_time_optim_and_eval_render_golden():
     assert torch.allclose(acc, fx.t("out.opacity"), atol=2e-6)
     psnr = -10 * O.mse_nanmean(rgb.view(-1, m["H"], m["W"], 3).permute(0, 3, 1, 2), fx.t("in.test_image")).log10()
     assert abs(float(psnr) - float(fx.arrays["out.psnr"])) < 1e-4
+
+
+# ---- N3: 2-D blur cache of the supervising images + Sobel edge masks -----------------------------------------
+def test_gt_blur_and_edge_masks_golden():
+    fx = Fixture("gt_blur_edge")
+    m = fx.meta
+    blurred = O.process_gt_images(fx.t("in.images"), m["it"] / m["max_iter"], m["blur_2d_c2f_schedule"], m["scales"],
+                                  m["blur_2d_c2f_kernel_size"], m["blur_2d_mode"])
+    for sc in m["scales"]:
+        assert torch.allclose(blurred[sc], fx.t("blur.%g" % sc), atol=2e-6), sc
+    masks = O.edge_masks(blurred, m["hard_edge_mask_mean_thresh"], m["soft_edge_mask"])
+    for sc in m["scales"]:
+        ref = fx.t("mask.%g" % sc)
+        # a pixel whose Sobel magnitude sits within round-off of the threshold may flip
+        assert (masks[sc] != ref).float().mean() < 1e-3, sc
+    assert torch.equal(blurred[0.0], fx.t("in.images"))  # zero width: the images themselves

@@ -498,6 +498,42 @@ def eval_case(bat, camera, opt, graph, var, out_path, test_iter=4, seed=21):
           "loss trace", [round(x, 6) for x in trace_loss])
 
 
+def gt_blur_case(bat, opt, out_path, n_views=5, seed=31):
+    """N3: the 2-D blur cache of the supervising images and the Sobel edge masks, by the
+    reference's own nerf.Model.process_GT_images / get_edge_mask (model/nerf.py:57-149)."""
+    import types
+    import json
+    import model.nerf as ref_nerf
+    import util_vis
+    g = torch.Generator().manual_seed(seed)
+    H, W = opt.H, opt.W
+    # smooth random images with some structure (pure noise has no meaningful edges)
+    base = torch.rand(n_views, 3, H // 4, W // 4, generator=g)
+    images = torch.nn.functional.interpolate(base, size=(H, W), mode="bilinear", align_corners=True)
+    images = (images + 0.15 * torch.rand(n_views, 3, H, W, generator=g)).clamp(0, 1).contiguous()
+    me = types.SimpleNamespace(it=700, tb=None)
+    me.train_data = types.SimpleNamespace(all=EasyDict(image=images))
+    orig = util_vis.tb_wandb_image
+    util_vis.tb_wandb_image = lambda *a, **k: None
+    try:
+        blurred = ref_nerf.Model.process_GT_images(me, opt)
+        masks = ref_nerf.Model.get_edge_mask(me, opt, blurred)
+    finally:
+        util_vis.tb_wandb_image = orig
+    out = {"in.images": images.numpy()}
+    scales = sorted(blurred.keys())
+    for sc in scales:
+        out["blur.%g" % sc] = blurred[sc].numpy()
+        out["mask.%g" % sc] = masks[sc].numpy()
+    meta = dict(it=700, max_iter=int(opt.max_iter), H=H, W=W, scales=[float(s) for s in scales],
+                blur_2d_c2f_schedule=[float(x) for x in opt.blur_2d_c2f_schedule],
+                blur_2d_c2f_kernel_size=int(opt.blur_2d_c2f_kernel_size), blur_2d_mode=str(opt.blur_2d_mode),
+                hard_edge_mask_mean_thresh=float(opt.hard_edge_mask_mean_thresh), soft_edge_mask=bool(opt.soft_edge_mask))
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(out_path, **out)
+    print("wrote", out_path, "scales", scales, "mask fractions", [float(masks[s].float().mean()) for s in scales])
+
+
 def known_answers(camera, kernels, bat, out_path):
     """Known-answer vectors for the small pure functions on the path."""
     import model.tensorf_repr.bateRF as bateRF
@@ -581,6 +617,8 @@ def main():
         for p in graph.nerf.tensorf.density_plane:
             p.mul_(22.0 / 40.0)
     eval_case(bat, camera, opt, graph, var, os.path.join(outdir, "blender_test_optim.npz"))
+    # N3: 2-D blur cache of the GT images + edge masks (host torch ops in the reference, every 500 iterations)
+    gt_blur_case(bat, opt, os.path.join(outdir, "gt_blur_edge.npz"))
 
     # all_view_rand_rays variant (config C1 uses it)
     opt2 = make_opt(options, "bat_blender_VM", H=40, W=40, n_voxel_init=14 ** 3,
