@@ -259,3 +259,26 @@ def test_reg_losses_vs_oracle():
     for i in range(9):
         assert _rel(dev[i].grad.cpu().numpy(), leaves[i].grad.numpy()) < 2e-5, i
     assert all(dev[i].grad is None for i in range(9, 12))
+
+
+def test_upsample_volume_grid_vs_golden():
+    """BAT_VMSplit.upsample_volume_grid (channel-last parameters) against the reference's up_sampling_VM."""
+    import joint_tensorf_amd as jt
+    d = np.load(GOLDEN + "/known_answers.npz")
+    g0 = [6, 7, 5]
+    tf = jt.BAT_VMSplit([-1.5] * 3 + [1.5] * 3, g0, DEV, density_n_comp=[4, 4, 4], appearance_n_comp=[4, 4, 4],
+                        app_dim=27, near_far=[2.0, 6.0], shadingMode="MLP_Fea", featureC=64)
+    with torch.no_grad():
+        for i in range(3):
+            for grp in ("density", "app"):
+                getattr(tf, grp + "_plane")[i].copy_(torch.tensor(d["up.plane_in.%d" % i], device=DEV))
+                getattr(tf, grp + "_line")[i].copy_(torch.tensor(d["up.line_in.%d" % i], device=DEV))
+    tf.upsample_volume_grid(d["up.res_target"].tolist())
+    assert tf.gridSize.tolist() == d["up.res_target"].tolist()
+    for i in range(3):
+        for grp in ("density", "app"):
+            p, l = getattr(tf, grp + "_plane")[i], getattr(tf, grp + "_line")[i]
+            np.testing.assert_allclose(p.detach().cpu().numpy(), d["up.plane_out.%d" % i], atol=2e-6)
+            np.testing.assert_allclose(l.detach().cpu().numpy(), d["up.line_out.%d" % i], atol=2e-6)
+            # still channel-last storage behind the logical [1,C,H,W] shape
+            assert p.permute(0, 2, 3, 1).is_contiguous() and l.permute(0, 2, 3, 1).is_contiguous()

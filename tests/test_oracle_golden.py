@@ -152,3 +152,14 @@ def test_gt_blur_and_edge_masks_golden():
         # a pixel whose Sobel magnitude sits within round-off of the threshold may flip
         assert (masks[sc] != ref).float().mean() < 1e-3, sc
     assert torch.equal(blurred[0.0], fx.t("in.images"))  # zero width: the images themselves
+
+
+def test_upsample_vm_known_answer():
+    """tensoRF.py:274-295 on a non-cubic grid."""
+    d = np.load(GOLDEN + "/known_answers.npz")
+    planes = [torch.tensor(d["up.plane_in.%d" % i]) for i in range(3)]
+    lines = [torch.tensor(d["up.line_in.%d" % i]) for i in range(3)]
+    up_p, up_l = O.upsample_vm(planes, lines, d["up.res_target"].tolist())
+    for i in range(3):
+        assert torch.allclose(up_p[i], torch.tensor(d["up.plane_out.%d" % i]), atol=1e-6)
+        assert torch.allclose(up_l[i], torch.tensor(d["up.line_out.%d" % i]), atol=1e-6)

@@ -569,6 +569,22 @@ def known_answers(camera, kernels, bat, out_path):
     line = torch.randn(1, 6, 17, 1)
     out["blur.line.in"] = line.numpy()
     out["blur.line.out"] = conv_line(None, k, line).numpy()
+    # grid upsampling of the VM factors (tensoRF.py:274-295), non-cubic 6x7x5 -> 9x11x8
+    import types
+    import model.tensorf_repr.tensoRF as tensoRF
+    vm = types.SimpleNamespace(matMode=[[0, 1], [0, 2], [1, 2]], vecMode=[2, 1, 0])
+    g0, g1 = [6, 7, 5], [9, 11, 8]
+    planes = [torch.randn(1, 4, g0[m1], g0[m0]) for m0, m1 in vm.matMode]
+    lines = [torch.randn(1, 4, g0[v], 1) for v in vm.vecMode]
+    for i in range(3):
+        out["up.plane_in.%d" % i] = planes[i].numpy()
+        out["up.line_in.%d" % i] = lines[i].numpy()
+    up_p, up_l = tensoRF.TensorVMSplit.up_sampling_VM(vm, [torch.nn.Parameter(p.clone()) for p in planes],
+                                                      [torch.nn.Parameter(l.clone()) for l in lines], g1)
+    for i in range(3):
+        out["up.plane_out.%d" % i] = up_p[i].detach().numpy()
+        out["up.line_out.%d" % i] = up_l[i].detach().numpy()
+    out["up.res_target"] = np.array(g1, np.int32)
     np.savez_compressed(out_path, **out)
     print("wrote", out_path)
 
