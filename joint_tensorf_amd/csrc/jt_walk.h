@@ -336,6 +336,7 @@ struct RecWalker {
   }
   // flush the slots whose texel the walk leaves with this sample, then adopt the sample's texels
   __device__ inline void advance(const float* rec) {
+    if (gP == nullptr) return;  // pose-only backward: no accumulators to keep
     const uint4 rl = *reinterpret_cast<const uint4*>(rec + 4);
     const unsigned bits = rl.z;
     if (bits & 0x3f00u) {
@@ -380,18 +381,21 @@ struct RecWalker {
       const float pv = w.x * tv.a[k] + w.y * tv.b[k] + w.z * tv.c[k] + w.w * tv.d[k];
       const float lv = x.x * tv.u[k] + x.y * tv.v[k];
       const float gpv = g[k] * lv, glv = g[k] * pv;
-      acc[0][k] += w.x * gpv;
-      acc[1][k] += w.y * gpv;
-      acc[2][k] += w.z * gpv;
-      acc[3][k] += w.w * gpv;
-      accl[0][k] += x.x * glv;
-      accl[1][k] += x.y * glv;
+      if (gP != nullptr) {
+        acc[0][k] += w.x * gpv;
+        acc[1][k] += w.y * gpv;
+        acc[2][k] += w.z * gpv;
+        acc[3][k] += w.w * gpv;
+        accl[0][k] += x.x * glv;
+        accl[1][k] += x.y * glv;
+      }
       aix += gpv * (x.z * (tv.b[k] - tv.a[k]) + x.w * (tv.d[k] - tv.c[k]));
       aiy += gpv * (y.x * (tv.c[k] - tv.a[k]) + y.y * (tv.d[k] - tv.b[k]));
       ail += glv * (sgz * (tv.v[k] - tv.u[k]));
     }
   }
   __device__ inline void finish() {
+    if (gP == nullptr) return;
     flush(gP, o[0], acc[0]);
     flush(gP, o[1], acc[1]);
     flush(gP, o[2], acc[2]);
