@@ -41,6 +41,9 @@ extern "C" {
 #define JT_MLP_FEA 0      /* MLPRender_Fea          tensorBase.py:101-126 */
 #define JT_MLP_WEAKVIEW 1 /* MLPRender_Fea_WeakView tensorBase.py:180-214 */
 
+#define JT_SHADE_POSE_ONLY 2  /* jt_shade_forward flags: the backward of this forward will be called without
+                                 g_factors and g_mlp (test-time pose optimisation); only the records that
+                                 backward reads are written */
 #define JT_SHADE_SKIP_WGRAD 1 /* jt_shade_backward flags: leave out the MLP/basis weight-gradient pass
                                  (kernel timing probes only; g_mlp is then not written) */
 
@@ -230,7 +233,7 @@ int jt_shade_forward(const JtScene* scene, const JtFactors* factors, const JtMlp
                      const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
                      const int32_t* shade_offset, int n_rays, const int32_t* entry_ray,
                      const int32_t* entry_smp, const float* viewdirs, float* rgb_s, int n_entries_max,
-                     void* workspace, size_t workspace_bytes, void* stream);
+                     void* workspace, size_t workspace_bytes, int flags, void* stream);
 int jt_shade_backward(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp, const float* rays_o,
                       const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
                       const int32_t* shade_offset, int n_rays, const int32_t* entry_ray,

@@ -15,6 +15,7 @@ c_i = ctypes.c_int32
 
 JT_ACT_SOFTPLUS, JT_ACT_RELU = 0, 1
 JT_MLP_FEA, JT_MLP_WEAKVIEW = 0, 1
+JT_SHADE_SKIP_WGRAD, JT_SHADE_POSE_ONLY = 1, 2
 
 
 class JtScene(ctypes.Structure):
@@ -79,7 +80,7 @@ SIGNATURES = {
     "jt_blur_batch_backward": (I, [P, I, P]),
     "jt_factor_reg_forward": (I, [P, I, I, I, P, P]),
     "jt_factor_reg_backward": (I, [P, I, I, I, P, P, I, P]),
-    "jt_shade_forward": (I, [SP, FP, MP, P, P, P, P, P, P, I, P, P, P, P, I, P, ctypes.c_size_t, P]),
+    "jt_shade_forward": (I, [SP, FP, MP, P, P, P, P, P, P, I, P, P, P, P, I, P, ctypes.c_size_t, I, P]),
     "jt_shade_backward": (I, [SP, FP, MP, P, P, P, P, P, P, I, P, P, P, P, P, FP, MP, P, I, P, ctypes.c_size_t, I, P, P, P, P]),
 }
 

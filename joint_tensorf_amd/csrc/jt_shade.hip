@@ -393,9 +393,10 @@ __device__ inline void rec_store(float* rt, int row0, const f32x16* v, int j, in
     for (int r = 0; r < 16; ++r) rt[(size_t)(row0 + t * 32 + rowmap(r, 0) + 4 * h) * 32 + j] = v[t][r];
 }
 
-// REC = true (training): besides rgb the kernel leaves the tile-blocked records of the layer inputs (see
-// BwdCfg) so that the backward does not have to gather and run the forward chain a second time.
-template <class C, bool REC>
+// REC = 1 (training): besides rgb the kernel leaves the tile-blocked records of the layer inputs (see BwdCfg) so
+// that the backward does not have to gather and run the forward chain a second time.  REC = 2: only what a
+// pose-only backward reads (basis output, ReLU sign words, sample coordinates).
+template <class C, int REC>
 __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm, const float* __restrict__ rays_o,
                                                       const float* __restrict__ rays_d,
                                                       const float* __restrict__ jitter,
@@ -427,11 +428,11 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
     if (REC && on && h == 0) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        rt[(size_t)(B::R_VD + c) * 32 + j] = vd[c];
+        if (REC == 1) rt[(size_t)(B::R_VD + c) * 32 + j] = vd[c];
         rt[(size_t)(B::R_GEO + c) * 32 + j] = g.n[c];
       }
     }
-    f32x16 facc = gather_basis<C, REC>(D, smem, g.n, j, h, rt, on);
+    f32x16 facc = gather_basis<C, REC == 1>(D, smem, g.n, j, h, rt, on);
     if (REC) rec_store<1>(rt, B::R_F, &facc, j, h, on);
     Hidden<C> h1 = layer1<C>(smem, facc, vd, pm, j, h);
     relu_<C>(h1);
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
 #pragma unroll
         for (int r = 0; r < 16; ++r) mask1 |= (h1.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
       if (on) rt[(size_t)(B::R_MASK + h) * 32 + j] = __uint_as_float(mask1);
-      rec_store<C::MT>(rt, B::R_H1, h1.v, j, h, on);
+      if (REC == 1) rec_store<C::MT>(rt, B::R_H1, h1.v, j, h, on);
     }
     Hidden<C> h2 = layer2<C>(smem, h1, j, h);
     relu_<C>(h2);
@@ -453,8 +454,8 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
 #pragma unroll
         for (int r = 0; r < 16; ++r) mask2 |= (h2.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
       if (on) rt[(size_t)(B::R_MASK + 2 + h) * 32 + j] = __uint_as_float(mask2);
-      rec_store<C::MT>(rt, B::R_MID + HOFF, h2.v, j, h, on);
-      if (C::KIND != JT_MLP_FEA) {
+      if (REC == 1) rec_store<C::MT>(rt, B::R_MID + HOFF, h2.v, j, h, on);
+      if (REC == 1 && C::KIND != JT_MLP_FEA) {
         float pe[12];
         view_pe(vd, pm, pe);
         if (on && h == 0) {
@@ -1056,7 +1057,7 @@ extern "C" size_t jt_shade_workspace_bytes(const JtScene* scene, int n_entries_m
   return (kind == 0) ? WsLayout<CfgBlender>::bytes(n_entries_max) : WsLayout<CfgLlff>::bytes(n_entries_max);
 }
 
-template <class C, bool REC>
+template <class C, int REC>
 static int launch_shade_fwd_t(const Dev& D, const MlpDev& M, const PeMask& pm, const float* rays_o,
                               const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
                               const int32_t* offset, int R, const int32_t* eray, const int32_t* esmp,
@@ -1078,21 +1079,25 @@ template <class C>
 static int launch_shade_fwd(const Dev& D, const MlpDev& M, const PeMask& pm, const float* rays_o,
                             const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
                             const int32_t* offset, int R, const int32_t* eray, const int32_t* esmp,
-                            const float* vdir, float* rgb_s, int cap, float* ws, size_t ws_bytes, hipStream_t st) {
+                            const float* vdir, float* rgb_s, int cap, float* ws, size_t ws_bytes, int flags,
+                            hipStream_t st) {
   if (ws) {
     if (ws_bytes < WsLayout<C>::bytes(cap)) return JT_ERR_ARG;
-    return launch_shade_fwd_t<C, true>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, offset, R, eray, esmp, vdir,
-                                       rgb_s, ws, cap, st);
+    if (flags & JT_SHADE_POSE_ONLY)
+      return launch_shade_fwd_t<C, 2>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, offset, R, eray, esmp, vdir,
+                                      rgb_s, ws, cap, st);
+    return launch_shade_fwd_t<C, 1>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, offset, R, eray, esmp, vdir,
+                                    rgb_s, ws, cap, st);
   }
-  return launch_shade_fwd_t<C, false>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, offset, R, eray, esmp, vdir,
-                                      rgb_s, nullptr, cap, st);
+  return launch_shade_fwd_t<C, 0>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, offset, R, eray, esmp, vdir,
+                                  rgb_s, nullptr, cap, st);
 }
 
 extern "C" int jt_shade_forward(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp, const float* rays_o,
                                 const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
                                 const int32_t* shade_offset, int n_rays, const int32_t* entry_ray,
                                 const int32_t* entry_smp, const float* viewdirs, float* rgb_s, int n_entries_max,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+                                void* workspace, size_t workspace_bytes, int flags, void* stream) {
   Dev D;
   int rc = make_dev(scene, factors, &D);
   if (rc) return rc;
@@ -1110,9 +1115,10 @@ extern "C" int jt_shade_forward(const JtScene* scene, const JtFactors* factors, 
   if (kind == 0)
     return launch_shade_fwd<CfgBlender>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, shade_offset, n_rays,
                                         entry_ray, entry_smp, viewdirs, rgb_s, n_entries_max, (float*)workspace,
-                                        workspace_bytes, st);
+                                        workspace_bytes, flags, st);
   return launch_shade_fwd<CfgLlff>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, shade_offset, n_rays, entry_ray,
-                                   entry_smp, viewdirs, rgb_s, n_entries_max, (float*)workspace, workspace_bytes, st);
+                                   entry_smp, viewdirs, rgb_s, n_entries_max, (float*)workspace, workspace_bytes, flags,
+                                   st);
 }
 
 template <class C>

@@ -296,9 +296,11 @@ class RenderRays(torch.autograd.Function):
                 nbytes = lib.jt_shade_workspace_bytes(scene, cap)
                 ws = _workspace(dev, "shade", nbytes)
                 ctx.ws_ticket = _workspace_claim(dev, "shade")
-                ws_args = (ptr(ws), nbytes)
+                # only the rays want a gradient (test-time pose optimisation): the light set of records
+                ctx.pose_only = not any(ctx.needs_input_grad[5:])
+                ws_args = (ptr(ws), nbytes, _lib.JT_SHADE_POSE_ONLY if ctx.pose_only else 0)
             else:
-                ws_args = (None, 0)
+                ws_args = (None, 0, 0)
             check(lib.jt_shade_forward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
                                        ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(rgb_s),
                                        cap, *ws_args, st), "jt_shade_forward")
@@ -389,7 +391,8 @@ class RenderRays(torch.autograd.Function):
                 ctx.ws_ticket = _workspace_claim(dev, "shade")
                 check(lib.jt_shade_forward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
                                            ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir),
-                                           ptr(torch.empty_like(rgb_s)), cap, ptr(ws), nbytes, st),
+                                           ptr(torch.empty_like(rgb_s)), cap, ptr(ws), nbytes,
+                                           _lib.JT_SHADE_POSE_ONLY if ctx.pose_only else 0, st),
                       "jt_shade_forward")
             if USE_AUX_STREAM and want_mlp:
                 aux, ev_fork, ev_join = _aux_stream(dev)
@@ -820,11 +823,11 @@ class KernelProbe:
         ws = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8)
         t_inf = timed(lambda: check(lib.jt_shade_forward(
             scene, fac, mlp, ptr(self.o), ptr(self.d), ptr(self.jitter), None, ptr(tmin), ptr(offset), R, ptr(eray),
-            ptr(esmp), ptr(vdir), ptr(rgb_s), n, None, 0, st), "jt_shade_forward"))
+            ptr(esmp), ptr(vdir), ptr(rgb_s), n, None, 0, 0, st), "jt_shade_forward"))
         # training forward: also leaves the layer-input records for the backward in the workspace
         t_fwd = timed(lambda: check(lib.jt_shade_forward(
             scene, fac, mlp, ptr(self.o), ptr(self.d), ptr(self.jitter), None, ptr(tmin), ptr(offset), R, ptr(eray),
-            ptr(esmp), ptr(vdir), ptr(rgb_s), n, ptr(ws), nbytes, st), "jt_shade_forward"))
+            ptr(esmp), ptr(vdir), ptr(rgb_s), n, ptr(ws), nbytes, 0, st), "jt_shade_forward"))
         # one backward launch = one chunk of shaded samples
         nb = min(n, self.CHUNK)
         g_rgb_s = torch.rand(max(n, 1), 3, **f32)
