@@ -204,7 +204,7 @@ extern "C" int jt_reg_losses_forward(const JtFactors* factors, const int32_t* pl
     if (i >= 6 && !tv) continue;  // appearance planes only enter TV_color
     const RegTensor& t = S.t[i];
     long total = (long)t.H * t.W * (t.C / 4);
-    int blocks = (int)min((total + 255) / 256, 2048L);
+    int blocks = (int)min((total + 255) / 256, 512L);  // every block ends in three same-address atomics
     if (tv)
       hipLaunchKernelGGL(k_factor_reg_fwd<true>, dim3(blocks), dim3(256), 0, st, t.x, t.H, t.W, t.C, scratch36 + i * 3);
     else
