@@ -296,8 +296,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
+    for w in range(args.warmup):
+        if w == 0:
+            # the first warm-up step takes the densest lattice (offsets 0, 0): every persistent workspace and
+            # allocator block reaches its final size before the timed region instead of growing inside it
+            orig_randint = np.random.randint
+            np.random.randint = lambda *a, **k: 0
+            try:
+                one_step()
+            finally:
+                np.random.randint = orig_randint
+        else:
+            one_step()
     barrier()
     rays_total = 0
     t0 = time.perf_counter()

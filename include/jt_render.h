@@ -75,6 +75,11 @@ typedef struct JtScene {
   int32_t fea_pe;
   float view_pe_progress;
   float fea_pe_progress;
+  /* alpha-mask volume (AlphaGridMask, tensorBase.py:80-98), used when JtFactors.alpha_volume != NULL:
+   * samples whose trilinear mask value is not > 0 are dropped (batBase.py:76-82). */
+  int32_t mask_dims[3]; /* the volume's gridSize (x, y, z); the tensor is [z][y][x]                      */
+  float mask_lo[3];     /* its own box: aabb[0]                                                         */
+  float mask_inv[3];    /* 1.0 / (aabb[1] - aabb[0]) * 2, rounded like AlphaGridMask.invgridSize        */
 } JtScene;
 
 /* the 12 VM factor tensors (or their gradients) */
@@ -83,6 +88,8 @@ typedef struct JtFactors {
   float* density_line[3];
   float* app_plane[3];
   float* app_line[3];
+  const float* alpha_volume; /* optional alpha-mask volume [z][y][x] (0 / 1 floats); NULL = no mask; ignored in
+                                gradient structs */
 } JtFactors;
 
 /* basis_mat.weight [app_dim][3*n_comp_app] and the render MLP (torch Linear layout [out][in]) */
@@ -167,6 +174,10 @@ int jt_blur_batch_backward(const JtBlurItem* items, int n_items, void* stream);
  * jt_shade_forward (fused, MFMA): prod -> basis -> MLP -> sigmoid, rgb_s [n][3].
  * jt_composite_forward: rgb [R][3] = sum_k w_k c_k (+ white bg) clamped, clamp_mask [R] bit ch
  *   set when the un-clamped value lies in [0,1]. */
+/* Opacity 1 - exp(-sigma * length) of one step at n arbitrary world points xyz [n][3] (masked points: 0).
+ * Replaces BatBase.compute_alpha (batBase.py:27-41) under TensorBase.getDenseAlpha (tensorBase.py:618-634). */
+int jt_dense_alpha(const JtScene* scene, const JtFactors* factors, const float* xyz, long n, float length,
+                   float* alpha, void* stream);
 int jt_march_forward(const JtScene* scene, const JtFactors* factors, const float* rays_o, const float* rays_d,
                      const float* jitter, const float* zvals, int n_rays, float* sigma_feat, float* weight,
                      float* tmin, int32_t* shade_count, int32_t* shade_offset, uint16_t* shade_idx,

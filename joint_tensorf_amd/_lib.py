@@ -28,12 +28,14 @@ class JtScene(ctypes.Structure):
         ("weight_thres", c_f), ("n_samples", c_i), ("ndc", c_i), ("white_bg", c_i),
         ("app_dim", c_i), ("mlp_kind", c_i), ("mlp_hidden", c_i), ("view_pe", c_i), ("fea_pe", c_i),
         ("view_pe_progress", c_f), ("fea_pe_progress", c_f),
+        ("mask_dims", c_i * 3), ("mask_lo", c_f * 3), ("mask_inv", c_f * 3),
     ]
 
 
 class JtFactors(ctypes.Structure):
     _fields_ = [("density_plane", ctypes.c_void_p * 3), ("density_line", ctypes.c_void_p * 3),
-                ("app_plane", ctypes.c_void_p * 3), ("app_line", ctypes.c_void_p * 3)]
+                ("app_plane", ctypes.c_void_p * 3), ("app_line", ctypes.c_void_p * 3),
+                ("alpha_volume", ctypes.c_void_p)]
 
 
 class JtMlp(ctypes.Structure):
@@ -76,6 +78,7 @@ SIGNATURES = {
     "jt_render_loss_backward": (I, [P, P, P, P, I, I, I, F, F, P, P, P, P]),
     "jt_reg_losses_forward": (I, [FP, P, I, I, I, I, P, P, P]),
     "jt_reg_losses_backward": (I, [FP, P, I, I, P, I, I, FP, I, P, P]),
+    "jt_dense_alpha": (I, [SP, FP, P, ctypes.c_long, F, P, P]),
     "jt_blur_batch_forward": (I, [P, I, P]),
     "jt_blur_batch_backward": (I, [P, I, P]),
     "jt_factor_reg_forward": (I, [P, I, I, I, P, P]),
@@ -112,5 +115,9 @@ def check(rc, what):
 
 
 def ptr(t):
-    """device pointer of a tensor (or None)."""
-    return None if t is None else t.data_ptr()
+    """device pointer of a tensor (or None).  A host tensor here would fault inside a kernel: refuse it."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise JtError("host tensor handed to a device entry point (shape %s)" % (tuple(t.shape),))
+    return t.data_ptr()

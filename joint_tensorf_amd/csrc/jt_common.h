@@ -25,6 +25,9 @@ struct Dev {
   const float* dL[3];
   const float* aP[3];
   const float* aL[3];
+  const float* mask;  // alpha-mask volume [z][y][x] or nullptr
+  int md[3];
+  float mlo[3], minv[3];
 };
 
 inline int make_dev(const JtScene* s, const JtFactors* f, Dev* d) {
@@ -54,6 +57,13 @@ inline int make_dev(const JtScene* s, const JtFactors* f, Dev* d) {
   d->S = s->n_samples;
   d->ndc = s->ndc;
   d->white_bg = s->white_bg;
+  d->mask = f ? f->alpha_volume : nullptr;
+  for (int a = 0; a < 3; ++a) {
+    d->md[a] = s->mask_dims[a];
+    d->mlo[a] = s->mask_lo[a];
+    d->minv[a] = s->mask_inv[a];
+    if (d->mask && d->md[a] < 1) return JT_ERR_ARG;
+  }
   if (d->S < 1 || d->S > 65535) return JT_ERR_ARG;
   return JT_OK;
 }
@@ -111,6 +121,38 @@ __device__ inline bool sample_point(const Dev& D, const Ray& r, float z, float p
     inside = inside && !(D.lo[a] > p[a]) && !(p[a] > D.hi[a]);
   }
   return inside;
+}
+
+// AlphaGridMask.sample_alpha(p) > 0 (tensorBase.py:92-99, grid_sample trilinear, align_corners=True, zero
+// padding) for a 0/1 volume: true iff a corner that is inside the volume, set, and has a non-zero weight exists.
+__device__ inline bool mask_keep(const Dev& D, const float p[3]) {
+  int i0[3];
+  float f[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float g = add_rn(mul_rn(add_rn(p[a], -D.mlo[a]), D.minv[a]), -1.f);  // (xyz - aabb[0]) * invgridSize - 1
+    const float ix = ((g + 1.f) * 0.5f) * (float)(D.md[a] - 1);
+    const float fl = floorf(ix);
+    i0[a] = (int)fl;
+    f[a] = ix - fl;
+  }
+  bool keep = false;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+    const int x = i0[0] + dx, y = i0[1] + dy, z = i0[2] + dz;
+    const float w = (dx ? f[0] : 1.f - f[0]) * (dy ? f[1] : 1.f - f[1]) * (dz ? f[2] : 1.f - f[2]);
+    if (x >= 0 && x < D.md[0] && y >= 0 && y < D.md[1] && z >= 0 && z < D.md[2] && w > 0.f)
+      keep = keep || (D.mask[((size_t)z * D.md[1] + y) * D.md[0] + x] > 0.f);
+  }
+  return keep;
+}
+
+// sample_point + the alpha mask: the validity of a sample as BatBase.forward sees it (batBase.py:76-82)
+__device__ inline bool sample_valid(const Dev& D, const Ray& r, float z, float p[3]) {
+  bool v = sample_point(D, r, z, p);
+  if (v && D.mask) v = mask_keep(D, p);
+  return v;
 }
 
 // normalize_coord (tensorBase.py:502-503)

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_march_fwd(Dev D, const float* __restric
       z0 = sample_z(D, r, zvals, i);
       if (i < S - 1) delta = (sample_z(D, r, zvals, i + 1) - z0) * r.norm;
       float p[3], n[3];
-      valid = sample_point(D, r, z0, p);
+      valid = sample_valid(D, r, z0, p);
       if (valid) {
         normalize(D, p, n);
         feat = density_feature(D, n);
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_march_bwd_scan(Dev D, const float* __re
       float z0 = sample_z(D, r, zvals, i);
       if (i < S - 1) delta = (sample_z(D, r, zvals, i + 1) - z0) * r.norm;
       float p[3];
-      valid = sample_point(D, r, z0, p);
+      valid = sample_valid(D, r, z0, p);
       feat = sigma_feat[row + i];
       wst = weight[row + i];
     }
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void k_march_bwd_scan(Dev D, const float* __re
       float z0 = sample_z(D, r, zvals, i);
       if (i < S - 1) delta = (sample_z(D, r, zvals, i + 1) - z0) * r.norm;
       float p[3];
-      valid = sample_point(D, r, z0, p);
+      valid = sample_valid(D, r, z0, p);
       feat = sigma_feat[row + i];
     }
     float v = live ? Gw * (alpha * T) : 0.f;
@@ -531,16 +531,49 @@ __global__ __launch_bounds__(256) void k_march_bwd_walk(Dev D, JtFactors G, cons
   else if (cl < 6) atomicAdd(g_rays_d + ray * 3 + (cl - 3), cl == 3 ? gd[0] : cl == 4 ? gd[1] : gd[2]);
 }
 
+// opacity of one step of `length` at arbitrary points (BatBase.compute_alpha, batBase.py:27-41): the dense
+// lattice of TensorBase.getDenseAlpha (tensorBase.py:618-634) goes through this
+__global__ __launch_bounds__(256) void k_dense_alpha(Dev D, const float* __restrict__ xyz, long n, float length,
+                                                     float* __restrict__ alpha) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float p[3] = {xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]};
+  float sigma = 0.f;
+  if (!D.mask || mask_keep(D, p)) {
+    float nrm[3];
+    normalize(D, p, nrm);
+    sigma = density_act(D.act, density_feature(D, nrm) + D.shift);
+  }
+  alpha[i] = 1.f - expf(-sigma * length);
+}
+
 }  // namespace jt
 
 using namespace jt;
-
-extern "C" int jt_version(void) { return JT_VERSION; }
 
 static int check_density_shape(const Dev& D) {
   if (D.Cd < 4 || (D.Cd % 4) != 0) return JT_ERR_UNSUPPORTED;
   return JT_OK;
 }
+
+extern "C" int jt_version(void) { return JT_VERSION; }
+
+extern "C" int jt_dense_alpha(const JtScene* scene, const JtFactors* factors, const float* xyz, long n, float length,
+                              float* alpha, void* stream) {
+  Dev D;
+  int rc = make_dev(scene, factors, &D);
+  if (rc) return rc;
+  if (!factors || !xyz || !alpha || n < 0) return JT_ERR_ARG;
+  if ((rc = check_density_shape(D))) return rc;
+  for (int a = 0; a < 3; ++a)
+    if (!D.dP[a] || !D.dL[a]) return JT_ERR_ARG;
+  if (n == 0) return JT_OK;
+  hipLaunchKernelGGL(k_dense_alpha, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, D, xyz, n,
+                     length, alpha);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
 
 extern "C" int jt_march_forward(const JtScene* scene, const JtFactors* factors, const float* rays_o,
                                 const float* rays_d, const float* jitter, const float* zvals, int n_rays,

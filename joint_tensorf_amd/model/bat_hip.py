@@ -137,15 +137,27 @@ class NeRF(torch.nn.Module):
             self.lr_basis *= self.lr_decay_factor
             self.lr_index *= self.lr_decay_factor
         if it in self.update_alphamask_iters:
-            r = self.resolution
-            if r[0] * r[1] * r[2] < 256 ** 3:
-                raise NotImplementedError("alpha-mask update (SURVEY.md §8(f) N4) -- never reached by the BAT yamls")
+            self._update_alphamask(it)
         if opt.loss_weight.TV_density > 0:
             opt.loss_weight.TV_density *= self.lr_decay_factor
             self.TV_weight_density = opt.loss_weight.TV_density
         if opt.loss_weight.TV_color > 0:
             opt.loss_weight.TV_color *= self.lr_decay_factor
             self.TV_weight_color = opt.loss_weight.TV_color
+
+    def _update_alphamask(self, it):
+        """model/tensorf.py:480-489: only while the grid is below 256^3 (never the case at the iterations the BAT
+        yamls name); the first update also shrinks the box.  As in the reference the optimizer is NOT rebuilt
+        here: it is rebuilt by the next upsampling."""
+        if it not in self.update_alphamask_iters:
+            return
+        r = self.resolution
+        if r[0] * r[1] * r[2] < 256 ** 3:
+            self.alphamask_resolution = r
+            new_aabb = self.tensorf.updateAlphaMask(tuple(r))
+            if it == self.update_alphamask_iters[0]:
+                self.tensorf.shrink(new_aabb)
+                self.bbox = new_aabb
 
     def freeze_scene(self, opt):
         self.tensorf.freeze_scene(opt)

@@ -128,7 +128,7 @@ class RenderCfg:
     def __init__(self, aabb, plane_hw, line_len, n_comp_density, n_comp_app, step_size, near_far,
                  distance_scale, density_shift, density_act, weight_thres, n_samples, ndc, white_bg,
                  app_dim, mlp_kind, mlp_hidden, view_pe, fea_pe, view_pe_progress=1.0, fea_pe_progress=1.0,
-                 shade_impl="mfma"):
+                 shade_impl="mfma", alpha_mask=None):
         self.aabb = [float(v) for v in aabb]  # lo xyz, hi xyz
         self.plane_hw = [(int(h), int(w)) for h, w in plane_hw]
         self.line_len = [int(v) for v in line_len]
@@ -151,6 +151,8 @@ class RenderCfg:
         self.view_pe_progress = float(view_pe_progress)
         self.fea_pe_progress = float(fea_pe_progress)
         self.shade_impl = shade_impl
+        # (volume [z,y,x] float32 contiguous on the device, lo [3], inv [3]) or None; see AlphaGridMask
+        self.alpha_mask = alpha_mask
 
     def scene(self):
         s = JtScene()
@@ -177,11 +179,18 @@ class RenderCfg:
         s.fea_pe = self.fea_pe
         s.view_pe_progress = self.view_pe_progress
         s.fea_pe_progress = self.fea_pe_progress
+        if self.alpha_mask is not None:
+            vol, lo, inv = self.alpha_mask
+            for a in range(3):
+                s.mask_dims[a] = int(vol.shape[2 - a])
+                s.mask_lo[a] = float(lo[a])
+                s.mask_inv[a] = float(inv[a])
         return s
 
 
-def _factors_struct(dp, dl, ap, al):
+def _factors_struct(dp, dl, ap, al, alpha_volume=None):
     f = JtFactors()
+    f.alpha_volume = ptr(alpha_volume) if alpha_volume is not None else None
     for i in range(3):
         f.density_plane[i] = ptr(dp[i]) if dp is not None else None
         f.density_line[i] = ptr(dl[i]) if dl is not None else None
@@ -252,7 +261,7 @@ class RenderRays(torch.autograd.Function):
         sal = [factor_storage(p) for p in al]
         mlp_t = [t.detach().contiguous() for t in (basis, w1, b1, w2, b2, w3, b3)]
         scene = cfg.scene()
-        fac = _factors_struct(sdp, sdl, sap, sal)
+        fac = _factors_struct(sdp, sdl, sap, sal, cfg.alpha_mask[0] if cfg.alpha_mask is not None else None)
         st = _stream()
 
         f32 = dict(device=dev, dtype=torch.float32)
@@ -324,7 +333,7 @@ class RenderRays(torch.autograd.Function):
         dev = rays_o.device
         R = rays_o.shape[0]
         scene = cfg.scene()
-        fac = _factors_struct(sdp, sdl, sap, sal)
+        fac = _factors_struct(sdp, sdl, sap, sal, cfg.alpha_mask[0] if cfg.alpha_mask is not None else None)
         st = _stream()
         f32 = dict(device=dev, dtype=torch.float32)
         g_rgb = g_rgb.contiguous().float()
@@ -726,6 +735,19 @@ class RayGen(torch.autograd.Function):
 
 def ray_gen(pose, intr_inv, intr, ray_idx, image_w, ndc=False, ndc_near=1.0):
     return RayGen.apply(pose, intr_inv, intr, ray_idx, image_w, ndc, ndc_near)
+
+
+def dense_alpha(cfg, density_plane, density_line, xyz, length):
+    """alpha [n] = 1 - exp(-sigma(xyz) * length) at world points xyz [n,3] (BatBase.compute_alpha, batBase.py:27-41;
+    points the scene's alpha mask drops get 0)."""
+    sd = [factor_storage(p) for p in density_plane]
+    sl = [factor_storage(p) for p in density_line]
+    fac = _factors_struct(sd, sl, None, None, cfg.alpha_mask[0] if cfg.alpha_mask is not None else None)
+    xyz = xyz.detach().contiguous().float()
+    out = torch.empty(xyz.shape[0], device=xyz.device, dtype=torch.float32)
+    check(lib.jt_dense_alpha(cfg.scene(), fac, ptr(xyz), xyz.shape[0], float(length), ptr(out), _stream()),
+          "jt_dense_alpha")
+    return out
 
 
 def blur_images(images, taps):

@@ -246,11 +246,81 @@ class BAT_VMSplit(torch.nn.Module):
         self.density_plane, self.density_line = self.up_sampling_VM(self.density_plane, self.density_line, res_target)
         self.update_stepSize(res_target)
 
-    def updateAlphaMask(self, gridSize=(200, 200, 200)):
-        raise NotImplementedError("alpha-mask volume is SURVEY.md §8(f) N4 (never active in the BAT yamls)")
+    # ---- alpha-mask volume and AABB shrink ----------------------------------------
+    def _density_cfg(self):
+        """RenderCfg for the density-only entry points, in the state the last forward left (blur kernel, mask)."""
+        g = self.gridSize.tolist()
+        blur = getattr(self, "kernel_density", None) is not None
+        m = (lambda i: (g[MAT_MODE[i][0]], g[MAT_MODE[i][1]])) if blur else (lambda i: (g[MAT_MODE[i][1]], g[MAT_MODE[i][0]]))
+        return ops.RenderCfg(
+            aabb=self.aabb.view(-1).tolist(), plane_hw=[m(i) for i in range(3)],
+            line_len=[g[VEC_MODE[i]] for i in range(3)], n_comp_density=self.density_n_comp[0],
+            n_comp_app=self.app_n_comp[0], step_size=float(self.stepSize), near_far=tuple(self.near_far),
+            distance_scale=self.distance_scale, density_shift=self.density_shift,
+            density_act=_lib.JT_ACT_SOFTPLUS if self.fea2denseAct == "softplus" else _lib.JT_ACT_RELU,
+            weight_thres=self.rayMarch_weight_thres, n_samples=1, ndc=False, white_bg=False, app_dim=self.app_dim,
+            mlp_kind=self.renderModule.kind, mlp_hidden=self.featureC, view_pe=self.view_pe, fea_pe=self.fea_pe,
+            alpha_mask=self.alphaMask.kernel_args() if self.alphaMask is not None else None)
 
+    @torch.no_grad()
+    def compute_alpha(self, xyz_locs, length=1):
+        """BatBase.compute_alpha (batBase.py:27-41): with the blur kernel the last forward used."""
+        dP, dL = list(self.density_plane), list(self.density_line)
+        if getattr(self, "kernel_density", None) is not None:
+            dP, dL, _, _ = ops.blur_factors(self.kernel_density, self.kernel_density, dP, dL, list(self.app_plane),
+                                            list(self.app_line))
+        return ops.dense_alpha(self._density_cfg(), dP, dL, xyz_locs.reshape(-1, 3), float(length)).view(xyz_locs.shape[:-1])
+
+    @torch.no_grad()
+    def getDenseAlpha(self, gridSize=None):
+        """tensorBase.py:618-634."""
+        gridSize = self.gridSize.tolist() if gridSize is None else [int(v) for v in gridSize]
+        dev = self.density_plane[0].device  # the scene box itself is host state (scalars of the kernel calls)
+        samples = torch.stack(torch.meshgrid(torch.linspace(0, 1, gridSize[0]), torch.linspace(0, 1, gridSize[1]),
+                                             torch.linspace(0, 1, gridSize[2]), indexing="ij"), -1).to(dev)
+        aabb = self.aabb.to(dev)
+        dense_xyz = aabb[0] * (1 - samples) + aabb[1] * samples
+        alpha = self.compute_alpha(dense_xyz.view(-1, 3), self.stepSize).view(*gridSize)
+        return alpha, dense_xyz
+
+    @torch.no_grad()
+    def updateAlphaMask(self, gridSize=(200, 200, 200)):
+        """tensorBase.py:636-661: dense alpha -> 5^3 max-pool -> threshold -> mask volume; returns the box of the
+        kept voxels."""
+        gridSize = [int(v) for v in gridSize]
+        alpha, dense_xyz = self.getDenseAlpha(gridSize)
+        dense_xyz = dense_xyz.transpose(0, 2).contiguous()
+        alpha = alpha.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
+        ks = 5
+        alpha = F.max_pool3d(alpha, kernel_size=ks, padding=ks // 2, stride=1).view(gridSize[::-1])
+        alpha = (alpha >= self.alphaMask_thres).to(torch.float32)
+        self.alphaMask = AlphaGridMask(alpha.device, self.aabb, alpha)
+        valid_xyz = dense_xyz[alpha > 0.5]
+        return torch.stack((valid_xyz.amin(0), valid_xyz.amax(0)))
+
+    @torch.no_grad()
     def shrink(self, new_aabb):
-        raise NotImplementedError("AABB shrink is SURVEY.md §8(f) N4 (never active in the BAT yamls)")
+        """tensoRF.py:297-334: crop every factor to the texels covering new_aabb (channel-last storage kept)."""
+        new_aabb = new_aabb.detach().to(self.aabb.device, dtype=torch.float32)  # box arithmetic on the host, fp32
+        xyz_min, xyz_max = new_aabb
+        t_l, b_r = (xyz_min - self.aabb[0]) / self.units, (xyz_max - self.aabb[0]) / self.units
+        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
+        b_r = torch.stack([b_r, self.gridSize.to(b_r.device)]).amin(0)
+        for i in range(3):
+            v = VEC_MODE[i]
+            m0, m1 = MAT_MODE[i]
+            for lines, planes in ((self.density_line, self.density_plane), (self.app_line, self.app_plane)):
+                lines[i] = _channel_last_param(lines[i].data[..., t_l[v]:b_r[v], :].contiguous())
+                planes[i] = _channel_last_param(planes[i].data[..., t_l[m1]:b_r[m1], t_l[m0]:b_r[m0]].contiguous())
+        if not torch.all(self.alphaMask.gridSize.cpu() == self.gridSize.cpu()):
+            t_l_r, b_r_r = t_l / (self.gridSize - 1), (b_r - 1) / (self.gridSize - 1)
+            correct_aabb = torch.zeros_like(new_aabb)
+            correct_aabb[0] = (1 - t_l_r) * self.aabb[0] + t_l_r * self.aabb[1]
+            correct_aabb[1] = (1 - b_r_r) * self.aabb[0] + b_r_r * self.aabb[1]
+            new_aabb = correct_aabb
+        newSize = b_r - t_l
+        self.aabb = new_aabb
+        self.update_stepSize((newSize[0], newSize[1], newSize[2]))
 
     # ---- checkpoint extras (tensorBase.py:508-552) ------------------------------------------------
     def get_reset_kwargs(self):
@@ -349,10 +419,38 @@ class BAT_VMSplit(torch.nn.Module):
             density_act=_lib.JT_ACT_SOFTPLUS if self.fea2denseAct == "softplus" else _lib.JT_ACT_RELU,
             weight_thres=self.rayMarch_weight_thres, n_samples=S, ndc=ndc_ray, white_bg=wb, app_dim=self.app_dim,
             mlp_kind=self.renderModule.kind, mlp_hidden=self.featureC, view_pe=self.view_pe, fea_pe=self.fea_pe,
-            view_pe_progress=view_pe_progress, fea_pe_progress=fea_pe_progress, shade_impl=self.shade_impl)
+            view_pe_progress=view_pe_progress, fea_pe_progress=fea_pe_progress, shade_impl=self.shade_impl,
+            # empty-space samples are dropped only while the blur is off (batBase.py:76-82)
+            alpha_mask=self.alphaMask.kernel_args() if (self.alphaMask is not None and c2f_mode is None
+                                                         and c2f_parameter_density is None
+                                                         and c2f_parameter_color is None) else None)
         rgb, depth, opacity = ops.render_rays(cfg, center, ray_dir, jitter, zvals, dP, dL, aP, aL,
                                               self.basis_mat.weight, self.renderModule.weights())
         return rgb, depth, opacity
+
+
+class AlphaGridMask(torch.nn.Module):
+    """tensorBase.py:80-98: a 0/1 occupancy volume [1,1,gz,gy,gx] over its own box."""
+
+    def __init__(self, device, aabb, alpha_volume):
+        super().__init__()
+        self.device = device
+        self.aabb = aabb.to(device)
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invgridSize = 1.0 / self.aabbSize * 2
+        self.alpha_volume = alpha_volume.view(1, 1, *alpha_volume.shape[-3:]).to(device=device, dtype=torch.float32).contiguous()
+        self.gridSize = torch.LongTensor([alpha_volume.shape[-1], alpha_volume.shape[-2], alpha_volume.shape[-3]]).to(device)
+
+    def normalize_coord(self, xyz_sampled):
+        return (xyz_sampled - self.aabb[0]) * self.invgridSize - 1
+
+    def sample_alpha(self, xyz_sampled):
+        g = self.normalize_coord(xyz_sampled)
+        return F.grid_sample(self.alpha_volume, g.view(1, -1, 1, 1, 3), align_corners=True).view(-1)
+
+    def kernel_args(self):
+        """(volume [z,y,x], lo, inv) as the render kernels take them (JtScene.mask_*, JtFactors.alpha_volume)."""
+        return self.alpha_volume[0, 0], self.aabb[0].tolist(), self.invgridSize.tolist()
 
 
 def _average_kernel(t, kernel_size):

@@ -428,7 +428,7 @@ def mlp_weakview(cfg, mlp, feat, viewdirs, view_pe_progress=1.0, fea_pe_progress
 # ----------------------------------------------------------------------------------------------
 def render(cfg, params, center, ray_dir, N_samples, white_bg=True, jitter=None, ndc_ray=False,
            kernel_density=None, kernel_color=None, view_pe_progress=1.0, fea_pe_progress=1.0,
-           use_taps=False, return_aux=False):
+           use_taps=False, return_aux=False, alpha_mask=None):
     """rgb [R,3], depth [R], opacity [R] for rays (center, ray_dir) [R,3].
 
     `white_bg` is the already-resolved flag `white_bg or (is_train and coin<0.5)` (batBase.py:154);
@@ -446,6 +446,11 @@ def render(cfg, params, center, ray_dir, N_samples, white_bg=True, jitter=None, 
         dists = torch.cat([z[:, 1:] - z[:, :-1], torch.zeros_like(z[:, :1])], -1)
     R, S = valid.shape
     viewdirs = viewdirs.view(-1, 1, 3).expand(R, S, 3).detach()  # arch.shading.detach_viewdirs
+    if alpha_mask is not None and kernel_density is None and kernel_color is None:
+        # samples in empty space are dropped -- only while the blur is off (batBase.py:76-82)
+        keep = alpha_mask_sample(alpha_mask, xyz[valid].detach()) > 0
+        valid = valid.clone()
+        valid[valid.clone()] = keep
 
     sigma = torch.zeros(R, S, dtype=center.dtype, device=center.device)
     rgb = torch.zeros(R, S, 3, dtype=center.dtype, device=center.device)
@@ -639,6 +644,76 @@ def edge_masks(blurred, thresh=1.25, soft=False):
         else:
             out[sc] = (GG > GG.mean(dim=1, keepdim=True) * thresh).to(torch.uint8)
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# N4  alpha-mask volume, AABB shrink        tensorBase.py:80-98,618-661,703-726, batBase.py:27-41, tensoRF.py:297-334
+# ----------------------------------------------------------------------------------------------
+def alpha_mask_sample(alpha_mask, xyz):
+    """AlphaGridMask.sample_alpha (tensorBase.py:92-99): trilinear sample of the volume [D,H,W] = grid[::-1]
+    over its own box; alpha_mask = (volume, aabb [2,3])."""
+    vol, aabb = alpha_mask
+    g = (xyz - aabb[0]) * (2.0 / (aabb[1] - aabb[0])) - 1
+    return F.grid_sample(vol[None, None], g.view(1, -1, 1, 1, 3), align_corners=True).view(-1)
+
+
+def compute_alpha(cfg, params, xyz, length, alpha_mask=None, kernel=None):
+    """BatBase.compute_alpha (batBase.py:27-41): opacity of a step of `length` at arbitrary points."""
+    keep = torch.ones(xyz.shape[0], dtype=torch.bool) if alpha_mask is None else alpha_mask_sample(alpha_mask, xyz) > 0
+    sigma = torch.zeros(xyz.shape[0])
+    if keep.any():
+        feat = density_feature(cfg, params, normalize_coord(cfg, xyz[keep]), kernel, False)
+        sigma[keep] = feature2density(cfg, feat)
+    return 1 - torch.exp(-sigma * length)
+
+
+def dense_alpha(cfg, params, grid, alpha_mask=None, kernel=None):
+    """TensorBase.getDenseAlpha (tensorBase.py:618-634): alpha [g0,g1,g2] at the lattice points of the box."""
+    with torch.no_grad():
+        s = torch.stack(torch.meshgrid(torch.linspace(0, 1, grid[0]), torch.linspace(0, 1, grid[1]),
+                                       torch.linspace(0, 1, grid[2]), indexing="ij"), -1)
+        xyz = cfg.aabb[0] * (1 - s) + cfg.aabb[1] * s
+        alpha = compute_alpha(cfg, params, xyz.view(-1, 3), cfg.stepSize, alpha_mask, kernel).view(*grid)
+    return alpha, xyz
+
+
+def update_alpha_mask(cfg, params, grid, thres, alpha_mask=None, kernel=None):
+    """TensorBase.updateAlphaMask (tensorBase.py:636-661): ((volume [g2,g1,g0], aabb), new_aabb)."""
+    alpha, xyz = dense_alpha(cfg, params, grid, alpha_mask, kernel)
+    xyz = xyz.transpose(0, 2).contiguous()
+    alpha = alpha.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
+    alpha = F.max_pool3d(alpha, kernel_size=5, padding=2, stride=1).view(grid[2], grid[1], grid[0])
+    alpha = (alpha >= thres).float()
+    valid = xyz[alpha > 0.5]
+    return (alpha, cfg.aabb.clone()), torch.stack((valid.amin(0), valid.amax(0)))
+
+
+def shrink(cfg, params, new_aabb, mask_grid):
+    """TensorVMSplit.shrink (tensoRF.py:297-334): crop the factors to the texels covering new_aabb; returns the
+    new (cfg, params).  mask_grid: grid of the alpha volume the box came from (the box is snapped to the factor
+    texels when the two grids differ)."""
+    g = torch.tensor(cfg.gridSize)
+    t_l, b_r = (new_aabb[0] - cfg.aabb[0]) / cfg.units, (new_aabb[1] - cfg.aabb[0]) / cfg.units
+    t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
+    b_r = torch.stack([b_r, g]).amin(0)
+    out = {k: v for k, v in params.items()}
+    for grp in ("density", "app"):
+        planes, lines = [], []
+        for i in range(3):
+            v = VEC_MODE[i]
+            m0, m1 = MAT_MODE[i]
+            lines.append(params[grp + "_line"][i].detach()[..., t_l[v]:b_r[v], :].clone())
+            planes.append(params[grp + "_plane"][i].detach()[..., t_l[m1]:b_r[m1], t_l[m0]:b_r[m0]].clone())
+        out[grp + "_plane"], out[grp + "_line"] = planes, lines
+    if list(mask_grid) != cfg.gridSize:
+        tl_r, br_r = t_l / (g - 1), (b_r - 1) / (g - 1)
+        new_aabb = torch.stack([(1 - tl_r) * cfg.aabb[0] + tl_r * cfg.aabb[1], (1 - br_r) * cfg.aabb[0] + br_r * cfg.aabb[1]])
+    new_cfg = SceneCfg(new_aabb.reshape(-1).tolist(), (b_r - t_l).tolist(), cfg.near_far, step_ratio=cfg.step_ratio,
+                       density_shift=cfg.density_shift, distance_scale=cfg.distance_scale, fea2denseAct=cfg.fea2denseAct,
+                       rayMarch_weight_thres=cfg.rayMarch_weight_thres, shadingMode=cfg.shadingMode, view_pe=cfg.view_pe,
+                       fea_pe=cfg.fea_pe, ndc_near_plane=cfg.ndc_near_plane)
+    new_cfg.aabb = new_aabb.float()  # keep the exact fp32 box (tolist() round-trips through double exactly)
+    return new_cfg, out
 
 
 # ----------------------------------------------------------------------------------------------

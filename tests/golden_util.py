@@ -13,6 +13,7 @@ CASES = [
     "blender_train_blur", "blender_train_sharp", "blender_vis_blur", "blender_train_mid",
     "blender_train_mid_blur", "blender_train_dense", "blender_train_dense_blur",
     "blender_train_randrays", "llff_train_sharp", "llff_train_blur", "llff_train_thin_whitebg",
+    "blender_train_alphamask", "blender_train_shrunk",
 ]
 
 
@@ -44,6 +45,12 @@ class Fixture:
             for _, v in O.flat_params(p):
                 v.requires_grad_(True)
         return p
+
+    def alpha_mask(self, device="cpu"):
+        """(volume [D,H,W], aabb [2,3]) of the fixtures rendered with an alpha mask, else None."""
+        if not self.has("mask.alpha_volume"):
+            return None
+        return self.t("mask.alpha_volume", device), self.t("mask.aabb", device)
 
     def white_bg(self):
         m = self.meta
@@ -99,7 +106,7 @@ def replay_oracle(fx, use_taps=False, device="cpu", pin_rays=True):
                                     white_bg=fx.white_bg(), jitter=jitter, ndc_ray=m["ndc_ray"],
                                     kernel_density=kd, kernel_color=kc,
                                     view_pe_progress=m["view_pe_progress"], fea_pe_progress=m["fea_pe_progress"],
-                                    use_taps=use_taps, return_aux=True)
+                                    use_taps=use_taps, return_aux=True, alpha_mask=fx.alpha_mask(device))
     rgb = rgb.view(B, r, 3)
     out = dict(pose=pose, center=center_own, ray=ray_own, rgb=rgb, depth=depth.view(B, r, 1), opacity=acc.view(B, r, 1),
                kd=kd, kc=kc, aux=aux)

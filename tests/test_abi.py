@@ -31,13 +31,28 @@ def test_header_vs_ctypes_vs_library():
     assert so.jt_version() >= 1001
 
 
-def test_struct_layout_matches_header():
-    """JtScene is 4-byte fields only; its ctypes mirror must have the same size as the C struct
-    (3+3 floats, 9 ints, 2 ints, 5 floats, 1 int, 1 float, 8 ints, 2 floats = 34 words)."""
+def test_struct_layout_matches_header(tmp_path):
+    """The ctypes mirrors must have the size and field offsets the C compiler gives the structs of the header."""
+    import os
+    import subprocess
     from joint_tensorf_amd import _lib
-    assert ctypes.sizeof(_lib.JtScene) == 34 * 4
-    assert ctypes.sizeof(_lib.JtFactors) == 12 * 8
-    assert ctypes.sizeof(_lib.JtMlp) == 7 * 8
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "jt_render.h"\n'
+        "int main(void) {\n"
+        '  printf("%zu %zu %zu %zu\\n", sizeof(JtScene), sizeof(JtFactors), sizeof(JtMlp), sizeof(JtBlurItem));\n'
+        '  printf("%zu %zu %zu %zu %zu\\n", offsetof(JtScene, n_comp_density), offsetof(JtScene, fea_pe_progress),\n'
+        "         offsetof(JtScene, mask_dims), offsetof(JtScene, mask_inv), offsetof(JtFactors, alpha_volume));\n"
+        "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    sizes, offs = [list(map(int, l.split())) for l in subprocess.check_output([str(exe)]).decode().splitlines()]
+    assert sizes == [ctypes.sizeof(_lib.JtScene), ctypes.sizeof(_lib.JtFactors), ctypes.sizeof(_lib.JtMlp),
+                     ctypes.sizeof(_lib.JtBlurItem)]
+    assert offs == [_lib.JtScene.n_comp_density.offset, _lib.JtScene.fea_pe_progress.offset,
+                    _lib.JtScene.mask_dims.offset, _lib.JtScene.mask_inv.offset, _lib.JtFactors.alpha_volume.offset]
+    assert ctypes.sizeof(_lib.JtScene) == 43 * 4  # 4-byte fields only
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():

@@ -33,7 +33,11 @@ def build_scene(fx, device, shade_impl):
                         rayMarch_weight_thres=m["rayMarch_weight_thres"], shade_impl=shade_impl)
     sd = {k[len("param.nerf.tensorf."):]: fx.t(k) for k in fx.arrays if k.startswith("param.nerf.tensorf.")}
     missing, unexpected = tf.load_state_dict(sd, strict=True)
-    return tf.to(device)
+    tf = tf.to(device)
+    if fx.has("mask.alpha_volume"):  # fixtures rendered with an alpha mask
+        from joint_tensorf_amd.tensorf_repr import AlphaGridMask
+        tf.alphaMask = AlphaGridMask(device, fx.t("mask.aabb", device), fx.t("mask.alpha_volume", device))
+    return tf
 
 
 def replay_hip(fx, shade_impl, pin_rays=True, device="cuda"):

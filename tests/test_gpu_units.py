@@ -282,3 +282,40 @@ def test_upsample_volume_grid_vs_golden():
             np.testing.assert_allclose(l.detach().cpu().numpy(), d["up.line_out.%d" % i], atol=2e-6)
             # still channel-last storage behind the logical [1,C,H,W] shape
             assert p.permute(0, 2, 3, 1).is_contiguous() and l.permute(0, 2, 3, 1).is_contiguous()
+
+
+def test_alpha_mask_update_and_shrink_vs_golden():
+    """BAT_VMSplit.getDenseAlpha / updateAlphaMask / shrink against the reference fixture."""
+    from tests.test_gpu_parity import build_scene
+    fx = Fixture("blender_train_alphamask")
+    tf = build_scene(fx, DEV, "mfma")
+    tf.alphaMask = None
+    tf.alphaMask_thres = float(fx.arrays["mask.thres"])
+    grid = fx.arrays["mask.grid"].tolist()
+    alpha, _ = tf.getDenseAlpha(grid)
+    np.testing.assert_allclose(alpha.cpu().numpy(), fx.arrays["mask.dense_alpha"], atol=1e-7, rtol=5e-5)
+    new_aabb = tf.updateAlphaMask(tuple(grid))
+    vol = tf.alphaMask.alpha_volume[0, 0].cpu().numpy()
+    assert (vol != fx.arrays["mask.alpha_volume"]).mean() < 2e-3   # voxels within round-off of the threshold
+    np.testing.assert_allclose(new_aabb.cpu().numpy(), fx.arrays["mask.new_aabb"], atol=1e-6)
+    # masked points sample to zero through the mask as the reference's AlphaGridMask does
+    pts = torch.rand(500, 3, device=DEV) * 3 - 1.5
+    ref = O.alpha_mask_sample((torch.tensor(fx.arrays["mask.alpha_volume"]), torch.tensor(fx.arrays["mask.aabb"])), pts.cpu())
+    tf.alphaMask = type(tf.alphaMask)(DEV, fx.t("mask.aabb", DEV), fx.t("mask.alpha_volume", DEV))
+    np.testing.assert_allclose(tf.alphaMask.sample_alpha(pts).cpu().numpy(), ref.numpy(), atol=1e-6)
+    a_masked = tf.compute_alpha(pts, 0.1).cpu()
+    assert float(a_masked[ref <= 0].abs().max()) == 0.0 and float(a_masked[ref > 0].max()) > 0.0
+    # shrink with the reference's box: cropped channel-last factors, snapped box, grid
+    fs = Fixture("blender_train_shrunk")
+    tf.shrink(fx.t("mask.new_aabb", DEV))
+    assert tf.gridSize.tolist() == fs.meta["gridSize"]
+    np.testing.assert_allclose(tf.aabb.view(-1).cpu().numpy(), np.array(fs.meta["aabb"], np.float32), atol=1e-6)
+    assert abs(float(tf.stepSize) - fs.meta["stepSize"]) < 1e-7
+    assert tf.aabb.device.type == "cpu"
+    sd = tf.state_dict()
+    for k in fs.arrays:
+        if k.startswith("param.nerf.tensorf.") and ("plane" in k or "line" in k):
+            got = sd[k[len("param.nerf.tensorf."):]]
+            assert tuple(got.shape) == fs.arrays[k].shape, k
+            np.testing.assert_array_equal(got.cpu().numpy(), fs.arrays[k], err_msg=k)
+            assert got.permute(0, 2, 3, 1).is_contiguous(), k

@@ -163,3 +163,25 @@ def test_upsample_vm_known_answer():
     for i in range(3):
         assert torch.allclose(up_p[i], torch.tensor(d["up.plane_out.%d" % i]), atol=1e-6)
         assert torch.allclose(up_l[i], torch.tensor(d["up.line_out.%d" % i]), atol=1e-6)
+
+
+# ---- N4: alpha-mask volume and AABB shrink ---------------------------------------------------------------------
+def test_alpha_mask_update_and_shrink_golden():
+    fx = Fixture("blender_train_alphamask")
+    cfg, params = fx.cfg(), fx.params(requires_grad=False)
+    grid = fx.arrays["mask.grid"].tolist()
+    alpha, _ = O.dense_alpha(cfg, params, grid)
+    assert torch.allclose(alpha, fx.t("mask.dense_alpha"), atol=1e-7, rtol=2e-5)
+    (vol, aabb), new_aabb = O.update_alpha_mask(cfg, params, grid, float(fx.arrays["mask.thres"]))
+    assert (vol != fx.t("mask.alpha_volume")).float().mean() < 1e-3  # voxels within round-off of the threshold
+    assert torch.equal(aabb, fx.t("mask.aabb"))
+    assert torch.allclose(new_aabb, fx.t("mask.new_aabb"), atol=1e-6)
+    # shrink: the cropped factors, box and grid of the next fixture
+    fs = Fixture("blender_train_shrunk")
+    cfg2, p2 = O.shrink(cfg, params, fx.t("mask.new_aabb"), grid)
+    assert cfg2.gridSize == fs.meta["gridSize"]
+    assert torch.allclose(cfg2.aabb.view(-1), torch.tensor(fs.meta["aabb"]), atol=1e-6)
+    assert abs(float(cfg2.stepSize) - fs.meta["stepSize"]) < 1e-7
+    ref = fs.params(requires_grad=False)
+    for (n, a), (_, b) in zip(O.flat_params(p2), O.flat_params(ref)):
+        assert a.shape == b.shape and torch.equal(a, b), n

@@ -243,7 +243,7 @@ def state_np(graph):
 
 
 def run_case(bat, camera, opt, graph, var, mode, it, progress, out_path, llff=False, extra_meta=None,
-             torch_seed=None):
+             torch_seed=None, extra_arrays=None):
     import model.tensorf_repr.tensorBase as tB
     import model.tensorf_repr.batBase as bB
     import util
@@ -357,6 +357,8 @@ def run_case(bat, camera, opt, graph, var, mode, it, progress, out_path, llff=Fa
     )
     if extra_meta:
         meta.update(extra_meta)
+    if extra_arrays:
+        out.update(extra_arrays)
     import json
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(out_path, **out)
@@ -534,6 +536,40 @@ def gt_blur_case(bat, opt, out_path, n_views=5, seed=31):
     print("wrote", out_path, "scales", scales, "mask fractions", [float(masks[s].float().mean()) for s in scales])
 
 
+def mask_case(bat, camera, opt, graph, var, outdir, grid=(20, 20, 20), quantile=0.93):
+    """N4: alpha-mask volume, masked render and AABB shrink by the reference's own
+    TensorBase.updateAlphaMask / BatBase.forward / TensorVMSplit.shrink (tensorBase.py:618-661, batBase.py:76-82,
+    tensoRF.py:297-334).  The threshold is set so that the mask is non-trivial on this random field."""
+    tf = graph.nerf.tensorf
+    tf.kernel_density, tf.c2f_mode = None, None
+    with torch.no_grad():
+        # concentrate the content in the middle of the box so that the shrink has something to cut away
+        for l, pl in zip(tf.density_line, tf.density_plane):
+            l[:, :, :4] *= 0.02
+            l[:, :, 10:] *= 0.02
+            pl[:, :, :4] *= 0.02
+            pl[:, :, 10:] *= 0.02
+            pl[:, :, :, :4] *= 0.02
+            pl[:, :, :, 10:] *= 0.02
+        alpha, dense_xyz = tf.getDenseAlpha(grid)
+    tf.alphaMask_thres = float(torch.quantile(alpha.flatten(), quantile))
+    pre = dict(aabb=tf.aabb.clone(), gridSize=tf.gridSize.clone())
+    new_aabb = tf.updateAlphaMask(grid)
+    vol = tf.alphaMask.alpha_volume
+    print("alpha mask: thres %.3e, kept %.1f %%, new aabb %s" % (tf.alphaMask_thres, 100 * float(vol.mean()), new_aabb.tolist()))
+    arrays = {"mask.alpha_volume": vol[0, 0].numpy().copy(), "mask.aabb": tf.alphaMask.aabb.numpy().copy(),
+              "mask.dense_alpha": alpha.numpy().copy(), "mask.new_aabb": new_aabb.numpy().copy(),
+              "mask.thres": np.float32(tf.alphaMask_thres), "mask.grid": np.array(grid, np.int32)}
+    run_case(bat, camera, opt, graph, var, "train", it=8, progress=0.9,
+             out_path=os.path.join(outdir, "blender_train_alphamask.npz"), extra_arrays=arrays)
+    tf.shrink(new_aabb)
+    arrays2 = dict(arrays)
+    arrays2["shrink.aabb_before"] = pre["aabb"].numpy()
+    arrays2["shrink.gridSize_before"] = pre["gridSize"].numpy()
+    run_case(bat, camera, opt, graph, var, "train", it=10, progress=0.9,
+             out_path=os.path.join(outdir, "blender_train_shrunk.npz"), extra_arrays=arrays2)
+
+
 def known_answers(camera, kernels, bat, out_path):
     """Known-answer vectors for the small pure functions on the path."""
     import model.tensorf_repr.bateRF as bateRF
@@ -635,6 +671,9 @@ def main():
     eval_case(bat, camera, opt, graph, var, os.path.join(outdir, "blender_test_optim.npz"))
     # N3: 2-D blur cache of the GT images + edge masks (host torch ops in the reference, every 500 iterations)
     gt_blur_case(bat, opt, os.path.join(outdir, "gt_blur_edge.npz"))
+    # N4: alpha-mask volume, masked render, AABB shrink (last: it changes the scene's box and grid)
+    graph.train()
+    mask_case(bat, camera, opt, graph, var, outdir)
 
     # all_view_rand_rays variant (config C1 uses it)
     opt2 = make_opt(options, "bat_blender_VM", H=40, W=40, n_voxel_init=14 ** 3,
