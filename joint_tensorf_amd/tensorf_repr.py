@@ -333,10 +333,22 @@ class BAT_VMSplit(torch.nn.Module):
                 "volume_init_scale": self.volume_init_scale, "volume_init_bias": self.volume_init_bias}
 
     def save_param_state(self):
-        return {"tensorf_reset_kwargs": self.get_reset_kwargs()}
+        """tensorBase.py:531-545: reset kwargs + the alpha mask as packed bits."""
+        ckpt = {"tensorf_reset_kwargs": self.get_reset_kwargs()}
+        if self.alphaMask is not None:
+            vol = self.alphaMask.alpha_volume.bool().cpu().numpy()
+            ckpt.update({"alphaMask.shape": vol.shape, "alphaMask.mask": np.packbits(vol.reshape(-1)),
+                         "alphaMask.aabb": self.alphaMask.aabb.cpu()})
+        return ckpt
 
     def load_param_state(self, ckpt):
+        """tensorBase.py:547-552."""
         self.reset(**ckpt["tensorf_reset_kwargs"])
+        if "alphaMask.aabb" in ckpt:
+            n = int(np.prod(ckpt["alphaMask.shape"]))
+            vol = torch.from_numpy(np.unpackbits(ckpt["alphaMask.mask"])[:n].reshape(ckpt["alphaMask.shape"]))
+            dev = self.density_plane[0].device
+            self.alphaMask = AlphaGridMask(dev, ckpt["alphaMask.aabb"].to(dev), vol.to(device=dev, dtype=torch.float32))
 
     # ---- small pure helpers kept for API parity ---------------------------------------------------
     def normalize_coord(self, xyz_sampled):

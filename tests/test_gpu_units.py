@@ -319,3 +319,16 @@ def test_alpha_mask_update_and_shrink_vs_golden():
             assert tuple(got.shape) == fs.arrays[k].shape, k
             np.testing.assert_array_equal(got.cpu().numpy(), fs.arrays[k], err_msg=k)
             assert got.permute(0, 2, 3, 1).is_contiguous(), k
+
+
+def test_alpha_mask_checkpoint_roundtrip():
+    from tests.test_gpu_parity import build_scene
+    fx = Fixture("blender_train_alphamask")
+    tf = build_scene(fx, DEV, "mfma")
+    ck = tf.save_param_state()
+    assert ck["alphaMask.mask"].dtype == np.uint8 and tuple(ck["alphaMask.shape"])[-3:] == (20, 20, 20)
+    vol = tf.alphaMask.alpha_volume.clone()
+    tf.alphaMask = None
+    tf.load_param_state(ck)
+    assert torch.equal(tf.alphaMask.alpha_volume, vol)
+    assert torch.equal(tf.alphaMask.aabb.cpu(), fx.t("mask.aabb"))
