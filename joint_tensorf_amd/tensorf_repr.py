@@ -476,3 +476,14 @@ def _average_kernel(t, kernel_size):
     k1 = torch.zeros(kernel_size)
     k1[kernel_size // 2 - t1:kernel_size // 2 + t1 + 1] = 1 / (t1 * 2 + 1)
     return (t % 1.0) * k1 + (1 - t % 1.0) * k0
+
+
+class TensorVMSplit(BAT_VMSplit):
+    """The plain TensoRF scene (tensoRF.py:136-334, `arch.tensorf.model: TensorVMSplit`, known poses): the same
+    kernels with the coarse-to-fine blur arguments ignored (TensorBase.forward has none)."""
+
+    def forward(self, opt, center, ray_dir, white_bg=True, is_train=False, ndc_ray=False, N_samples=-1,
+                is_test_optim=False, view_pe_progress=1.0, fea_pe_progress=1.0, **_c2f_ignored):
+        return super().forward(opt, center, ray_dir, white_bg=white_bg, is_train=is_train, ndc_ray=ndc_ray,
+                               N_samples=N_samples, is_test_optim=is_test_optim, view_pe_progress=view_pe_progress,
+                               fea_pe_progress=fea_pe_progress)
