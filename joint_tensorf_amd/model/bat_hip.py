@@ -539,9 +539,21 @@ class Model(torch.nn.Module):
         pose, pose_GT = self.get_all_training_poses(opt, pose_GT)
         pose_aligned, self.graph.sim3 = self.prealign_cameras(opt, pose, pose_GT)
         error = self.evaluate_camera_alignment(opt, pose_aligned, pose_GT)
-        res = [self.evaluate_view(opt, Opt(dict(v))) for v in test_views]
-        return Opt(R_error=error.R, t_error=error.t, views=res,
-                   psnr=float(np.mean([r.psnr for r in res])) if res else float("nan"))
+        # held-out views are independent: with torch.distributed initialised every rank takes every world-th view
+        # (no collective on the render path); the per-view PSNRs are gathered at the end
+        import torch.distributed as dist
+        world, rank = (dist.get_world_size(), dist.get_rank()) if (dist.is_available() and dist.is_initialized()) else (1, 0)
+        test_views = list(test_views)
+        mine = list(range(rank, len(test_views), world))
+        res = [self.evaluate_view(opt, Opt(dict(test_views[i]))) for i in mine]
+        psnr = torch.full((len(test_views),), float("nan"), device=opt.device, dtype=torch.float64)
+        for i, r in zip(mine, res):
+            psnr[i] = r.psnr
+        if world > 1:
+            psnr = torch.nan_to_num(psnr, nan=0.0)
+            dist.all_reduce(psnr)
+        return Opt(R_error=error.R, t_error=error.t, views=res, psnr_per_view=psnr.tolist(),
+                   psnr=float(psnr.mean()) if len(test_views) else float("nan"))
 
     # ---- 2-D blur cache of the supervising images + edge masks ----------------------------------
     @torch.no_grad()
