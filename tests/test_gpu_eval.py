@@ -151,3 +151,18 @@ def test_gt_blur_cache_and_edge_masks():
     model.it = 1001
     model.select_supervision(opt, images)
     assert model.blurred_gt_cached_images is cache
+
+
+def test_evaluate_full_runs_end_to_end():
+    """camera alignment + per-view test-time optimisation + eval render + PSNR through Model.evaluate_full."""
+    from joint_tensorf_amd.options import Opt
+    fx = Fixture("blender_test_optim")
+    opt, model = _model(fx)
+    views = [Opt(idx=torch.arange(1, device="cuda"), pose=fx.t("in.test_pose", "cuda"), intr=fx.t("in.intr", "cuda"),
+                 intr_inv=fx.t("in.intr_inv", "cuda"), image=fx.t("in.test_image", "cuda")) for _ in range(2)]
+    np.random.seed(0)
+    out = model.evaluate_full(opt, views, fx.t("in.pose_gt", "cuda"))
+    assert out.R_error.shape == (3,) and out.t_error.shape == (3,)
+    assert len(out.views) == 2 and len(out.psnr_per_view) == 2 and np.isfinite(out.psnr)
+    assert 5.0 < out.psnr < 15.0  # random target image: ~9 dB
+    assert model.graph.sim3 is not None
