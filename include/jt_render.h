@@ -293,6 +293,24 @@ int jt_reg_losses_backward(const JtFactors* factors, const int32_t* plane_hw_lin
                            int n_comp_app, const float* g3, int with_tv_density, int with_tv_app,
                            const JtFactors* g_factors, int accumulate, float* scratch36, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dense Adam step over all tensors of an optimizer in one launch.  Replaces torch.optim.Adam.step of the
+ * optimizer built by tensorf.NeRF._get_optimizer (model/tensorf.py:463-478, betas (0.9, 0.99)):
+ *   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr / bias_correction1 * m / (sqrt(v) / sqrt(bias_correction2) + eps)
+ * p, g, m, v: n floats each in the same (dense) layout, 16-byte aligned; updated in place. */
+typedef struct JtAdamItem {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+  float lr;
+  float bias_correction1; /* 1 - beta1^step */
+  float bias_correction2; /* 1 - beta2^step */
+  int32_t pad_;
+} JtAdamItem;
+int jt_adam_step(const JtAdamItem* items, int n_items, float beta1, float beta2, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,12 @@ class JtBlurItem(ctypes.Structure):
                 ("n_taps", ctypes.c_int32)]
 
 
+class JtAdamItem(ctypes.Structure):
+    _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
+                ("n", ctypes.c_int64), ("lr", ctypes.c_float), ("bias_correction1", ctypes.c_float),
+                ("bias_correction2", ctypes.c_float), ("pad_", ctypes.c_int32)]
+
+
 # every symbol include/jt_render.h declares (tests/test_abi.py checks header <-> this table <-> .so)
 P = ctypes.c_void_p
 I = ctypes.c_int
@@ -78,6 +84,7 @@ SIGNATURES = {
     "jt_render_loss_backward": (I, [P, P, P, P, I, I, I, F, F, P, P, P, P]),
     "jt_reg_losses_forward": (I, [FP, P, I, I, I, I, P, P, P]),
     "jt_reg_losses_backward": (I, [FP, P, I, I, P, I, I, FP, I, P, P]),
+    "jt_adam_step": (I, [P, I, F, F, F, P]),
     "jt_dense_alpha": (I, [SP, FP, P, ctypes.c_long, F, P, P]),
     "jt_blur_batch_forward": (I, [P, I, P]),
     "jt_blur_batch_backward": (I, [P, I, P]),

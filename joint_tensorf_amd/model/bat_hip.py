@@ -114,10 +114,12 @@ class NeRF(torch.nn.Module):
             self.lr_basis, self.lr_index = lr_basis, lr_index
         groups = self.tensorf.get_optparam_groups(self.lr_index, self.lr_basis)
         if opt.optim.algo == "Adam":
-            # same update rule as the reference's torch.optim.Adam(betas=(0.9, 0.99)) (model/tensorf.py:474-475);
-            # fused=True runs it as one multi-tensor kernel instead of ~8 passes over the 123 MB of factors
-            fused = str(opt.device).startswith("cuda")
-            return torch.optim.Adam(groups, betas=(0.9, 0.99), fused=fused)
+            # same update rule, state and param-group interface as the reference's torch.optim.Adam(betas=(0.9,
+            # 0.99)) (model/tensorf.py:474-475); on the GPU all tensors are stepped by one HIP launch (optim.VMAdam)
+            if str(opt.device).startswith("cuda"):
+                from ..optim import VMAdam
+                return VMAdam(groups, betas=(0.9, 0.99))
+            return torch.optim.Adam(groups, betas=(0.9, 0.99))
         return getattr(torch.optim, opt.optim.algo)(groups)
 
     def update_schedule(self, opt, it):

@@ -332,3 +332,41 @@ def test_alpha_mask_checkpoint_roundtrip():
     tf.load_param_state(ck)
     assert torch.equal(tf.alphaMask.alpha_volume, vol)
     assert torch.equal(tf.alphaMask.aabb.cpu(), fx.t("mask.aabb"))
+
+
+def test_vmadam_matches_torch_adam():
+    """optim.VMAdam (one HIP launch for all tensors) against torch.optim.Adam: channel-last factor parameters, odd
+    sizes, two lr groups, lr changes between steps, a parameter without gradient, state-dict interchange."""
+    from joint_tensorf_amd.optim import VMAdam
+    from joint_tensorf_amd.tensorf_repr import _channel_last_param
+    g = torch.Generator().manual_seed(0)
+    shapes = [(1, 16, 9, 7), (1, 48, 5, 1), (27, 144), (64,), (3,), (5, 5)]
+    base = [torch.randn(*s, generator=g) for s in shapes]
+    ref_p = [torch.nn.Parameter(b.clone()) for b in base]
+    hip_p = [_channel_last_param(b.clone().to(DEV)) if b.dim() == 4 else torch.nn.Parameter(b.clone().to(DEV)) for b in base]
+    groups = lambda ps: [dict(params=ps[:2], lr=0.02), dict(params=ps[2:], lr=1e-3)]
+    ref = torch.optim.Adam(groups(ref_p), betas=(0.9, 0.99))
+    hip = VMAdam(groups(hip_p), betas=(0.9, 0.99))
+    for step in range(6):
+        for i, (a, b) in enumerate(zip(ref_p, hip_p)):
+            if i == 5 and step % 2 == 0:
+                a.grad = b.grad = None  # a parameter that sits a step out keeps its own step count
+                continue
+            gr = torch.randn(a.shape, generator=g) * (10.0 ** (step - 3))
+            a.grad = gr.clone()
+            b.grad = gr.clone().to(DEV)  # contiguous gradient for a channel-last parameter: re-laid out by step()
+        ref.step()
+        hip.step()
+        for grp_r, grp_h in zip(ref.param_groups, hip.param_groups):
+            grp_r["lr"] *= 0.97
+            grp_h["lr"] *= 0.97
+        for i, (a, b) in enumerate(zip(ref_p, hip_p)):
+            np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().numpy(), rtol=2e-6, atol=2e-7,
+                                       err_msg="step %d tensor %d %s" % (step, i, tuple(a.shape)))
+    sd = hip.state_dict()
+    ref2 = torch.optim.Adam(groups(ref_p), betas=(0.9, 0.99))
+    ref2.load_state_dict({"state": {k: {kk: (vv.cpu() if torch.is_tensor(vv) else vv) for kk, vv in v.items()}
+                                    for k, v in sd["state"].items()}, "param_groups": sd["param_groups"]})
+    assert float(ref2.state[ref_p[0]]["step"]) == 6.0
+    m_ref = ref.state[ref_p[0]]["exp_avg"].numpy()
+    np.testing.assert_allclose(ref2.state[ref_p[0]]["exp_avg"].numpy(), m_ref, rtol=2e-6, atol=1e-7 * np.abs(m_ref).max())
