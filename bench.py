@@ -361,7 +361,7 @@ def main():
                     "app": float(sum(p.double().abs().sum() for p in tf.app_plane)),
                     "mlp": float(sum(p.double().abs().sum() for p in tf.renderModule.weights())),
                     "se3": float(model.graph.se3_refine.weight.double().abs().sum())}
-        if world == 1 and not args.no_roofline:
+        if not args.no_roofline:  # single-launch probe on rank 0 (independent of N)
             try:
                 from joint_tensorf_amd.options import Opt
                 out["roofline"] = measure_roofline(model, opt, Opt(dict(var_all)))
@@ -373,6 +373,7 @@ def main():
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()  # rank 0 may still be probing / printing
         dist.destroy_process_group()
 
 
