@@ -2,9 +2,6 @@
 // and their backward.  One 64-lane wavefront owns one ray; lanes stride over the ray's samples so
 // the transmittance product is a wave prefix scan with a carry between 64-sample chunks.
 #include "jt_common.h"
-#ifdef JT_EXP_DRY
-#define JT_FLUSH_COND(x) ((x) == 12345.678f)
-#endif
 #include "jt_walk.h"
 
 namespace jt {

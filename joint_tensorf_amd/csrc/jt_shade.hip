@@ -16,9 +16,6 @@
 #include <cstdlib>
 
 #include "jt_common.h"
-#ifdef JT_EXP_DRY
-#define JT_FLUSH_COND(x) ((x) == 12345.678f)
-#endif
 #include "jt_walk.h"
 
 namespace jt {
