@@ -474,15 +474,16 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
 // =================================================================================================
 // backward
 // =================================================================================================
-// Per tile of 32 samples a wave (1) recomputes the forward, (2) walks the MLP backwards with the same
+// Per tile of 32 samples a wave (1) reads back what the training forward left in the tile's records (basis
+// output, ReLU sign words, sample coordinates), (2) walks the MLP backwards with the same
 // transposed MFMA chain (the gradient w.r.t. a layer's input comes out in exactly the register layout the
 // forward consumed, so the chain rule through ReLU / positional encoding is lane-local), (3) turns the
 // feature gradient into per-channel product gradients (basis_mat^T), hands them through a small LDS tile
 // to a channel-parallel scatter that walks the samples of the tile in ray order and accumulates the four
 // plane corners / two line taps in registers, flushing a texel with ONE float atomic per channel only
 // when the walk leaves it (samples are half a voxel apart, so consecutive samples share texels), and
-// (4) leaves sample-major records (layer inputs / pre-activation gradients) for the weight-gradient
-// kernel k_wgrad, which is a skinny GEMM over the sample axis on the same MFMA instruction.
+// (4) adds the pre-activation gradients to the tile's records for the weight-gradient kernel k_wgrad,
+// which is a skinny GEMM over the sample axis on the same MFMA instruction.
 
 // LDS hand-off between the lanes of ONE wave: the LDS executes a wave's instructions in order, so it is
 // enough to stop the compiler from moving LDS accesses across this point and to wait for the LDS queue
@@ -490,28 +491,6 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
 __device__ inline void wave_lds_sync() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-}
-
-// rows = tile*32 + rowmap(r,h), column = sample j  ->  tp[row][j]
-template <int NT>
-__device__ inline void tp_write(float* tp, const f32x16* v, int j, int h) {
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tp[(t * 32 + rowmap(r, h)) * 33 + j] = v[t][r];
-}
-
-// rec[(e0+s)*ld + col] = tp[col][s] for the tile's live samples; 256-byte contiguous row pieces
-__device__ inline void tp_store_rows(const float* tp, float* rec, size_t ld, int ncols, int e0, int nlive, int lane) {
-  if (nlive < 0) return;  // ablation switch (profiling only)
-  if (nlive == 32) {       // full tile: all 32 row stores issued back to back
-#pragma unroll 4
-    for (int sidx = 0; sidx < 32; ++sidx)
-      for (int col = lane; col < ncols; col += 64) rec[(size_t)(e0 + sidx) * ld + col] = tp[col * 33 + sidx];
-    return;
-  }
-  for (int sidx = 0; sidx < nlive; ++sidx)
-    for (int col = lane; col < ncols; col += 64) rec[(size_t)(e0 + sidx) * ld + col] = tp[col * 33 + sidx];
 }
 
 // ---- channel-parallel scatter of one plane's product gradients ------------------------------------------
