@@ -299,7 +299,7 @@ class RenderRays(torch.autograd.Function):
             ctx.prod = prod
         else:
             mlp = _mlp_struct(*mlp_t)
-            if any(ctx.needs_input_grad):
+            if getattr(cfg, "grad_enabled", True) and any(ctx.needs_input_grad):
                 # training: the forward leaves the layer inputs of every shaded sample in the (persistent)
                 # workspace; the backward consumes them instead of gathering / evaluating the chain again
                 nbytes = lib.jt_shade_workspace_bytes(scene, cap)
@@ -443,6 +443,9 @@ class RenderRays(torch.autograd.Function):
 def render_rays(cfg, rays_o, rays_d, jitter, zvals, density_plane, density_line, app_plane, app_line, basis,
                 mlp_params):
     """mlp_params = (w1, b1, w2, b2, w3, b3)."""
+    # inside Function.forward grad mode is always off and needs_input_grad only mirrors requires_grad: whether a
+    # backward can follow (=> the forward must leave its records) is decided here
+    cfg.grad_enabled = torch.is_grad_enabled()
     return RenderRays.apply(cfg, rays_o, rays_d, jitter, zvals, *density_plane, *density_line, *app_plane,
                             *app_line, basis, *mlp_params)
 
