@@ -418,7 +418,7 @@ constexpr int kWalkRecW = 3 * kRecWords + 4;  // per sample: three plane records
 __device__ inline int sel3(int i, int a, int b, int c) { return i == 0 ? a : (i == 1 ? b : c); }
 
 template <int CD>
-__global__ __launch_bounds__(256) void k_march_bwd_walk(Dev D, JtFactors G, const float* __restrict__ rays_o,
+__global__ __launch_bounds__(256, 4) void k_march_bwd_walk(Dev D, JtFactors G, const float* __restrict__ rays_o,
                                                         const float* __restrict__ rays_d,
                                                         const float* __restrict__ jitter,
                                                         const float* __restrict__ zvals,
