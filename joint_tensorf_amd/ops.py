@@ -820,7 +820,9 @@ class KernelProbe:
         offset = torch.empty(R + 1, device=dev, dtype=torch.int32)
         sidx = torch.empty(R, S, device=dev, dtype=torch.int16)
         opacity, depth = torch.empty(R, **f32), torch.empty(R, **f32)
-        check(lib.jt_march_forward(scene, fac, ptr(self.o), ptr(self.d), ptr(self.jitter), None, R, ptr(sigma_feat),
+        # NDC rays share one row of z values (sample_ray_ndc); the probe takes the un-jittered row
+        zv = torch.linspace(cfg.near_far[0], cfg.near_far[1], S, **f32) if cfg.ndc else None
+        check(lib.jt_march_forward(scene, fac, ptr(self.o), ptr(self.d), ptr(self.jitter), ptr(zv), R, ptr(sigma_feat),
                                    ptr(weight), ptr(tmin), ptr(count), ptr(offset), ptr(sidx), ptr(opacity),
                                    ptr(depth), st), "jt_march_forward")
         n = int(offset[R].item())
@@ -847,11 +849,11 @@ class KernelProbe:
         nbytes = lib.jt_shade_workspace_bytes(scene, max(n, 1))
         ws = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8)
         t_inf = timed(lambda: check(lib.jt_shade_forward(
-            scene, fac, mlp, ptr(self.o), ptr(self.d), ptr(self.jitter), None, ptr(tmin), ptr(offset), R, ptr(eray),
+            scene, fac, mlp, ptr(self.o), ptr(self.d), ptr(self.jitter), ptr(zv), ptr(tmin), ptr(offset), R, ptr(eray),
             ptr(esmp), ptr(vdir), ptr(rgb_s), n, None, 0, 0, st), "jt_shade_forward"))
         # training forward: also leaves the layer-input records for the backward in the workspace
         t_fwd = timed(lambda: check(lib.jt_shade_forward(
-            scene, fac, mlp, ptr(self.o), ptr(self.d), ptr(self.jitter), None, ptr(tmin), ptr(offset), R, ptr(eray),
+            scene, fac, mlp, ptr(self.o), ptr(self.d), ptr(self.jitter), ptr(zv), ptr(tmin), ptr(offset), R, ptr(eray),
             ptr(esmp), ptr(vdir), ptr(rgb_s), n, ptr(ws), nbytes, 0, st), "jt_shade_forward"))
         # one backward launch = one chunk of shaded samples
         nb = min(n, self.CHUNK)
@@ -862,7 +864,7 @@ class KernelProbe:
         gm = _mlp_struct(*gm_t)
         g_xyz = torch.empty(max(n, 1), 3, **f32)
         t_bwd = timed(lambda: check(lib.jt_shade_backward(
-            scene, fac, mlp, ptr(self.o), ptr(self.d), ptr(self.jitter), None, ptr(tmin), ptr(offset), R, ptr(eray),
+            scene, fac, mlp, ptr(self.o), ptr(self.d), ptr(self.jitter), ptr(zv), ptr(tmin), ptr(offset), R, ptr(eray),
             ptr(esmp), ptr(vdir), ptr(rgb_s), ptr(g_rgb_s), gfac, gm, ptr(g_xyz), nb, ptr(ws), nbytes, 1, st, None,
             None, None), "jt_shade_backward"))
         peak = 8000.0
