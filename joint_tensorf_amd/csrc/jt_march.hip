@@ -428,7 +428,10 @@ __global__ __launch_bounds__(256, 4) void k_march_bwd_walk(Dev D, JtFactors G, c
                                                         const int* __restrict__ nvalid, int runs_per_ray,
                                                         float* __restrict__ g_rays_o, float* __restrict__ g_rays_d) {
   constexpr int NCH = (CD + 15) / 16;
-  __shared__ __align__(16) float s_rec[16][kWalkSub * kWalkRecW];
+  // + 16 words per group: the four groups of a wave read their own records in the same instruction, and a group
+  // stride that is a multiple of the 64 LDS banks would put all four on the same banks (measured: 17 % of the
+  // kernel's CU cycles in bank-conflict stalls)
+  __shared__ __align__(16) float s_rec[16][kWalkSub * kWalkRecW + 16];
   const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const long item = (long)blockIdx.x * 16 + grp;
   const int ray = (int)(item / runs_per_ray);
