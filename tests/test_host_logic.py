@@ -1,0 +1,101 @@
+"""CPU tests of the host side (no GPU needed): option loading, the grid / sample-count schedule of both BAT yamls
+against the stage tables SURVEY.md 8(d) reproduced from the reference, the ray lattice, the blur schedule, and that
+the product path refuses to run without a GPU instead of falling back."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tensorf_oracle as O
+
+
+def _opt(name, **over):
+    from joint_tensorf_amd.options import make_options
+    return make_options(name, device="cpu", **over)
+
+
+def test_options_inheritance_and_overrides():
+    b = _opt("bat_blender_VM")
+    l = _opt("bat_llff_VM_MLP")
+    assert b.max_iter == 40000 and l.max_iter == 50000
+    assert l.arch.shading.model == "MLP_Fea_WeakView" and b.arch.shading.model == "MLP_Fea"
+    assert l.arch.tensorf.density_components == [16, 16, 16]          # inherited through _parent_
+    assert l.arch.tensorf.color_components == [20, 20, 20] and b.arch.tensorf.color_components == [48, 48, 48]
+    assert l.camera.ndc and not b.camera.ndc and (l.H, l.W) == (480, 640)
+    o = _opt("bat_blender_VM", data=dict(image_size=[40, 50]), nerf=dict(n_rays=96))
+    assert (o.H, o.W) == (40, 50) and o.nerf.n_rays == 96 and o.nerf.sample_intvs == 1000
+
+
+@pytest.mark.parametrize("name,table", [
+    ("bat_blender_VM", [([64, 64, 64], 221), ([101, 101, 101], 349), ([159, 159, 159], 550), ([252, 252, 252], 872),
+                        ([400, 400, 400], 1000)]),
+    ("bat_llff_VM_MLP", [([48, 53, 48], 287), ([96, 107, 96], 576), ([192, 214, 192], 1000), ([385, 429, 385], 1000),
+                         ([771, 859, 771], 1000)]),
+])
+def test_grid_schedule_matches_the_reference_stage_table(name, table):
+    """resolution and samples per ray of every grid stage, walked through
+    NeRF.update_schedule exactly as the training loop does (upsample, optimizer rebuild, sample count)."""
+    from joint_tensorf_amd.model import bat_hip
+    opt = _opt(name)
+    # shrink only the channel counts' memory: the schedule depends on n_voxels and the box, not on the tensors
+    nerf = bat_hip.NeRF(opt)
+    optim = [nerf._get_optimizer(opt)]
+    nerf.get_current_optimizer = lambda: optim[0]
+    nerf.register_new_optimizer = lambda o: optim.__setitem__(0, o)
+    got = [(nerf.tensorf.gridSize.tolist(), nerf.n_samples)]
+    for it in list(opt.train_schedule.upsample_iters):
+        if max(table[len(got)][0]) > 260:
+            break  # the largest grids are GBs of host memory: checked through the formulas below instead
+        nerf.update_schedule(opt, it)
+        got.append((nerf.tensorf.gridSize.tolist(), nerf.n_samples))
+        assert len(optim[0].param_groups) == 6
+    for (g, s), (eg, es) in zip(got, table):
+        assert g == eg and s == es, (g, s, eg, es)
+    # all stages through the same two formulas the schedule uses (model/tensorf.py:449-461)
+    n_list = torch.round(torch.exp(torch.linspace(np.log(opt.train_schedule.n_voxel_init),
+                                                  np.log(opt.train_schedule.n_voxel_final), len(table)))).long().tolist()
+    scale = [1.0, 1.0, 1.0]
+    for i, (eg, es) in enumerate(table):
+        sc = opt.train_schedule.resolution_scale_init if i == 0 else scale
+        res = O.find_resolution(opt.data.scene_bbox, n_list[i], sc)
+        assert res == eg and O.find_n_samples(res, opt.nerf.step_ratio, opt.nerf.sample_intvs) == es
+
+
+def test_ray_lattice_counts():
+    """model/nerf.py:655-673: 2048 rays over 100 Blender views -> step 90 -> 16-25 pixels per view."""
+    counts = set()
+    for ox in (0, 39, 40, 89):
+        for oy in (0, 39, 40, 89):
+            idx, step, gh, gw = O.rand_grid_ray_idx(400, 400, 2048, 100, ox, oy)
+            assert step == 90 and len(idx) == gh * gw
+            counts.add(len(idx) * 100)
+    assert min(counts) == 1600 and max(counts) == 2500
+    idx, step, _, _ = O.rand_grid_ray_idx(480, 640, 4096, 18, 0, 0)
+    assert step == 37 and 3672 <= len(idx) * 18 <= 4212
+
+
+def test_blur_schedule_switches_off_at_the_yaml_progress():
+    from joint_tensorf_amd.model.bat_hip import interp_schedule
+    opt = _opt("bat_blender_VM")
+    assert interp_schedule(0.0, opt.c2f_schedule_density) == pytest.approx(0.3)
+    assert interp_schedule(0.1, opt.c2f_schedule_density) == pytest.approx(0.15)
+    assert abs(interp_schedule(0.3, opt.c2f_schedule_density)) < 1e-9 and interp_schedule(0.9, opt.c2f_schedule_density) == 0.0
+    assert interp_schedule(0.3, opt.c2f_schedule_density) < 0.001  # under the cut-off of model/tensorf.py:208-220
+    assert O.interp_schedule(0.25, opt.c2f_schedule_density) == pytest.approx(interp_schedule(0.25, opt.c2f_schedule_density))
+
+
+def test_product_path_refuses_to_run_without_a_gpu():
+    """No CPU fallback: host tensors are rejected before any kernel argument is built."""
+    from joint_tensorf_amd import _lib, ops
+    with pytest.raises(_lib.JtError):
+        _lib.ptr(torch.zeros(4))
+    opt = _opt("bat_blender_VM", data=dict(image_size=[8, 8]), train_schedule=dict(n_voxel_init=8 ** 3))
+    from joint_tensorf_amd.model import bat_hip
+    nerf = bat_hip.NeRF(opt)
+    o = torch.zeros(3, 3)
+    d = torch.tensor([[0.0, 0.0, 1.0]]).repeat(3, 1)
+    with pytest.raises((AssertionError, RuntimeError, _lib.JtError)):
+        nerf.tensorf(opt, o, d, white_bg=True, is_train=False, N_samples=8)
+    with pytest.raises(RuntimeError):
+        nerf.tensorf.density_L1()
