@@ -107,9 +107,17 @@ def data_parallel_world():
 
 
 def factor_storage(p):
-    """logical [1,C,H,W] -> contiguous [H,W,C] tensor (no copy if p is stored channel-last)."""
+    """logical [1,C,H,W] -> contiguous [H,W,C] tensor (no copy if p is stored channel-last).  For a Parameter the
+    view is remembered on the object (three tensor constructions per call otherwise, ~40 calls per iteration on a
+    host-bound path); it is dropped as soon as the parameter's storage or shape is not what it was."""
+    c = p.__dict__.get("_jt_cl") if isinstance(p, torch.nn.Parameter) else None
+    if c is not None and c[0] == p.data_ptr() and c[1] == p.shape:
+        return c[2]
     x = p.detach()[0].permute(1, 2, 0)
-    return x if x.is_contiguous() else x.contiguous()
+    x = x if x.is_contiguous() else x.contiguous()
+    if isinstance(p, torch.nn.Parameter) and x.data_ptr() == p.data_ptr():
+        p.__dict__["_jt_cl"] = (p.data_ptr(), p.shape, x)
+    return x
 
 
 def factor_logical(x):
