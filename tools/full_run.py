@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""The whole bat_blender_VM training schedule on the synthetic scene, start to finish: every grid stage and
+upsampling (optimizer rebuilds), the blur schedule, the 2-D supervision cache refreshed every 500 iterations, edge
+masks on alternate iterations until 8000, pose Adam + scheduler.  Reports wall time per schedule segment; asserts a
+finite loss throughout.  usage: python tools/full_run.py [--max-iter N] [--config bat_blender_VM]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="bat_blender_VM")
+    ap.add_argument("--max-iter", type=int, default=0, help="stop early (0 = the yaml's max_iter)")
+    args = ap.parse_args()
+    from joint_tensorf_amd.model import bat_hip
+    from joint_tensorf_amd.options import make_options, Opt
+    from joint_tensorf_amd.synthetic import make_views
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    opt = make_options(args.config, device=dev)
+    n_views = int(opt.data.num_views)
+    model = bat_hip.Model(opt)
+    model.build_networks(opt, n_views=n_views)
+    model.setup_optimizer(opt)
+    views = make_views(opt, n_views, seed=0, device=dev)
+    last = args.max_iter or int(opt.max_iter)
+    marks = sorted(set([0] + [u for u in opt.train_schedule.upsample_iters] + [int(0.3 * opt.max_iter), last]))
+    marks = [m for m in marks if m <= last]
+    seg, t_seg, it_seg = [], time.perf_counter(), 0
+    worst = 0.0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter()
+    for it in range(last):
+        if it < opt.train_schedule.change_n_rays_after_n_iters:
+            opt.nerf.n_rays = opt.train_schedule.n_rays_init
+        else:
+            opt.nerf.n_rays = opt.train_schedule.n_rays_rest
+        images, masks, sc = model.select_supervision(opt, views.image)      # model/nerf.py:172-176,209-227
+        var = Opt(dict(views))
+        var.image, var.train_edge_masks = images, masks
+        loss = model.train_iteration(opt, var)
+        model.after_iteration(opt, it)
+        if (it + 1) in marks or (it + 1) % 2000 == 0:
+            torch.cuda.synchronize()
+            lv = float(loss.all)
+            assert np.isfinite(lv), (it, lv)
+            worst = max(worst, lv)
+        if (it + 1) in marks:
+            now = time.perf_counter()
+            tf = model.graph.nerf.tensorf
+            seg.append(dict(iters="%d-%d" % (it_seg, it + 1), grid=tf.gridSize.tolist(), S=model.graph.nerf.n_samples,
+                            seconds=round(now - t_seg, 2), ms_per_iter=round((now - t_seg) / (it + 1 - it_seg) * 1e3, 3),
+                            loss=round(float(loss.all), 5)))
+            print(json.dumps(seg[-1]), flush=True)
+            t_seg, it_seg = now, it + 1
+    torch.cuda.synchronize()
+    print(json.dumps(dict(total_seconds=round(time.perf_counter() - t_all, 1), iterations=last,
+                          peak_memory_GB=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), max_loss_seen=round(worst, 4))))
+
+
+if __name__ == "__main__":
+    main()
