@@ -49,13 +49,18 @@ def parse():
     return ap.parse_args()
 
 
+# JT_FORCE_DIST=1 under `torch.distributed.run --nproc-per-node 1`: a process group of ONE rank on RCCL, all
+# collectives issued -- the functional check of the N > 1 code path that a one-GPU box allows
+FORCE_DIST = os.environ.get("JT_FORCE_DIST") == "1"
+
+
 def setup_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("JT_BENCH_SINGLE_DEVICE") == "1":
         local = 0  # functional test of the N > 1 path on a one-GPU box (with JT_DIST_BACKEND=gloo)
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         import torch.distributed as dist
         torch.cuda.set_device(local)
         backend = os.environ.get("JT_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
@@ -101,15 +106,15 @@ OVERLAP = os.environ.get("JT_DIST_OVERLAP", "1") != "0"
 
 
 def allreduce_grads(model, world):
-    if world == 1:
+    if world == 1 and not FORCE_DIST:
         return
     from joint_tensorf_amd import dist as jdist
     if OVERLAP:
         # the renderer's backward has already reduced the scene gradients (ops.set_data_parallel); what left
         # through the rays -- the pose refinements -- is reduced here
-        jdist.allreduce_gradients([model.graph.se3_refine.weight], world)
+        jdist.allreduce_gradients([model.graph.se3_refine.weight], world, force=FORCE_DIST)
     else:
-        jdist.allreduce_gradients(list(model.graph.parameters()), world)
+        jdist.allreduce_gradients(list(model.graph.parameters()), world, force=FORCE_DIST)
 
 
 def cpu_baseline(opt_name, seconds_budget=24.0):
@@ -233,15 +238,18 @@ def main():
         opt.nerf.n_rays = args.n_rays
     n_views = int(opt.data.num_views)
     model = build_model(opt, it0, n_views)
-    if world > 1 and OVERLAP:
+    if (world > 1 or FORCE_DIST) and OVERLAP:
         from joint_tensorf_amd import ops as jops
-        jops.set_data_parallel(world)
+        jops.set_data_parallel(world, force=FORCE_DIST)
         model.render_loss_scale = 1.0 / world
     var_all = make_views(opt, n_views, seed=0, device=dev)
     nerf = model.graph.nerf
     res, S = nerf.resolution, nerf.n_samples
-    # per-rank lattice offsets differ (different pixels per GPU); everything else is shared
-    lattice_rng = np.random.RandomState(1000 + rank)
+    # the lattice draw is SHARED by all ranks; each rank shifts it inside the draw's class (dist.rank_lattice_offset):
+    # different pixels per GPU, the same ray count on every GPU in every iteration (no straggler at the all-reduce)
+    lattice_rng = np.random.RandomState(1000)
+    if world > 1:
+        model.graph.lattice_rank = (rank, world)
     if args.probe_only:
         from joint_tensorf_amd.options import Opt
         print(json.dumps(measure_roofline(model, opt, Opt(dict(var_all)), reps=10)))
@@ -291,7 +299,7 @@ def main():
         rays_total += var.rgb.shape[0] * var.rgb.shape[1]
 
     def barrier():
-        if world > 1:
+        if world > 1 or FORCE_DIST:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -316,7 +324,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt, float(rays_total)], device=dev, dtype=torch.float64)
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         import torch.distributed as dist
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -371,7 +379,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         import torch.distributed as dist
         dist.barrier()  # rank 0 may still be probing / printing
         dist.destroy_process_group()

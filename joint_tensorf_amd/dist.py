@@ -12,6 +12,21 @@ import torch.distributed as dist
 SMALL_BYTES = 1 << 20
 
 
+def rank_lattice_offset(o, step, extent, rank, world):
+    """One axis of the all_view_rand_grid lattice (model/nerf.py:655-673) for rank `rank` of `world`.
+
+    `o` in [0, step) is the draw SHARED by all ranks (same seeded host generator everywhere).
+    The number of lattice points along the axis, len(range(o, extent, step)), takes two values depending on
+    which side of a threshold `o` falls; a rank that drew its own offset would therefore render 1600 / 2000 /
+    2500 rays at random and every iteration of the job would run at the pace of the rank with the most.  Each
+    rank instead shifts the shared draw cyclically INSIDE the shared draw's class: different pixels per
+    rank, the same ray count on every rank."""
+    n = len(range(o, extent, step))
+    cls = [x for x in range(step) if len(range(x, extent, step)) == n]
+    k = cls.index(o)
+    return cls[(k + (rank * len(cls)) // max(world, 1)) % len(cls)]
+
+
 def _contiguous_view(g):
     """A contiguous alias of g's memory (channel-last factors are contiguous after a permute)."""
     if g.is_contiguous():
@@ -21,9 +36,9 @@ def _contiguous_view(g):
     return None
 
 
-def allreduce_gradients(params, world, group=None):
+def allreduce_gradients(params, world, group=None, force=False):
     """SUM-all-reduce the .grad of every parameter that has one (callers scale the loss by 1/world)."""
-    if world == 1:
+    if world == 1 and not force:
         return
     big, small = [], []
     for p in params:

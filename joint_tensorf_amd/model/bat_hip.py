@@ -177,6 +177,7 @@ class Graph(torch.nn.Module):
         self.pose_eye = torch.eye(3, 4, device=opt.device)
         self.tvloss = tensorf_repr.TVLoss()
         self.sim3 = None
+        self.lattice_rank = None  # (rank, world) under ray-sharded data parallelism (dist.rank_lattice_offset)
 
     # ---- pose (model/bat.py:341-367) -------------------------------------------------------------
     def get_pose(self, opt, var, mode=None):
@@ -215,6 +216,10 @@ class Graph(torch.nn.Module):
                 rays_per_view = opt.nerf.n_rays // batch_size
                 step = math.ceil((opt.H * opt.W // rays_per_view) ** 0.5)
                 ox, oy = np.random.randint(step), np.random.randint(step)
+                if self.lattice_rank is not None:  # ray-sharded data parallelism: same draw, same count, other pixels
+                    from ..dist import rank_lattice_offset
+                    ox = rank_lattice_offset(ox, step, opt.W, *self.lattice_rank)
+                    oy = rank_lattice_offset(oy, step, opt.H, *self.lattice_rank)
                 sx = torch.arange(ox, opt.W, step, device=opt.device)
                 sy = torch.arange(oy, opt.H, step, device=opt.device)
                 gY, gX = torch.meshgrid(sy, sx, indexing="ij")

@@ -95,11 +95,12 @@ def _zeros_flat(groups, with_flat=False):
 # the kernels that are still running.  Callers scale the RENDER loss by 1 / world; the regularisers are the
 # same on every rank and are neither scaled nor reduced.  Gradients that leave through the rays (poses) are the
 # caller's to reduce (dist.allreduce_gradients).
-_DP = {"world": 1, "group": None}
+_DP = {"world": 1, "group": None, "force": False}
 
 
-def set_data_parallel(world, group=None):
-    _DP["world"], _DP["group"] = int(world), group
+def set_data_parallel(world, group=None, force=False):
+    """force=True issues the collectives even for a group of one rank (exercises the RCCL path on a one-GPU box)."""
+    _DP["world"], _DP["group"], _DP["force"] = int(world), group, bool(force)
 
 
 def data_parallel_world():
@@ -369,8 +370,9 @@ class RenderRays(torch.autograd.Function):
         join = None
         g_mlp = [None] * 7
         dp_works = []
-        dp = _DP["world"] > 1 and fused_mlp_zero
-        if _DP["world"] > 1 and not dp and (want_fac or want_mlp):
+        dp_on = _DP["world"] > 1 or _DP["force"]
+        dp = dp_on and fused_mlp_zero
+        if dp_on and not dp and (want_fac or want_mlp):
             raise RuntimeError("data-parallel render backward needs the fused path with all scene gradients wanted")
 
         def dp_reduce(lo, hi):

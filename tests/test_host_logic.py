@@ -99,3 +99,25 @@ def test_product_path_refuses_to_run_without_a_gpu():
         nerf.tensorf(opt, o, d, white_bg=True, is_train=False, N_samples=8)
     with pytest.raises(RuntimeError):
         nerf.tensorf.density_L1()
+
+
+@pytest.mark.parametrize("step,extent", [(90, 400), (64, 400), (16, 400), (17, 640), (37, 480)])
+def test_rank_lattice_offsets_keep_the_ray_count(step, extent):
+    """Ray-sharded data parallelism: every rank shifts the SHARED lattice draw inside its class, so all ranks
+    render the same number of rays in every iteration (no straggler at the gradient all-reduce), rank 0 keeps the
+    reference's draw, and the ranks look at different pixels."""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("jt_dist", os.path.join(here, "joint_tensorf_amd", "dist.py"))
+    jd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(jd)
+    for world in (1, 2, 8):
+        for o in range(step):
+            offs = [jd.rank_lattice_offset(o, step, extent, r, world) for r in range(world)]
+            assert offs[0] == o
+            assert all(0 <= x < step for x in offs)
+            assert len({len(range(x, extent, step)) for x in offs}) == 1
+            n_cls = sum(1 for x in range(step) if len(range(x, extent, step)) == len(range(o, extent, step)))
+            if n_cls >= world:
+                assert len(set(offs)) == world
