@@ -257,6 +257,15 @@ def main():
 
     rays_total = 0
     grad_sums = []
+    # JT_GRAPH=1 on one GPU: the steady-state iteration is replayed from a hipGraph (joint_tensorf_amd/graphed.py).
+    # Off by default: at this workload the step is GPU-bound (host enqueue 2.1 ms of a 4.8 ms step) and the replay
+    # measures the same 4.8 ms.  Data-parallel runs issue their collectives from the eager backward.
+    stepper = None
+    if world == 1 and not FORCE_DIST and os.environ.get("JT_GRAPH", "0") == "1" \
+            and os.environ.get("JT_BENCH_CHECKSUM") != "1" and args.shade_impl == "mfma":
+        from joint_tensorf_amd.graphed import GraphedTrainStep
+        stepper = GraphedTrainStep(model, min_repeats=0)
+    use_graph = [False]
 
     def one_step():
         nonlocal rays_total
@@ -265,6 +274,14 @@ def main():
         state = np.random.get_state()
         np.random.set_state(lattice_rng.get_state())
         g = model.graph
+        if stepper is not None:
+            stepper.train_iteration(opt, var, force_eager=not use_graph[0])
+            lattice_rng.set_state(np.random.get_state())
+            np.random.set_state(state)
+            model.after_iteration(opt, model.it - 1)
+            rgb = stepper.last_var.rgb
+            rays_total += rgb.shape[0] * rgb.shape[1]
+            return
         g.it = model.it
         model.optim.zero_grad()
         var = g.forward(opt, var, mode="train")
@@ -304,18 +321,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for w in range(args.warmup):
-        if w == 0:
-            # the first warm-up step takes the densest lattice (offsets 0, 0): every persistent workspace and
-            # allocator block reaches its final size before the timed region instead of growing inside it
-            orig_randint = np.random.randint
-            np.random.randint = lambda *a, **k: 0
-            try:
-                one_step()
-            finally:
-                np.random.randint = orig_randint
-        else:
+    def primed_step(offsets):
+        seq = list(offsets)  # (ox, oy), handed out cyclically: a step that falls back to the eager path draws again
+        orig_randint = np.random.randint
+
+        def fixed(*a, **k):
+            seq.append(seq.pop(0))
+            return seq[-1]
+        np.random.randint = fixed
+        try:
             one_step()
+        finally:
+            np.random.randint = orig_randint
+
+    # priming (untimed, in front of the warm-up): one eager step on the densest lattice (offsets 0, 0) so that every
+    # persistent workspace and allocator block reaches its final size, then one step per lattice shape so that the
+    # hipGraph of each shape is captured before the clock starts
+    primed_step([0, 0])
+    if stepper is not None:
+        use_graph[0] = True
+        lat = model.graph.lattice_step(opt, n_views)
+        for offs in ([0, 0], [0, lat - 1], [lat - 1, 0], [lat - 1, lat - 1]):
+            primed_step(offs)
+    for w in range(args.warmup):
+        one_step()
     barrier()
     rays_total = 0
     t0 = time.perf_counter()
@@ -358,6 +387,8 @@ def main():
                 "samples_per_ray": S,
                 "Msamples_per_s": rays_all * S / dt / 1e6,
                 "shade_impl": args.shade_impl,
+                "launch": ("hipGraph replay (%(replayed)d replayed / %(captured)d captured / %(eager)d eager steps)"
+                           % stepper.stats) if stepper is not None else "eager",
             },
         }
         if os.environ.get("JT_BENCH_CHECKSUM") == "1":  # validation of the N > 1 paths against each other

@@ -311,6 +311,19 @@ typedef struct JtAdamItem {
 } JtAdamItem;
 int jt_adam_step(const JtAdamItem* items, int n_items, float beta1, float beta2, float eps, void* stream);
 
+/* The same step with the two per-tensor coefficients that change every iteration read from DEVICE memory:
+ * dyn[2 i] = lr_i / (1 - beta1^step_i), dyn[2 i + 1] = 1 / sqrt(1 - beta2^step_i) for item i (the lr /
+ * bias_correction fields of the items are ignored).  A hipGraph that captured this launch (the whole steady-state
+ * iteration is captured, joint_tensorf_amd/graphed.py) is replayed with new coefficients written by jt_poke. */
+int jt_adam_step_dyn(const JtAdamItem* items, int n_items, float beta1, float beta2, float eps, const float* dyn,
+                     void* stream);
+
+/* Write n_words (1..256) 32-bit words from HOST memory `words` to device memory `dst` on `stream`: the values
+ * travel as launch arguments (no host staging buffer, no synchronisation, the host array may be reused at once).
+ * The per-iteration host scalars of the reference's loop -- lattice offsets (model/nerf.py:663), Adam coefficients
+ * (model/tensorf.py:441-447 decays the lr every iteration) -- reach a replayed hipGraph this way. */
+int jt_poke(void* dst, const uint32_t* words, int n_words, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

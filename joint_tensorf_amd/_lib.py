@@ -85,6 +85,8 @@ SIGNATURES = {
     "jt_reg_losses_forward": (I, [FP, P, I, I, I, I, P, P, P]),
     "jt_reg_losses_backward": (I, [FP, P, I, I, P, I, I, FP, I, P, P]),
     "jt_adam_step": (I, [P, I, F, F, F, P]),
+    "jt_adam_step_dyn": (I, [P, I, F, F, F, P, P]),
+    "jt_poke": (I, [P, P, I, P]),
     "jt_dense_alpha": (I, [SP, FP, P, ctypes.c_long, F, P, P]),
     "jt_blur_batch_forward": (I, [P, I, P]),
     "jt_blur_batch_backward": (I, [P, I, P]),

@@ -7,6 +7,13 @@
 
 namespace jt {
 
+// Accumulators are cleared by a kernel, not hipMemsetAsync: the whole iteration is captured into a hipGraph
+// (joint_tensorf_amd/graphed.py) and a captured 16-byte memset node was observed to leave stale accumulator contents
+// in front of the kernel that follows it on replay.
+__global__ void k_loss_zero(float* __restrict__ p, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
+}
+
 // acc[0] = sum (m d)^2, acc[1] = #non-NaN of it, acc[2] = sum ((1-m) d)^2, acc[3] = #non-NaN
 __global__ __launch_bounds__(256) void k_render_loss_fwd(const float* __restrict__ rgb, const float* __restrict__ image,
                                                          const int64_t* __restrict__ ray_idx,
@@ -90,7 +97,8 @@ extern "C" int jt_render_loss_forward(const float* rgb, const float* image, cons
   if (!rgb || !image || !ray_idx || !acc4 || !loss || n_views < 1 || rays_per_view < 1 || n_pixels < 1)
     return JT_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(acc4, 0, 4 * sizeof(float), st) != hipSuccess) return JT_ERR_ARG;
+  hipLaunchKernelGGL(k_loss_zero, dim3(1), dim3(64), 0, st, acc4, 4);
+  JT_LAUNCH_CHECK();
   long n = (long)n_views * rays_per_view * 3;
   int blocks = (int)min((n + 255) / 256, 512L);
   hipLaunchKernelGGL(k_render_loss_fwd, dim3(blocks), dim3(256), 0, st, rgb, image, ray_idx, edge_mask, n_views,

@@ -91,6 +91,10 @@ __global__ __launch_bounds__(256) void k_factor_reg_bwd(const float* __restrict_
   }
 }
 
+__global__ void k_reg_zero(float* __restrict__ p, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
+}
+
 }  // namespace jt
 
 using namespace jt;
@@ -197,7 +201,8 @@ extern "C" int jt_reg_losses_forward(const JtFactors* factors, const int32_t* pl
   if (rc) return rc;
   if (!scratch36 || !out3) return JT_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(scratch36, 0, 36 * sizeof(float), st) != hipSuccess) return JT_ERR_ARG;
+  hipLaunchKernelGGL(k_reg_zero, dim3(1), dim3(64), 0, st, scratch36, 36);  // not a memset node: see jt_loss.hip
+  JT_LAUNCH_CHECK();
   for (int i = 0; i < 9; ++i) {  // app lines (9-11) enter no regulariser
     // a TV term whose weight is zero is not evaluated (it reads every texel three times): out3 carries 0 for it
     const bool tv = (i < 3 && with_tv_density) || (i >= 6 && with_tv_app);

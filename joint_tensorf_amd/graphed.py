@@ -1,0 +1,247 @@
+"""hipGraph replay of the steady-state training iteration.
+
+The reference's loop (model/base.py:154-172 around model/nerf.py:650-679) is ~75 kernel launches per iteration
+issued from Python.  Once the renderer is fused the HOST is what bounds an iteration whenever the field is sparse
+or the grid small (2.1-2.4 ms of Python per step against 1.5 ms of kernels at 64^3): the whole step -- pose
+composition, ray generation, march, shade, composite, losses, the complete backward and the Adam launch over all
+scene tensors -- is therefore captured ONCE into a hipGraph (torch.cuda.CUDAGraph is a hipGraph on ROCm) and
+replayed with one launch per iteration.
+
+What changes from one iteration to the next never enters the graph as a launch argument:
+  * the lattice offsets of `all_view_rand_grid` (NumPy draws, model/nerf.py:663) live in a device int32[2]; the pixel
+    lattice is computed from them inside the graph,
+  * Adam's per-tensor `lr / (1 - b1^t)` and `1 / sqrt(1 - b2^t)` (the lr decays every iteration,
+    model/tensorf.py:441-447) live in a device array read by `jt_adam_step_dyn`,
+both written by ONE `jt_poke` launch each in front of the replay (values travel as kernel arguments: no staging
+buffer, no synchronisation).  The per-ray jitter is torch's graph-safe Philox stream.  The pose optimizer (600
+floats, torch's fused Adam + ExponentialLR) stays outside the graph.
+
+Everything else that is baked into the captured launches -- grid stage, sample count, lattice SHAPE (the number of
+lattice points per axis takes two values), edge-loss parity, loss weights, the supervising image buffers, the
+persistent workspaces -- forms the SIGNATURE of a graph.  An iteration whose signature has a graph is replayed; one
+whose signature has been seen `min_repeats` times is captured; anything else (blur active: taps and 2-D scale
+change per iteration; LLFF: white-background coin, decaying TV weights, pose-gradient accumulation; data-parallel
+runs) runs through `Model.train_iteration` unchanged.  Host draws are consumed in exactly the eager order, so a run
+switches between the two paths without changing its random streams.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from .optim import VMAdam
+from .options import Opt
+
+
+class _Entry:
+    pass
+
+
+class GraphedTrainStep:
+    def __init__(self, model, min_repeats=2, max_graphs=24):
+        self.model = model
+        self.min_repeats = int(min_repeats)
+        self.max_graphs = int(max_graphs)
+        self.cache = {}
+        self.seen = {}
+        self.pool = None
+        self.epoch = None
+        self.last_var = None
+        self.eager_rays = {}  # (grid, samples per ray) -> most rays an EAGER step has rendered: the persistent
+        #                       workspaces fit that many, and a capture is not allowed to grow them
+        self.stats = dict(replayed=0, captured=0, eager=0)
+
+    # ------------------------------------------------------------------------------------------------------
+    def _eligible(self, opt):
+        m = self.model
+        has = lambda o, k: (k in o) and o[k] is not None  # noqa: E731
+        return (opt.nerf.ray_sampling_strategy == "all_view_rand_grid"
+                and opt.data.dataset == "blender" and bool(opt.nerf.setbg_opaque)
+                and not opt.optim.warmup_pose
+                and (not has(opt.optim, "grad_accum_iter") or int(opt.optim.grad_accum_iter) == 1)
+                and (not has(opt.optim, "pose_grad_accum_iter") or int(opt.optim.pose_grad_accum_iter) == 1)
+                and isinstance(m.optim, VMAdam)
+                and ops.data_parallel_world() == 1 and not ops._DP["force"])
+
+    def _blur_scheduled(self, opt):
+        """True while the factor-blur schedule is above its cut-off (model/tensorf.py:208-220) whatever the random
+        scale turns out to be: decided without touching the host random stream (saving and restoring NumPy's state
+        costs more than the rest of this class together)."""
+        from .model.bat_hip import interp_schedule
+        if not (opt.model in ("bat", "bat_hip") and opt.c2f_mode != "None"):
+            return False
+        p = self.model.graph.nerf.progress_host
+        return interp_schedule(p, opt.c2f_schedule_color) >= 0.001
+
+    def _signature(self, opt, var, ny, nx):
+        m, g = self.model, self.model.graph
+        it = m.it
+        has = lambda o, k: (k in o) and o[k] is not None  # noqa: E731
+        edge_on = False
+        if has(opt, "edge_mask_on_render_loss") and opt.edge_mask_on_render_loss:
+            edge_on = (it % 2 == 0) if (has(opt, "alternate_edge_loss") and opt.alternate_edge_loss) else True
+        use_edge = bool(edge_on and it < opt.edge_mask_before_iter)
+        first = opt.train_schedule.update_alphamask_iters[0]
+        l1 = float(opt.loss_weight.L1.rest if it > first else opt.loss_weight.L1.init) if "L1" in opt.loss_weight else 0.0
+        weights = tuple((k, None if opt.loss_weight[k] is None else (l1 if k == "L1" else float(opt.loss_weight[k])))
+                        for k in sorted(opt.loss_weight))
+        tf = g.nerf.tensorf
+        # (the edge masks are rebuilt every 500 iterations, model/nerf.py:172-176: their address only counts while
+        # the edge-weighted loss reads them)
+        ptrs = tuple(int(var[k].data_ptr()) if (k in var and torch.is_tensor(var[k])) else 0
+                     for k in ("idx", "image", "pose", "intr", "intr_inv") + (("train_edge_masks",) if use_edge else ()))
+        view_pe = fea_pe = 1.0
+        from .model.bat_hip import interp_schedule
+        if has(opt, "c2f_view_pe_schedule"):
+            view_pe = interp_schedule(g.nerf.progress_host, opt.c2f_view_pe_schedule)
+        if has(opt, "c2f_fea_pe_schedule"):
+            fea_pe = interp_schedule(g.nerf.progress_host, opt.c2f_fea_pe_schedule)
+        return (id(m.optim), getattr(m.optim, "_dyn_gen", 0), ops.workspace_generation(), tuple(g.nerf.resolution),
+                int(g.nerf.n_samples), int(opt.nerf.n_rays), ny, nx, use_edge, weights, ptrs, float(view_pe),
+                float(fea_pe), float(getattr(m, "render_loss_scale", 1.0)), tf.alphaMask is not None,
+                tuple(float(v) for v in tf.near_far), id(tf.jitter_override))
+
+    def _drop_all(self):
+        self.cache.clear()
+        self.seen.clear()
+        self.pool = None
+
+    # ------------------------------------------------------------------------------------------------------
+    def train_iteration(self, opt, var, force_eager=False):
+        """Drop-in for Model.train_iteration (same state transitions, same host draws)."""
+        m, g = self.model, self.model.graph
+        if force_eager or not self._eligible(opt) or self._blur_scheduled(opt):
+            self.stats["eager"] += 1
+            return self._eager(opt, var)
+        np_state = np.random.get_state()
+        g.it = m.it
+        batch_size = len(var.idx)
+        step = g.lattice_step(opt, batch_size)
+        ox, oy = np.random.randint(step), np.random.randint(step)
+        if g.lattice_rank is not None:
+            from .dist import rank_lattice_offset
+            ox = rank_lattice_offset(ox, step, opt.W, *g.lattice_rank)
+            oy = rank_lattice_offset(oy, step, opt.H, *g.lattice_rank)
+        blur = g.resolve_blur(opt, "train")  # consumes the blur-scale draw exactly like the eager path
+        if blur[2] is not None:
+            np.random.set_state(np_state)
+            self.stats["eager"] += 1
+            return self._eager(opt, var)
+        nx, ny = len(range(ox, opt.W, step)), len(range(oy, opt.H, step))
+        epoch = (id(m.optim), ops.workspace_generation())
+        if epoch != self.epoch:  # optimizer rebuilt (grid upsampled) or a workspace moved: every graph is stale
+            self._drop_all()
+            self.epoch = epoch
+        sig = self._signature(opt, var, ny, nx)
+        e = self.cache.get(sig)
+        if e is None:
+            if len(self.seen) > 4096:
+                self.seen.clear()
+            n = self.seen[sig] = self.seen.get(sig, 0) + 1
+            fits = batch_size * ny * nx <= self.eager_rays.get((tuple(g.nerf.resolution), int(g.nerf.n_samples)), 0)
+            if n <= self.min_repeats or not fits:
+                np.random.set_state(np_state)
+                self.stats["eager"] += 1
+                return self._eager(opt, var)
+            if os.environ.get("JT_GRAPH_DEBUG") == "1" and self.cache:
+                near = min(self.cache, key=lambda k: sum(a != b for a, b in zip(k, sig)))
+                print("graphed: capture #%d at it %d, differs from the nearest graph in fields %s"
+                      % (self.stats["captured"] + 1, m.it, [i for i, (a, b) in enumerate(zip(near, sig)) if a != b]),
+                      flush=True)
+            e = self._capture(opt, var, sig, ny, nx, step)
+            if (id(m.optim), ops.workspace_generation()) != self.epoch or e is None:
+                # capture is not allowed to move anything; if it did, start over on the eager path
+                self._drop_all()
+                np.random.set_state(np_state)
+                self.stats["eager"] += 1
+                return self._eager(opt, var)
+            if len(self.cache) >= self.max_graphs:  # least recently replayed graph goes (its memory returns to the pool)
+                del self.cache[min(self.cache, key=lambda k: self.cache[k].last_used)]
+            self.cache[sig] = e
+            self.stats["captured"] += 1
+        # ---- replay ------------------------------------------------------------------------------------------
+        e.last_used = self.stats["replayed"]
+        ops.poke_words(e.off, [ox, oy])
+        m.optim.prepare_step(e.stepped)
+        e.graph.replay()
+        self.stats["replayed"] += 1
+        m.it += 1
+        w = g.se3_refine.weight
+        w.grad = e.pose_grad
+        m.optim_pose.step()
+        w.grad = None
+        if m.sched_pose is not None:
+            m.sched_pose.step()
+        g.nerf.set_progress(m.it / opt.max_iter)
+        self.last_var = e.var
+        return e.loss
+
+    def _eager(self, opt, var):
+        nerf = self.model.graph.nerf
+        key = (tuple(nerf.resolution), int(nerf.n_samples))  # before the step: it may end with an upsampling
+        loss = self.model.train_iteration(opt, var)
+        self.last_var = var
+        if "rgb" in var:
+            self.eager_rays[key] = max(self.eager_rays.get(key, 0), var.rgb.shape[0] * var.rgb.shape[1])
+        return loss
+
+    # ------------------------------------------------------------------------------------------------------
+    def _capture(self, opt, var, sig, ny, nx, step):
+        m, g = self.model, self.model.graph
+        dev = opt.device
+        e = _Entry()
+        e.off = torch.zeros(2, device=dev, dtype=torch.int32)
+        # allocated OUTSIDE the capture: the entry must keep them alive for as long as the graph exists
+        e.base_x = base_x = torch.arange(nx, device=dev) * step
+        e.base_y = base_y = torch.arange(ny, device=dev) * step
+        W = int(opt.W)
+
+        def lattice(_step):
+            off = e.off.long()
+            sx, sy = base_x + off[0], base_y + off[1]
+            return (sx[None, :] + sy[:, None] * W).reshape(-1), ny, nx
+
+        m.optim.zero_grad()
+        m.optim_pose.zero_grad()
+        # The captured backward must not meet the parameters' cached AccumulateGrad nodes: such a node carries the
+        # stream it was created on -- the legacy stream of an earlier eager iteration whose autograd graph is still
+        # alive somewhere (a loss kept for logging is enough) -- and the engine would synchronise that stream with the
+        # capturing one, i.e. pull it into the capture (hipStreamEndCapture then crashes).  The capture therefore runs
+        # the model on fresh leaf ALIASES of the parameters (same storage, no history) and takes their gradients
+        # with autograd.grad.
+        from torch.nn.utils import stateless
+        named = [(n, p) for n, p in g.named_parameters() if p.requires_grad]
+        subs = {n: p.detach().requires_grad_(True) for n, p in named}
+        np_state = np.random.get_state()
+        e.graph = torch.cuda.CUDAGraph()
+        g.lattice_override = lattice
+        try:
+            kw = dict(pool=self.pool) if self.pool is not None else {}
+            err = None
+            with torch.cuda.graph(e.graph, **kw):
+                try:
+                    with stateless._reparametrize_module(g, subs):
+                        v = g.forward(opt, Opt(dict(var)), mode="train")
+                        loss = g.compute_loss(opt, v, mode="train")
+                        loss = m.summarize_loss(opt, v, loss)
+                        grads = torch.autograd.grad(loss.all, list(subs.values()), allow_unused=True)
+                    for (_, p), gr in zip(named, grads):
+                        p.grad = gr
+                    m.optim.launch_step()
+                except Exception as ex:  # leave the capture in an orderly way first: ending a capture that a
+                    err = ex             # Python exception tore open crashes inside hipStreamEndCapture
+            if err is not None:
+                raise err
+        finally:
+            g.lattice_override = None
+            np.random.set_state(np_state)
+        if self.pool is None:
+            self.pool = e.graph.pool()
+        e.var, e.loss = v, loss
+        e.pose_grad = g.se3_refine.weight.grad
+        e.stepped = {id(p) for grp in m.optim.param_groups for p in grp["params"] if p.grad is not None}
+        m.optim.zero_grad()
+        g.se3_refine.weight.grad = None
+        return e

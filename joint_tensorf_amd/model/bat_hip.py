@@ -178,6 +178,7 @@ class Graph(torch.nn.Module):
         self.tvloss = tensorf_repr.TVLoss()
         self.sim3 = None
         self.lattice_rank = None  # (rank, world) under ray-sharded data parallelism (dist.rank_lattice_offset)
+        self.lattice_override = None  # callable(step) -> (ray_idx, grid_H, grid_W); see graphed.GraphedTrainStep
 
     # ---- pose (model/bat.py:341-367) -------------------------------------------------------------
     def get_pose(self, opt, var, mode=None):
@@ -203,6 +204,12 @@ class Graph(torch.nn.Module):
             return pose
         return var.pose
 
+    @staticmethod
+    def lattice_step(opt, batch_size):
+        """pixel stride of the all_view_rand_grid lattice (model/nerf.py:660-662)."""
+        rays_per_view = opt.nerf.n_rays // batch_size
+        return math.ceil((opt.H * opt.W // rays_per_view) ** 0.5)
+
     # ---- forward (model/nerf.py:650-679) ---------------------------------------------------------
     def forward(self, opt, var, mode=None):
         batch_size = len(var.idx)
@@ -212,9 +219,14 @@ class Graph(torch.nn.Module):
             strat = opt.nerf.ray_sampling_strategy
             if strat == "all_view_rand_rays":
                 var.ray_idx = torch.randperm(opt.H * opt.W, device=opt.device)[:opt.nerf.n_rays // batch_size]
+            elif strat == "all_view_rand_grid" and self.lattice_override is not None:
+                # hipGraph capture / replay (graphed.GraphedTrainStep): the lattice is computed on the device from
+                # offsets that live in device memory; the host draws happen outside the graph
+                step = self.lattice_step(opt, batch_size)
+                var.ray_idx, var.grid_H, var.grid_W = self.lattice_override(step)
+                var.ray_grid_step = step
             elif strat == "all_view_rand_grid":
-                rays_per_view = opt.nerf.n_rays // batch_size
-                step = math.ceil((opt.H * opt.W // rays_per_view) ** 0.5)
+                step = self.lattice_step(opt, batch_size)
                 ox, oy = np.random.randint(step), np.random.randint(step)
                 if self.lattice_rank is not None:  # ray-sharded data parallelism: same draw, same count, other pixels
                     from ..dist import rank_lattice_offset

@@ -25,9 +25,28 @@ def _stream():
     return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
+def poke_words(dst, words, offset=0):
+    """Write up to 256 32-bit words (Python ints) into the device tensor `dst` (4-byte elements) at element
+    `offset`, on the current stream: the values travel as launch arguments (jt_poke) -- no staging buffer, no
+    synchronisation.  This is how per-iteration host scalars reach a replayed hipGraph."""
+    n = len(words)
+    assert dst.element_size() == 4 and dst.is_contiguous() and offset + n <= dst.numel()
+    arr = (ctypes.c_uint32 * n)(*words)
+    check(lib.jt_poke(ctypes.c_void_p(dst.data_ptr() + 4 * offset), arr, n, _stream()), "jt_poke")
+
+
+def poke_floats(dst, values, offset=0):
+    n = len(values)
+    assert dst.dtype == torch.float32 and dst.is_contiguous() and offset + n <= dst.numel()
+    arr = (ctypes.c_float * n)(*values)
+    check(lib.jt_poke(ctypes.c_void_p(dst.data_ptr() + 4 * offset), ctypes.cast(arr, ctypes.c_void_p), n, _stream()),
+          "jt_poke")
+
+
 _AUX = {}
 _WS = {}
 _WS_EPOCH = {}
+_WS_GEN = [0]  # bumped whenever a persistent workspace is (re)allocated: captured hipGraphs hold its address
 
 
 def _workspace(dev, name, nbytes):
@@ -37,8 +56,15 @@ def _workspace(dev, name, nbytes):
     key = (str(dev), name)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("workspace %r would grow during hipGraph capture" % (name,))
         _WS[key] = t = torch.empty(max(int(nbytes), 16), device=dev, dtype=torch.uint8)
+        _WS_GEN[0] += 1
     return t
+
+
+def workspace_generation():
+    return _WS_GEN[0]
 
 
 def _workspace_claim(dev, name):
@@ -416,8 +442,9 @@ class RenderRays(torch.autograd.Function):
             if USE_AUX_STREAM and want_mlp:
                 aux, ev_fork, ev_join = _aux_stream(dev)
                 # the weight-gradient GEMMs read mlp_t / ws and write g_mlp on the auxiliary stream
-                for t in list(mlp_t) + g_mlp + [offset]:
-                    t.record_stream(aux)
+                if not torch.cuda.is_current_stream_capturing():  # graph-pool memory is never recycled elsewhere
+                    for t in list(mlp_t) + g_mlp + [offset]:
+                        t.record_stream(aux)
                 h_aux = (ctypes.c_void_p(aux.cuda_stream), ctypes.c_void_p(ev_fork.cuda_event),
                          ctypes.c_void_p(ev_join.cuda_event))
                 join = ev_join

@@ -16,25 +16,45 @@ class VMAdam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        loss = None
-        if closure is not None:
-            with torch.enable_grad():
-                loss = closure()
-        # one launch per (betas, eps) combination; the reference uses a single one
+    # The step is split in two so that a hipGraph can hold the launch (graphed.GraphedTrainStep): `prepare_step`
+    # is the host half -- Adam's step counters, lr and bias corrections in Python doubles exactly as
+    # torch.optim.Adam computes them -- and ends with ONE jt_poke that puts the coefficients of all tensors into
+    # device memory; `launch_step` is the device half and reads them from there.
+
+    def _items(self):
+        """[(p, group)] of every parameter with a gradient, grouped by (betas, eps), in param-group order."""
         batches = {}
-        keep = []
         for group in self.param_groups:
             key = (float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]))
             for p in group["params"]:
-                g = p.grad
-                if g is None:
+                if p.grad is None:
+                    continue
+                batches.setdefault(key, []).append((p, group))
+        return batches
+
+    def _dyn_buffer(self, dev, n_items):
+        d = self.__dict__.setdefault("_dyn", {})
+        key = str(dev)
+        if key not in d or d[key].numel() < 2 * n_items:
+            d[key] = torch.zeros(2 * max(n_items, 32), device=dev, dtype=torch.float32)
+            self._dyn_gen = getattr(self, "_dyn_gen", 0) + 1  # a captured graph holding the old buffer is stale
+        return d[key]
+
+    @torch.no_grad()
+    def prepare_step(self, params_with_grad=None):
+        """Advance the step counters and write this iteration's (lr / bias_correction1, 1 / sqrt(bias_correction2))
+        of every tensor to the device.  `params_with_grad`: the ids of the parameters the following launch will step (default:
+        those that have a .grad now); the order must be the one `launch_step` sees."""
+        coefs = []
+        dev = None
+        for group in self.param_groups:
+            b1, b2 = float(group["betas"][0]), float(group["betas"][1])
+            for p in group["params"]:
+                if (p.grad is None) if params_with_grad is None else (id(p) not in params_with_grad):
                     continue
                 if not p.is_cuda:
                     raise RuntimeError("VMAdam steps parameters on the GPU only (no CPU fallback)")
-                if g.is_sparse or p.dtype != torch.float32:
-                    raise RuntimeError("VMAdam: dense float32 parameters only")
+                dev = p.device
                 st = self.state[p]
                 if len(st) == 0:
                     st["step"] = torch.tensor(0.0)
@@ -42,6 +62,29 @@ class VMAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
                 t = float(st["step"])
+                coefs.append(float(group["lr"]) / (1.0 - b1 ** t))
+                coefs.append(1.0 / math.sqrt(1.0 - b2 ** t))
+        if not coefs:
+            return
+        if len({(float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])) for g in self.param_groups}) != 1:
+            raise RuntimeError("VMAdam: one (betas, eps) combination per optimizer (the reference uses a single one)")
+        from .ops import poke_floats
+        dyn = self._dyn_buffer(dev, len(coefs) // 2)
+        for lo in range(0, len(coefs), 256):
+            poke_floats(dyn, coefs[lo:lo + 256], offset=lo)
+
+    @torch.no_grad()
+    def launch_step(self):
+        """One launch over all parameter tensors that have a gradient (coefficients from `prepare_step`)."""
+        keep = []
+        stream = _stream()
+        for (b1, b2, eps), plist in self._items().items():
+            arr = (JtAdamItem * len(plist))()
+            for k, (p, group) in enumerate(plist):
+                g = p.grad
+                if g.is_sparse or p.dtype != torch.float32:
+                    raise RuntimeError("VMAdam: dense float32 parameters only")
+                st = self.state[p]
                 if g.stride() != p.stride() or g.dtype != torch.float32:
                     # the kernel walks all four tensors in the parameter's memory order
                     g2 = torch.empty_like(p, memory_format=torch.preserve_format)
@@ -50,13 +93,16 @@ class VMAdam(torch.optim.Optimizer):
                     keep.append(g)
                 m, v = st["exp_avg"], st["exp_avg_sq"]
                 assert m.stride() == p.stride() and v.stride() == p.stride()
-                batches.setdefault(key, []).append(
-                    (p, g, m, v, float(group["lr"]), 1.0 - key[0] ** t, 1.0 - key[1] ** t))
-        stream = _stream()
-        for (b1, b2, eps), items in batches.items():
-            arr = (JtAdamItem * len(items))()
-            for k, (p, g, m, v, lr, bc1, bc2) in enumerate(items):
-                arr[k].p, arr[k].g, arr[k].m, arr[k].v = ptr(p), ptr(g), ptr(m), ptr(v)
-                arr[k].n, arr[k].lr, arr[k].bias_correction1, arr[k].bias_correction2 = p.numel(), lr, bc1, bc2
-            check(lib.jt_adam_step(arr, len(items), b1, b2, eps, stream), "jt_adam_step")
+                arr[k].p, arr[k].g, arr[k].m, arr[k].v, arr[k].n = ptr(p), ptr(g), ptr(m), ptr(v), p.numel()
+            dyn = self._dyn_buffer(plist[0][0].device, len(plist))
+            check(lib.jt_adam_step_dyn(arr, len(plist), b1, b2, eps, ptr(dyn), stream), "jt_adam_step_dyn")
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self.prepare_step()
+        self.launch_step()
         return loss

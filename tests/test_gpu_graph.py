@@ -1,0 +1,98 @@
+"""hipGraph replay of the training iteration (joint_tensorf_amd/graphed.py) against the eager loop: same initial
+state, same host draws, no jitter -- parameters, pose refinements and losses must follow the same trajectory
+(differences: the order of float atomics only), across lattice shapes, the edge-loss parity and a signature change.
+
+Tolerances (calibrated with tools/graph_calib.py): the loop is chaotic at the level of single texels -- Adam turns
+the sign of a gradient that is pure atomics-order noise into a full +-lr step -- so two EAGER runs of these 12
+iterations are either bit-close (1e-7) or, after one such event, 1e-2 apart in the appearance planes (1e-5 in the
+losses, 1e-4 in the density planes); the graph-replayed run shows exactly the same two levels against eager.  A
+wrong graph (stale lattice offsets, stale Adam coefficients, a missed zero-fill) moves the LOSSES at the 1e-2
+level at once, which is what the test pins."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _build(seed=0):
+    from joint_tensorf_amd.model import bat_hip
+    from joint_tensorf_amd.options import make_options
+    from joint_tensorf_amd.synthetic import make_views
+    B, HW = 3, 42   # 42 px, stride 8: 5 or 6 lattice points per axis -> four lattice shapes
+    opt = make_options("bat_blender_VM", device=DEV, data=dict(image_size=[HW, HW], num_views=B),
+                       train_schedule=dict(n_voxel_init=14 ** 3, n_rays_init=96, n_rays_rest=96), nerf=dict(n_rays=96))
+    opt.nerf.sample_stratified = False          # no jitter: the two runs are comparable sample by sample
+    opt.c2f_schedule_density = [0.0, 0.0]       # sharp stage (the blurred stages stay on the eager path)
+    opt.c2f_schedule_color = [0.0, 0.0]
+    torch.manual_seed(seed)
+    model = bat_hip.Model(opt)
+    model.build_networks(opt, n_views=B)
+    model.setup_optimizer(opt)
+    with torch.no_grad():
+        for p in model.graph.nerf.tensorf.density_plane:
+            p.mul_(22.0)
+        model.graph.se3_refine.weight.copy_(0.01 * torch.randn(B, 6, device=DEV))
+    var0 = make_views(opt, B, seed=3, device=DEV)
+    return opt, model, var0
+
+
+def _run(use_graph, K, it0=0):
+    from joint_tensorf_amd.graphed import GraphedTrainStep
+    from joint_tensorf_amd.options import Opt
+    opt, model, var0 = _build()
+    model.it = it0
+    model.graph.nerf.set_progress(it0 / opt.max_iter)
+    np.random.seed(5)
+    stepper = GraphedTrainStep(model, min_repeats=0) if use_graph else None
+    losses = []
+    orig_randint = np.random.randint
+    for k in range(K):
+        var = Opt(dict(var0))
+        # the first two iterations are eager on both sides, the very first on the densest lattice (offsets 0, 0):
+        # the persistent workspaces reach their final size there, as a training run's first iterations make them
+        if k == 0:
+            np.random.randint = lambda *a, **kw: 0
+        try:
+            loss = stepper.train_iteration(opt, var, force_eager=k < 2) if use_graph else model.train_iteration(opt, var)
+        finally:
+            np.random.randint = orig_randint
+        losses.append([float(loss.all.detach()), float(loss.render.detach()), float(loss.L1.detach())])
+        model.after_iteration(opt, model.it - 1)
+    sd = {k: v.detach().clone() for k, v in model.graph.state_dict().items()}
+    return np.array(losses), sd, (stepper.stats if use_graph else None), np.random.get_state()[1][:8].copy()
+
+
+@pytest.mark.parametrize("it0", [0, 9000])
+def test_graph_replay_follows_the_eager_trajectory(it0):
+    K = 12
+    l_e, sd_e, _, rs_e = _run(False, K, it0)
+    l_g, sd_g, stats, rs_g = _run(True, K, it0)
+    assert stats["captured"] >= 2 and stats["replayed"] >= K - 4, stats
+    assert (rs_e == rs_g).all()  # the host random stream is consumed identically
+    np.testing.assert_allclose(l_g, l_e, rtol=1e-3, atol=1e-8)
+    for k in sd_e:
+        a, b = sd_e[k].float(), sd_g[k].float()
+        tol = 1e-2 if "density" in k else 0.2
+        assert float((a - b).norm()) <= tol * (float(a.norm()) + 1e-12), k
+
+
+def test_graph_is_dropped_when_the_optimizer_is_rebuilt():
+    from joint_tensorf_amd.graphed import GraphedTrainStep
+    from joint_tensorf_amd.options import Opt
+    opt, model, var0 = _build()
+    opt.train_schedule.upsample_iters = [12, 10 ** 9]
+    model.graph.nerf.upsample_list = opt.train_schedule.upsample_iters
+    np.random.seed(1)
+    stepper = GraphedTrainStep(model, min_repeats=0)
+    for _ in range(30):
+        stepper.train_iteration(opt, Opt(dict(var0)))
+        model.after_iteration(opt, model.it - 1)
+    assert stepper.stats["replayed"] >= 20
+    res = model.graph.nerf.resolution
+    assert res[0] > 14  # the grid was upsampled in the middle and the run went on (graphs re-captured)
+    for p in model.graph.parameters():
+        assert torch.isfinite(p).all()

@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="bat_blender_VM")
     ap.add_argument("--max-iter", type=int, default=0, help="stop early (0 = the yaml's max_iter)")
+    ap.add_argument("--graph", action="store_true", help="replay the sharp-stage iterations from hipGraphs (graphed.py)")
     args = ap.parse_args()
     from joint_tensorf_amd.model import bat_hip
     from joint_tensorf_amd.options import make_options, Opt
@@ -34,6 +35,8 @@ def main():
     model.build_networks(opt, n_views=n_views)
     model.setup_optimizer(opt)
     views = make_views(opt, n_views, seed=0, device=dev)
+    from joint_tensorf_amd.graphed import GraphedTrainStep
+    stepper = GraphedTrainStep(model) if args.graph else None
     last = args.max_iter or int(opt.max_iter)
     marks = sorted(set([0] + [u for u in opt.train_schedule.upsample_iters] + [int(0.3 * opt.max_iter), last]))
     marks = [m for m in marks if m <= last]
@@ -49,7 +52,7 @@ def main():
         images, masks, sc = model.select_supervision(opt, views.image)      # model/nerf.py:172-176,209-227
         var = Opt(dict(views))
         var.image, var.train_edge_masks = images, masks
-        loss = model.train_iteration(opt, var)
+        loss = stepper.train_iteration(opt, var) if stepper is not None else model.train_iteration(opt, var)
         model.after_iteration(opt, it)
         if (it + 1) in marks or (it + 1) % 2000 == 0:
             torch.cuda.synchronize()
@@ -61,7 +64,7 @@ def main():
             tf = model.graph.nerf.tensorf
             seg.append(dict(iters="%d-%d" % (it_seg, it + 1), grid=tf.gridSize.tolist(), S=model.graph.nerf.n_samples,
                             seconds=round(now - t_seg, 2), ms_per_iter=round((now - t_seg) / (it + 1 - it_seg) * 1e3, 3),
-                            loss=round(float(loss.all), 5)))
+                            loss=round(float(loss.all), 5), launch=dict(stepper.stats) if stepper is not None else "eager"))
             print(json.dumps(seg[-1]), flush=True)
             t_seg, it_seg = now, it + 1
     torch.cuda.synchronize()
