@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--n-voxel-final", type=int, default=0,
                     help="override train_schedule.n_voxel_final (e.g. 27000000 = the 300^3 of the parent yaml "
                          "options/tensorf_blender_VM.yaml that BASELINE.json's configs[1] text quotes)")
+    ap.add_argument("--scene", default="random", choices=["random", "blobs"],
+                    help="random = the reference's random-init factors (every in-box sample is shaded: the worst case "
+                         "and the default); blobs = a few opaque Gaussian blobs baked into the density factors "
+                         "(SURVEY 8(d) structured scene: a few per cent of the samples shaded, like a trained field)")
     ap.add_argument("--shade-impl", default="mfma", choices=["mfma", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -238,6 +242,9 @@ def main():
         opt.nerf.n_rays = args.n_rays
     n_views = int(opt.data.num_views)
     model = build_model(opt, it0, n_views)
+    if args.scene == "blobs":
+        from joint_tensorf_amd.synthetic import bake_blobs
+        bake_blobs(model.graph.nerf.tensorf, n_blobs=12, seed=0)
     if (world > 1 or FORCE_DIST) and OVERLAP:
         from joint_tensorf_amd import ops as jops
         jops.set_data_parallel(world, force=FORCE_DIST)
@@ -376,7 +383,9 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (random-init VM factors / MLP, random images, 100 cameras on a radius-4 sphere)",
+            "data": "synthetic (%s, random-init appearance factors / MLP, random images, 100 cameras on a radius-4 "
+                    "sphere)" % ("random-init density factors" if args.scene == "random"
+                                 else "12 opaque Gaussian blobs baked into the density factors"),
             "config": {
                 "workload": "%s stage %d: grid %s, S=%d samples/ray, %d rays/iter/GPU (%s lattice over %d views), "
                             "blur %s, full train step (fwd+loss+bwd+Adam+pose Adam)"

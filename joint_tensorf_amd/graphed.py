@@ -217,6 +217,10 @@ class GraphedTrainStep:
         np_state = np.random.get_state()
         e.graph = torch.cuda.CUDAGraph()
         g.lattice_override = lattice
+        # one stream inside the graph: the auxiliary stream of the eager backward (weight-gradient GEMMs next to the
+        # density backward) buys 0.1 ms of a dense 4.8 ms step there, but as a fork / join inside a hipGraph it COSTS
+        # 0.07-0.1 ms (measured, dense and sparse scene)
+        aux_was, ops.USE_AUX_STREAM = ops.USE_AUX_STREAM, False
         try:
             kw = dict(pool=self.pool) if self.pool is not None else {}
             err = None
@@ -235,6 +239,7 @@ class GraphedTrainStep:
             if err is not None:
                 raise err
         finally:
+            ops.USE_AUX_STREAM = aux_was
             g.lattice_override = None
             np.random.set_state(np_state)
         if self.pool is None:

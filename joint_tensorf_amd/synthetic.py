@@ -52,3 +52,35 @@ def make_views(opt, n_views, seed=0, device="cpu", with_images=True):
         var.image = torch.rand(n_views, 3, H, W, generator=g).to(device)
         var.train_edge_masks = (torch.rand(n_views, H * W, generator=g) < 0.5).to(torch.uint8).to(device)
     return var
+
+
+@torch.no_grad()
+def bake_blobs(tensorf, n_blobs=12, seed=0, amplitude=60.0, radius=(0.12, 0.3), background=-12.0):
+    """Overwrite the DENSITY factors with a few opaque Gaussian blobs (the "structured" scene).
+
+    exp(-|p - c|^2 / 2 s^2) factorises into an (x, y) plane times a z line, i.e. one blob is exactly one rank-1
+    VM component of plane 0 / line 0; the last component is the constant `background` (what a trained field's empty
+    space looks like: softplus(-12 - 10) gives weights of 1e-11, far below rayMarch_weight_thres, where the
+    zero feature of an untouched grid still gives 4e-6); all other density components are zeroed.  Only the few
+    samples at a blob's surface are shaded -- the regime of a trained scene (a few per cent of the in-box samples), against
+    the random-init field in which every in-box sample is shaded."""
+    rng = np.random.RandomState(seed)
+    dev = tensorf.density_plane[0].device
+    lo, hi = tensorf.aabb[0].to(dev).float(), tensorf.aabb[1].to(dev).float()
+    C = tensorf.density_plane[0].shape[1]
+    n_blobs = min(int(n_blobs), C - 1)
+    for p in list(tensorf.density_plane) + list(tensorf.density_line):
+        p.zero_()
+    plane, line = tensorf.density_plane[0], tensorf.density_line[0]   # plane 0: (x -> W, y -> H); line 0: z
+    H, W, L = plane.shape[2], plane.shape[3], line.shape[2]
+    X = lo[0] + (hi[0] - lo[0]) * torch.linspace(0, 1, W, device=dev)
+    Y = lo[1] + (hi[1] - lo[1]) * torch.linspace(0, 1, H, device=dev)
+    Z = lo[2] + (hi[2] - lo[2]) * torch.linspace(0, 1, L, device=dev)
+    for k in range(n_blobs):
+        c = (lo + (hi - lo) * torch.tensor(0.25 + 0.5 * rng.rand(3), device=dev, dtype=torch.float32))
+        s = float(radius[0] + (radius[1] - radius[0]) * rng.rand())
+        plane[0, k] = amplitude * torch.exp(-((X[None, :] - c[0]) ** 2 + (Y[:, None] - c[1]) ** 2) / (2 * s * s))
+        line[0, k, :, 0] = torch.exp(-((Z - c[2]) ** 2) / (2 * s * s))
+    plane[0, C - 1] = background
+    line[0, C - 1] = 1.0
+    return n_blobs
