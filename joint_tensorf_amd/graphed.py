@@ -39,6 +39,65 @@ class _Entry:
     pass
 
 
+def capture(fn, pool=None):
+    """Capture the launches of `fn()` into a hipGraph; returns (graph, fn's result).  A Python exception inside the
+    capture is held until the capture has ended in an orderly way (ending a capture that an exception tore open
+    crashes inside hipStreamEndCapture on this ROCm build) and re-raised afterwards."""
+    graph = torch.cuda.CUDAGraph()
+    box = {}
+    kw = dict(pool=pool) if pool is not None else {}
+    with torch.cuda.graph(graph, **kw):
+        try:
+            box["out"] = fn()
+        except Exception as ex:
+            box["err"] = ex
+    if "err" in box:
+        raise box["err"]
+    return graph, box["out"]
+
+
+class GraphedEvalRender:
+    """The sliced full-image render of one view (Graph.render_by_slices, model/nerf.py:728-740) as ONE hipGraph:
+    BASELINE.json configs[4] ("hipGraph-captured ray tiles").  Pose and intrinsics live in static device buffers, so
+    the graph of a scene state is replayed for every held-out view; it is re-captured when the scene tensors, the
+    grid stage, the blur / PE schedule position or a workspace move.  No gradient is involved."""
+
+    def __init__(self, graph_module):
+        self.g = graph_module
+        self.key = None
+        self.entry = None
+
+    def _key(self, opt, pose):
+        nerf = self.g.nerf
+        tf = nerf.tensorf
+        ptrs = tuple(int(p.data_ptr()) for p in nerf.parameters())
+        return (tuple(pose.shape), int(opt.H), int(opt.W), tuple(nerf.resolution), int(nerf.n_samples),
+                float(nerf.progress_host), ops.workspace_generation(), tuple(float(v) for v in tf.near_far), ptrs,
+                tf.alphaMask is not None, int(opt.nerf.n_rays),
+                int(opt.nerf.eval_slice_rays) if ("eval_slice_rays" in opt.nerf) else 0)
+
+    @torch.no_grad()
+    def render(self, opt, pose, intr_inv, intr):
+        key = self._key(opt, pose)
+        if key != self.key:
+            self.entry = self.key = None
+            e = _Entry()
+            e.pose, e.intr_inv, e.intr = pose.clone(), intr_inv.clone(), intr.clone()
+            # once eagerly: lazy initialisation and the persistent workspaces happen outside the capture
+            self.g.render_by_slices(opt, e.pose, intr_inv=e.intr_inv, mode="eval", intr=e.intr)
+            if ops.workspace_generation() != key[6]:
+                key = self._key(opt, pose)
+            e.graph, e.out = capture(lambda: self.g.render_by_slices(opt, e.pose, intr_inv=e.intr_inv, mode="eval",
+                                                                     intr=e.intr))
+            self.entry, self.key = e, key
+        e = self.entry
+        e.pose.copy_(pose)
+        e.intr_inv.copy_(intr_inv)
+        e.intr.copy_(intr)
+        e.graph.replay()
+        return Opt({k: v.clone() for k, v in e.out.items()})
+
+
 class GraphedTrainStep:
     def __init__(self, model, min_repeats=2, max_graphs=24):
         self.model = model
@@ -215,29 +274,24 @@ class GraphedTrainStep:
         named = [(n, p) for n, p in g.named_parameters() if p.requires_grad]
         subs = {n: p.detach().requires_grad_(True) for n, p in named}
         np_state = np.random.get_state()
-        e.graph = torch.cuda.CUDAGraph()
         g.lattice_override = lattice
         # one stream inside the graph: the auxiliary stream of the eager backward (weight-gradient GEMMs next to the
         # density backward) buys 0.1 ms of a dense 4.8 ms step there, but as a fork / join inside a hipGraph it COSTS
         # 0.07-0.1 ms (measured, dense and sparse scene)
         aux_was, ops.USE_AUX_STREAM = ops.USE_AUX_STREAM, False
         try:
-            kw = dict(pool=self.pool) if self.pool is not None else {}
-            err = None
-            with torch.cuda.graph(e.graph, **kw):
-                try:
-                    with stateless._reparametrize_module(g, subs):
-                        v = g.forward(opt, Opt(dict(var)), mode="train")
-                        loss = g.compute_loss(opt, v, mode="train")
-                        loss = m.summarize_loss(opt, v, loss)
-                        grads = torch.autograd.grad(loss.all, list(subs.values()), allow_unused=True)
-                    for (_, p), gr in zip(named, grads):
-                        p.grad = gr
-                    m.optim.launch_step()
-                except Exception as ex:  # leave the capture in an orderly way first: ending a capture that a
-                    err = ex             # Python exception tore open crashes inside hipStreamEndCapture
-            if err is not None:
-                raise err
+            def body():
+                with stateless._reparametrize_module(g, subs):
+                    v = g.forward(opt, Opt(dict(var)), mode="train")
+                    loss = g.compute_loss(opt, v, mode="train")
+                    loss = m.summarize_loss(opt, v, loss)
+                    grads = torch.autograd.grad(loss.all, list(subs.values()), allow_unused=True)
+                for (_, p), gr in zip(named, grads):
+                    p.grad = gr
+                m.optim.launch_step()
+                return v, loss
+
+            e.graph, (v, loss) = capture(body, pool=self.pool)
         finally:
             ops.USE_AUX_STREAM = aux_was
             g.lattice_override = None

@@ -178,6 +178,7 @@ class Graph(torch.nn.Module):
         self.tvloss = tensorf_repr.TVLoss()
         self.sim3 = None
         self.lattice_rank = None  # (rank, world) under ray-sharded data parallelism (dist.rank_lattice_offset)
+        self.eval_graph = None
         self.lattice_override = None  # callable(step) -> (ray_idx, grid_H, grid_W); see graphed.GraphedTrainStep
 
     # ---- pose (model/bat.py:341-367) -------------------------------------------------------------
@@ -241,6 +242,12 @@ class Graph(torch.nn.Module):
                 assert strat == "single_view_rand_rays"
                 var.ray_idx = torch.randperm(opt.H * opt.W, device=opt.device)[:opt.nerf.n_rays]
             ret = self.render(opt, pose, intr_inv=var.intr_inv, ray_idx=var.ray_idx, mode=mode, intr=var.intr)
+        elif _has(opt.nerf, "eval_graph") and opt.nerf.eval_graph and not torch.is_grad_enabled():
+            # the whole sliced render of a view as one hipGraph, replayed per held-out view (graphed.GraphedEvalRender)
+            if self.eval_graph is None:
+                from ..graphed import GraphedEvalRender
+                self.eval_graph = GraphedEvalRender(self)
+            ret = self.eval_graph.render(opt, pose, var.intr_inv, var.intr)
         else:
             ret = self.render_by_slices(opt, pose, intr_inv=var.intr_inv, mode=mode, intr=var.intr)
         var.update(ret)

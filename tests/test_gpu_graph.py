@@ -96,3 +96,30 @@ def test_graph_is_dropped_when_the_optimizer_is_rebuilt():
     assert res[0] > 14  # the grid was upsampled in the middle and the run went on (graphs re-captured)
     for p in model.graph.parameters():
         assert torch.isfinite(p).all()
+
+
+def test_graph_captured_eval_render_matches_the_sliced_render():
+    """BASELINE.json configs[4]: the whole sliced render of a view as one hipGraph, replayed for other views."""
+    from joint_tensorf_amd.options import Opt
+    opt, model, var0 = _build()
+    opt.nerf.eval_slice_rays = 500      # several slices per image (42 x 42 = 1764 pixels)
+    opt.nerf.n_rays = 96
+    g = model.graph
+    g.eval()
+    outs = {}
+    for use_graph in (False, True):
+        opt.nerf.eval_graph = use_graph
+        res = []
+        with torch.no_grad():
+            for i in (0, 1, 2, 0):
+                var = Opt({k: (v[i:i + 1] if torch.is_tensor(v) and v.shape[:1] == (3,) else v) for k, v in dict(var0).items()})
+                var.idx = torch.arange(1, device=DEV)
+                v = g.forward(opt, var, mode="vis_eval")
+                res.append((v.rgb.clone(), v.depth.clone(), v.opacity.clone()))
+        outs[use_graph] = res
+    assert g.eval_graph is not None and g.eval_graph.entry is not None
+    for a, b in zip(outs[False], outs[True]):
+        for x, y in zip(a, b):
+            assert x.shape == y.shape
+            torch.testing.assert_close(y, x, rtol=0, atol=0)   # same kernels, no atomics in the forward: bit-equal
+    assert not torch.equal(outs[True][0][0], outs[True][1][0])  # different views really differ

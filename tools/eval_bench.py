@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--samples", type=int, default=1024)
     ap.add_argument("--test-iters", type=int, default=50)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--graph", action="store_true", help="replay the sliced render from one hipGraph (nerf.eval_graph)")
     args = ap.parse_args()
     sys.argv = [sys.argv[0]]
     import bench
@@ -32,6 +33,7 @@ def main():
     np.random.seed(0)
     opt = make_options("bat_blender_VM", device=dev, data=dict(image_size=[args.size, args.size]),
                        nerf=dict(sample_intvs=args.samples), optim=dict(test_iter=args.test_iters))
+    opt.nerf.eval_graph = bool(args.graph)
     stage, it0 = bench.stage_setup(opt, -1)
     opt.nerf.n_rays = opt.train_schedule.n_rays_rest
     model = bench.build_model(opt, it0, int(opt.data.num_views))
@@ -65,7 +67,7 @@ def main():
     print(json.dumps({
         "eval_render": {"image": [args.size, args.size], "samples_per_ray": int(g.nerf.n_samples),
                         "grid": g.nerf.tensorf.gridSize.tolist(), "ms_per_image": t_render * 1e3,
-                        "rays_per_s": rays / t_render, "Msamples_per_s": rays * g.nerf.n_samples / t_render / 1e6},
+                        "rays_per_s": rays / t_render, "launch": "hipGraph replay" if args.graph else "eager", "Msamples_per_s": rays * g.nerf.n_samples / t_render / 1e6},
         "test_time_optim": {"rays_per_iter": int(v.rgb.shape[1]), "ms_per_iter": t_opt * 1e3,
                             "iters": args.test_iters, "backward": "pose-only (no factor / weight gradients)"}}))
 
