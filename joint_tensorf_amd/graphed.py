@@ -304,3 +304,171 @@ class GraphedTrainStep:
         m.optim.zero_grad()
         g.se3_refine.weight.grad = None
         return e
+
+
+class GraphedTestOptim:
+    """Test-time photometric pose optimisation of a held-out view (model/bat.py:265-292) with every iteration replayed
+    from a hipGraph -- the launch-bound inner loop of the evaluation (200 views x 400 iterations in bat_blender_VM).
+
+    One persistent se(3) vector [1,6], its Adam state and static copies of the view's image / pose / intrinsics are
+    re-initialised per view, so the graphs (one per lattice shape) serve the whole test set.  The iteration inside
+    the graph: se3 -> SE(3) -> pose composition -> lattice rays -> march / shade (pose-only records) / composite ->
+    loss -> backward to the rays -> pose -> se3 -> Adam launch (`jt_adam_step_dyn`).  Lattice offsets and the Adam
+    coefficients (ExponentialLR decays the lr every iteration) are poked in front of each replay; host draws are
+    consumed in the eager order.  Iterations with the factor blur on (LLFF's test_kernel_schedule) run eagerly on
+    the same state."""
+
+    def __init__(self, model):
+        self.model = model
+        self.se3 = None
+        self.cache = {}
+        self.pool = None
+        self.epoch = None
+        self.eager_shapes = set()   # lattice shapes that have run eagerly in the current scene state
+        self.force_eager = False    # run the same loop without any replay (tests)
+        self.stats = dict(replayed=0, captured=0, eager=0)
+
+    def _setup(self, opt, var):
+        dev = opt.device
+        if self.se3 is None:
+            self.se3 = torch.nn.Parameter(torch.zeros(1, 6, device=dev))
+            # torch.optim.Adam's defaults, as in the reference (model/bat.py:270)
+            self.optim = VMAdam([dict(params=[self.se3], lr=opt.optim.lr_pose)], betas=(0.9, 0.999), eps=1e-8)
+            self.static = {}
+            self.eye = torch.eye(3, 4, device=dev)
+        for k in ("image", "pose", "intr", "intr_inv"):
+            if k in var and torch.is_tensor(var[k]):
+                if k not in self.static or self.static[k].shape != var[k].shape:
+                    self.static[k] = var[k].clone()
+                    self.cache.clear()
+                else:
+                    self.static[k].copy_(var[k])
+        with torch.no_grad():
+            self.se3.zero_()
+        self.se3.grad = None
+        st = self.optim.state[self.se3]
+        if st:
+            st["step"].zero_()
+            st["exp_avg"].zero_()
+            st["exp_avg_sq"].zero_()
+        self.optim.param_groups[0]["lr"] = float(opt.optim.lr_pose)
+
+    def _iteration(self, opt, v, se3_leaf):
+        m, g = self.model, self.model.graph
+        v.pose_refine_test = ops.train_pose(se3_leaf, None, self.eye)  # se3_to_SE3 (camera.py:81-99)
+        v = g.forward(opt, v, mode="test-optim")
+        loss = g.compute_loss(opt, v, mode="test-optim")
+        loss = m.summarize_loss(opt, v, loss)
+        return v, loss
+
+    @torch.enable_grad()
+    def run(self, opt, var):
+        m, g = self.model, self.model.graph
+        self._setup(opt, var)
+        var.se3_refine_test = self.se3
+        gamma = (opt.optim.lr_pose_test_end / opt.optim.lr_pose_test) ** (1.0 / opt.optim.test_iter)
+        frozen = [p for p in g.parameters() if p.requires_grad]
+        for p in frozen:
+            p.requires_grad_(False)
+        svar = Opt(dict(var))
+        svar.update(self.static)
+        batch_size = len(var.idx)
+        last = None
+        try:
+            for it in range(opt.optim.test_iter):
+                g.nerf.test_time_progress_host = it / opt.optim.test_iter
+                g.nerf.test_time_progress.data.fill_(it / opt.optim.test_iter)
+                graphable = (opt.nerf.ray_sampling_strategy == "all_view_rand_grid" and not opt.camera.ndc
+                             and bool(opt.nerf.setbg_opaque) and not self.force_eager)
+                np_state = np.random.get_state() if graphable else None
+                e = None
+                if graphable:
+                    step = g.lattice_step(opt, batch_size)
+                    ox, oy = np.random.randint(step), np.random.randint(step)
+                    blur = g.resolve_blur(opt, "test-optim")
+                    if blur[2] is None:
+                        nx, ny = len(range(ox, opt.W, step)), len(range(oy, opt.H, step))
+                        e = self._graph_for(opt, svar, ny, nx, step)
+                    if e is None:
+                        np.random.set_state(np_state)
+                if e is None:   # eager iteration on the same state
+                    self.se3.grad = None
+                    v, loss = self._iteration(opt, Opt(dict(svar)), self.se3)
+                    loss.all.backward()
+                    self.optim.step()
+                    last = v
+                    self.stats["eager"] += 1
+                else:
+                    ops.poke_words(e.off, [ox, oy])
+                    self.optim.prepare_step({id(self.se3)})
+                    e.graph.replay()
+                    last = e.var
+                    self.stats["replayed"] += 1
+                self.optim.param_groups[0]["lr"] *= gamma   # ExponentialLR.step()
+        finally:
+            for p in frozen:
+                p.requires_grad_(True)
+        self.se3.grad = None
+        # NOTE (reproduced): the pose refinement that the eval render sees is the one from the top of the last
+        # iteration, i.e. from before the last Adam step (model/bat.py:284, model/nerf.py:539)
+        if last is not None:
+            for k in ("pose_refine_test", "rgb", "depth", "opacity", "ray_idx", "current_pose"):
+                if k in last:
+                    var[k] = last[k].detach().clone()
+        return var
+
+    def _graph_for(self, opt, svar, ny, nx, step):
+        m, g = self.model, self.model.graph
+        nerf = g.nerf
+        epoch = (ops.workspace_generation(), getattr(self.optim, "_dyn_gen", 0), tuple(nerf.resolution),
+                 int(nerf.n_samples), float(nerf.progress_host), tuple(int(p.data_ptr()) for p in nerf.parameters()),
+                 tuple(float(v) for v in nerf.tensorf.near_far), int(opt.nerf.n_rays))
+        if epoch != self.epoch:
+            self.cache.clear()
+            self.eager_shapes.clear()
+            self.pool = None
+            self.epoch = epoch
+        e = self.cache.get((ny, nx))
+        if e is not None:
+            return e
+        if not self.optim.state[self.se3] or (ny, nx) not in self.eager_shapes:
+            # first meeting of this lattice shape in this scene state: one eager iteration sizes the workspaces
+            self.eager_shapes.add((ny, nx))
+            return None
+        dev = opt.device
+        e = _Entry()
+        e.off = torch.zeros(2, device=dev, dtype=torch.int32)
+        e.base_x = base_x = torch.arange(nx, device=dev) * step
+        e.base_y = base_y = torch.arange(ny, device=dev) * step
+        W = int(opt.W)
+
+        def lattice(_step):
+            off = e.off.long()
+            sx, sy = base_x + off[0], base_y + off[1]
+            return (sx[None, :] + sy[:, None] * W).reshape(-1), ny, nx
+
+        np_state = np.random.get_state()
+        ws_gen = ops.workspace_generation()
+        g.lattice_override = lattice
+        leaf = self.se3.detach().requires_grad_(True)   # fresh leaf alias: see GraphedTrainStep._capture
+        self.se3.grad = None
+        try:
+            def body():
+                v, loss = self._iteration(opt, Opt(dict(svar)), leaf)
+                (gr,) = torch.autograd.grad(loss.all, [leaf])
+                self.se3.grad = gr
+                self.optim.launch_step()
+                return v, loss
+
+            e.graph, (e.var, e.loss) = capture(body, pool=self.pool)
+        finally:
+            g.lattice_override = None
+            np.random.set_state(np_state)
+        self.se3.grad = None
+        if ops.workspace_generation() != ws_gen:
+            return None
+        if self.pool is None:
+            self.pool = e.graph.pool()
+        self.cache[(ny, nx)] = e
+        self.stats["captured"] += 1
+        return e

@@ -515,6 +515,12 @@ class Model(torch.nn.Module):
         The scene is frozen for the duration, so the renderer's backward takes its pose-only route (no factor
         or weight gradients are formed; the reference forms and discards them)."""
         g = self.graph
+        if _has(opt.optim, "test_graph") and opt.optim.test_graph:
+            # every iteration replayed from a hipGraph (graphed.GraphedTestOptim); same state transitions and draws
+            if getattr(self, "_test_optim_graph", None) is None:
+                from ..graphed import GraphedTestOptim
+                self._test_optim_graph = GraphedTestOptim(self)
+            return self._test_optim_graph.run(opt, var)
         var.se3_refine_test = torch.nn.Parameter(torch.zeros(1, 6, device=opt.device))
         kw = dict(fused=True) if str(opt.device).startswith("cuda") else {}
         optim_pose = torch.optim.Adam([dict(params=[var.se3_refine_test], lr=opt.optim.lr_pose)], **kw)

@@ -123,3 +123,41 @@ def test_graph_captured_eval_render_matches_the_sliced_render():
             assert x.shape == y.shape
             torch.testing.assert_close(y, x, rtol=0, atol=0)   # same kernels, no atomics in the forward: bit-equal
     assert not torch.equal(outs[True][0][0], outs[True][1][0])  # different views really differ
+
+
+def test_graph_replayed_test_time_pose_optimisation_matches_eager():
+    """model/bat.py:265-292 with every iteration replayed from a hipGraph.  Against the SAME loop run eagerly (same
+    kernels, same Adam arithmetic; the pose path has no order-dependent float atomics) the se(3) trajectory agrees to
+    round-off; against the reference-shaped loop (torch's fused Adam) only as far as the on-the-face coin toss of
+    the first sample of a ray allows once the two poses differ in the last bit."""
+    from joint_tensorf_amd.graphed import GraphedTestOptim
+    from joint_tensorf_amd.options import Opt
+    res = {}
+    for kind in ("reference-shaped", "same-loop-eager", "replayed"):
+        opt, model, var0 = _build()
+        opt.optim.test_iter = 16
+        opt.optim.test_graph = kind != "reference-shaped"
+        if kind == "same-loop-eager":
+            model._test_optim_graph = GraphedTestOptim(model)
+            model._test_optim_graph.force_eager = True
+        g = model.graph
+        g.sim3 = Opt(t0=torch.zeros(3, device=DEV), t1=torch.zeros(3, device=DEV), s0=1.0, s1=1.0,
+                     R=torch.eye(3, device=DEV))
+        np.random.seed(11)
+        out = []
+        for i in (0, 1):   # two held-out views through the same graphs
+            var = Opt({k: (v[i:i + 1].clone() if torch.is_tensor(v) and v.shape[:1] == (3,) else v) for k, v in dict(var0).items()})
+            var.idx = torch.arange(1, device=DEV)
+            with torch.no_grad():   # a wrong start pose for the optimisation to correct
+                var.pose[0, :, 3] += torch.tensor([0.02, -0.01, 0.015], device=DEV)
+            v = model.evaluate_test_time_photometric_optim(opt, var)
+            out.append((v.se3_refine_test.detach().clone(), v.pose_refine_test.detach().clone()))
+        res[kind] = out
+        if kind == "replayed":
+            st = model._test_optim_graph.stats
+            assert st["replayed"] >= 16 and st["captured"] >= 1, st
+    for (se3_r, pr_r), (se3_e, pr_e), (se3_g, pr_g) in zip(res["reference-shaped"], res["same-loop-eager"], res["replayed"]):
+        assert float(se3_e.abs().max()) > 1e-4          # the optimisation moved
+        torch.testing.assert_close(se3_g, se3_e, rtol=1e-4, atol=1e-7)
+        torch.testing.assert_close(pr_g, pr_e, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(se3_g, se3_r, rtol=0, atol=0.25 * float(se3_r.abs().max()))

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--samples", type=int, default=1024)
     ap.add_argument("--test-iters", type=int, default=50)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--scene", default="random", choices=["random", "blobs"], help="see bench.py --scene")
     ap.add_argument("--graph", action="store_true", help="replay the sliced render from one hipGraph (nerf.eval_graph)")
     args = ap.parse_args()
     sys.argv = [sys.argv[0]]
@@ -34,9 +35,13 @@ def main():
     opt = make_options("bat_blender_VM", device=dev, data=dict(image_size=[args.size, args.size]),
                        nerf=dict(sample_intvs=args.samples), optim=dict(test_iter=args.test_iters))
     opt.nerf.eval_graph = bool(args.graph)
+    opt.optim.test_graph = bool(args.graph)
     stage, it0 = bench.stage_setup(opt, -1)
     opt.nerf.n_rays = opt.train_schedule.n_rays_rest
     model = bench.build_model(opt, it0, int(opt.data.num_views))
+    if args.scene == "blobs":
+        from joint_tensorf_amd.synthetic import bake_blobs
+        bake_blobs(model.graph.nerf.tensorf, n_blobs=12, seed=0)
     views = make_views(opt, int(opt.data.num_views), seed=0, device=dev)
     pose, pose_GT = model.get_all_training_poses(opt, views["pose"])
     _, model.graph.sim3 = model.prealign_cameras(opt, pose, pose_GT)
@@ -69,7 +74,8 @@ def main():
                         "grid": g.nerf.tensorf.gridSize.tolist(), "ms_per_image": t_render * 1e3,
                         "rays_per_s": rays / t_render, "launch": "hipGraph replay" if args.graph else "eager", "Msamples_per_s": rays * g.nerf.n_samples / t_render / 1e6},
         "test_time_optim": {"rays_per_iter": int(v.rgb.shape[1]), "ms_per_iter": t_opt * 1e3,
-                            "iters": args.test_iters, "backward": "pose-only (no factor / weight gradients)"}}))
+                            "iters": args.test_iters, "scene": args.scene,
+                            "launch": dict(model._test_optim_graph.stats) if args.graph else "eager", "backward": "pose-only (no factor / weight gradients)"}}))
 
 
 if __name__ == "__main__":
