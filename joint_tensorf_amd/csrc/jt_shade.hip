@@ -20,6 +20,36 @@
 
 namespace jt {
 
+// Record traffic is streaming (1.2 GB written per launch, read once by the backward a millisecond later, far more
+// than L2 + Infinity Cache hold): non-temporal accesses keep it from evicting the factor set the gathers live on.
+#ifndef JT_REC_NT
+#define JT_REC_NT 1
+#endif
+__device__ inline void rec_st(float* p, float v) {
+#if JT_REC_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ inline float rec_ld(const float* p) {
+#if JT_REC_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ inline float4 rec_ld4(const float* p) {
+#if JT_REC_NT
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return ld4(p);
+#endif
+}
+
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __host__ __device__ constexpr int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -170,7 +200,7 @@ __device__ inline f32x16 gather_basis(const Dev& D, const float* s, const float 
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float bv = live ? pr[k] : 0.f;
-        if (REC && live && onrec) rt[(size_t)(BwdCfg<C>::R_PROD + i * C::CA + c0 + k) * 32 + j] = pr[k];
+        if (REC && live && onrec) rec_st(rt + (size_t)(BwdCfg<C>::R_PROD + i * C::CA + c0 + k) * 32 + j, pr[k]);
         float av = sb[i * C::CA + c0 + k];
         facc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, facc, 0, 0, 0);
       }
@@ -387,7 +417,7 @@ __device__ inline void rec_store(float* rt, int row0, const f32x16* v, int j, in
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rt[(size_t)(row0 + t * 32 + rowmap(r, 0) + 4 * h) * 32 + j] = v[t][r];
+    for (int r = 0; r < 16; ++r) rec_st(rt + (size_t)(row0 + t * 32 + rowmap(r, 0) + 4 * h) * 32 + j, v[t][r]);
 }
 
 // REC = 1 (training): besides rgb the kernel leaves the tile-blocked records of the layer inputs (see BwdCfg) so
@@ -425,8 +455,8 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
     if (REC && on && h == 0) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        if (REC == 1) rt[(size_t)(B::R_VD + c) * 32 + j] = vd[c];
-        rt[(size_t)(B::R_GEO + c) * 32 + j] = g.n[c];
+        if (REC == 1) rec_st(rt + (size_t)(B::R_VD + c) * 32 + j, vd[c]);
+        rec_st(rt + (size_t)(B::R_GEO + c) * 32 + j, g.n[c]);
       }
     }
     f32x16 facc = gather_basis<C, REC == 1>(D, smem, g.n, j, h, rt, on);
@@ -439,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
       for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mask1 |= (h1.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
-      if (on) rt[(size_t)(B::R_MASK + h) * 32 + j] = __uint_as_float(mask1);
+      if (on) rec_st(rt + (size_t)(B::R_MASK + h) * 32 + j, __uint_as_float(mask1));
       if (REC == 1) rec_store<C::MT>(rt, B::R_H1, h1.v, j, h, on);
     }
     Hidden<C> h2 = layer2<C>(smem, h1, j, h);
@@ -450,14 +480,14 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
       for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mask2 |= (h2.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
-      if (on) rt[(size_t)(B::R_MASK + 2 + h) * 32 + j] = __uint_as_float(mask2);
+      if (on) rec_st(rt + (size_t)(B::R_MASK + 2 + h) * 32 + j, __uint_as_float(mask2));
       if (REC == 1) rec_store<C::MT>(rt, B::R_MID + HOFF, h2.v, j, h, on);
       if (REC == 1 && C::KIND != JT_MLP_FEA) {
         float pe[12];
         view_pe(vd, pm, pe);
         if (on && h == 0) {
 #pragma unroll
-          for (int k = 0; k < 12; ++k) rt[(size_t)(B::R_MID + k) * 32 + j] = pe[k];
+          for (int k = 0; k < 12; ++k) rec_st(rt + (size_t)(B::R_MID + k) * 32 + j, pe[k]);
         }
       }
     }
@@ -584,17 +614,17 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
     float* rt = rec + (size_t)tile * RC * 32;  // this tile's record block (layer inputs left by the forward)
     const int jj = on ? j : nlive - 1;         // padding lanes mirror the last live sample
     if (h == 0) {
-      geo[j * 4 + 0] = rt[(size_t)(B::R_GEO + 0) * 32 + jj];
-      geo[j * 4 + 1] = rt[(size_t)(B::R_GEO + 1) * 32 + jj];
-      geo[j * 4 + 2] = rt[(size_t)(B::R_GEO + 2) * 32 + jj];
+      geo[j * 4 + 0] = rec_ld(rt + (size_t)(B::R_GEO + 0) * 32 + jj);
+      geo[j * 4 + 1] = rec_ld(rt + (size_t)(B::R_GEO + 1) * 32 + jj);
+      geo[j * 4 + 2] = rec_ld(rt + (size_t)(B::R_GEO + 2) * 32 + jj);
       gxyz[j * 4 + 0] = gxyz[j * 4 + 1] = gxyz[j * 4 + 2] = 0.f;
     }
     // basis_mat output of the forward (accumulator layout) and the ReLU sign bits of both hidden layers
     f32x16 facc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) facc[r] = rt[(size_t)(B::R_F + rowmap(r, 0) + 4 * h) * 32 + jj];
-    const unsigned mask1 = __float_as_uint(rt[(size_t)(B::R_MASK + h) * 32 + jj]);
-    const unsigned mask2 = __float_as_uint(rt[(size_t)(B::R_MASK + 2 + h) * 32 + jj]);
+    for (int r = 0; r < 16; ++r) facc[r] = rec_ld(rt + (size_t)(B::R_F + rowmap(r, 0) + 4 * h) * 32 + jj);
+    const unsigned mask1 = __float_as_uint(rec_ld(rt + (size_t)(B::R_MASK + h) * 32 + jj));
+    const unsigned mask2 = __float_as_uint(rec_ld(rt + (size_t)(B::R_MASK + 2 + h) * 32 + jj));
     // sin / cos of the features, parked in the wave's LDS scratch for the layer-1 backward
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -613,7 +643,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
     }
     if (onrec && h == 0) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) rt[(size_t)(B::R_GO + c) * 32 + j] = go[c];
+      for (int c = 0; c < 3; ++c) rec_st(rt + (size_t)(B::R_GO + c) * 32 + j, go[c]);
     }
     Hidden<C> G2;
 #pragma unroll
