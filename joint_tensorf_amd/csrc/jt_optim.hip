@@ -10,6 +10,19 @@
 
 namespace jt {
 
+#ifndef JT_ADAM_NT
+#define JT_ADAM_NT 1
+#endif
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+__device__ inline float4 nt_ld4(const float* p) {
+  const v4f_nt v = __builtin_nontemporal_load(reinterpret_cast<const v4f_nt*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ inline void nt_st4(float* p, float4 a) {
+  v4f_nt v = {a.x, a.y, a.z, a.w};
+  __builtin_nontemporal_store(v, reinterpret_cast<v4f_nt*>(p));
+}
+
 constexpr int kAdamMaxItems = 32;
 constexpr int kAdamElemsPerBlock = 256 * 4 * 4;  // 256 threads x 4 float4
 
@@ -64,16 +77,27 @@ __global__ __launch_bounds__(256) void k_adam_batch(AdamBatch B) {
   for (int k = 0; k < 4; ++k) {
     const long i = base + ((long)k * 256 + threadIdx.x) * 4;
     if (i + 3 < T.n) {
+#if JT_ADAM_NT
+      // the gradient and both moments stream through once per iteration; only the parameters are read again soon
+      float4 p = *reinterpret_cast<float4*>(T.p + i), m = nt_ld4(T.m + i), v = nt_ld4(T.v + i);
+      const float4 g = nt_ld4(T.g + i);
+#else
       float4 p = *reinterpret_cast<float4*>(T.p + i), m = *reinterpret_cast<float4*>(T.m + i),
              v = *reinterpret_cast<float4*>(T.v + i);
       const float4 g = ld4(T.g + i);
+#endif
       adam1(p.x, g.x, m.x, v.x, B.b1, B.b2, B.eps, step_size, inv_bc2_sqrt);
       adam1(p.y, g.y, m.y, v.y, B.b1, B.b2, B.eps, step_size, inv_bc2_sqrt);
       adam1(p.z, g.z, m.z, v.z, B.b1, B.b2, B.eps, step_size, inv_bc2_sqrt);
       adam1(p.w, g.w, m.w, v.w, B.b1, B.b2, B.eps, step_size, inv_bc2_sqrt);
       *reinterpret_cast<float4*>(T.p + i) = p;
+#if JT_ADAM_NT
+      nt_st4(T.m + i, m);
+      nt_st4(T.v + i, v);
+#else
       *reinterpret_cast<float4*>(T.m + i) = m;
       *reinterpret_cast<float4*>(T.v + i) = v;
+#endif
     } else {
       for (long j = i; j < T.n && j < i + 4; ++j)
         adam1(T.p[j], T.g[j], T.m[j], T.v[j], B.b1, B.b2, B.eps, step_size, inv_bc2_sqrt);
