@@ -370,3 +370,46 @@ def test_vmadam_matches_torch_adam():
     assert float(ref2.state[ref_p[0]]["step"]) == 6.0
     m_ref = ref.state[ref_p[0]]["exp_avg"].numpy()
     np.testing.assert_allclose(ref2.state[ref_p[0]]["exp_avg"].numpy(), m_ref, rtol=2e-6, atol=1e-7 * np.abs(m_ref).max())
+
+
+def test_adam_entry_points_by_value_and_device_coefficients_agree():
+    """jt_adam_step (coefficients as launch arguments) and jt_adam_step_dyn (coefficients poked into device memory
+    with jt_poke, the variant a hipGraph replays) are the same update (to the last-bit rounding of the coefficient)."""
+    import ctypes
+    import math
+    from joint_tensorf_amd import ops
+    from joint_tensorf_amd._lib import JtAdamItem, check, lib, ptr
+    torch.manual_seed(3)
+    sizes = [4096 + 8, 1000, 64]
+    base = [(torch.randn(n, device=DEV), torch.randn(n, device=DEV), torch.rand(n, device=DEV), torch.rand(n, device=DEV))
+            for n in sizes]
+    lrs, t, b1, b2, eps = [1e-2, 5e-4, 3e-3], 7, 0.9, 0.99, 1e-8
+    out = []
+    for dyn_path in (False, True):
+        ts = [[x.clone() for x in item] for item in base]
+        arr = (JtAdamItem * len(ts))()
+        coefs = []
+        for k, (p, g, m, v) in enumerate(ts):
+            arr[k].p, arr[k].g, arr[k].m, arr[k].v, arr[k].n = ptr(p), ptr(g), ptr(m), ptr(v), p.numel()
+            bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
+            arr[k].lr, arr[k].bias_correction1, arr[k].bias_correction2 = lrs[k], bc1, bc2
+            # what jt_adam_step derives from its float arguments, computed the same way
+            f = ctypes.c_float
+            coefs += [f(f(lrs[k]).value / f(bc1).value).value, f(1.0 / math.sqrt(f(bc2).value)).value]
+        st = ops._stream()
+        if dyn_path:
+            dyn = torch.zeros(2 * len(ts), device=DEV)
+            ops.poke_floats(dyn, coefs)
+            check(lib.jt_adam_step_dyn(arr, len(ts), b1, b2, eps, ptr(dyn), st), "jt_adam_step_dyn")
+        else:
+            check(lib.jt_adam_step(arr, len(ts), b1, b2, eps, st), "jt_adam_step")
+        torch.cuda.synchronize()
+        out.append(ts)
+    for a, b in zip(*out):
+        for x, y in zip(a, b):
+            torch.testing.assert_close(y, x, rtol=2e-6, atol=1e-9)
+    # jt_poke: words arrive where they are sent, nothing around them is touched
+    buf = torch.full((16,), -1, device=DEV, dtype=torch.int32)
+    ops.poke_words(buf, [7, 11, 13], offset=5)
+    assert buf.tolist() == [-1] * 5 + [7, 11, 13] + [-1] * 8
+    assert lib.jt_poke(None, None, 1, None) != 0 and lib.jt_poke(ptr(buf), (ctypes.c_uint32 * 1)(), 257, None) != 0
