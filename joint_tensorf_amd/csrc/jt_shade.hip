@@ -1039,7 +1039,17 @@ static int shade_kind(const JtScene* s) {
 // gradients].  Every chunk has its own record block so that the weight-gradient GEMMs of all chunks can run
 // on an auxiliary stream, concurrently with whatever the caller enqueues next on the main stream (the
 // density backward: atomics / VALU bound, while the GEMMs are MFMA bound).
-static const int kChunkEntries = 1 << 20;
+// shaded samples per backward launch (and per set of weight-gradient GEMMs); JT_SHADE_CHUNK_LOG2 overrides (16..22)
+static int chunk_entries() {
+  static const int n = [] {
+    const char* e = getenv("JT_SHADE_CHUNK_LOG2");
+    int l = e ? atoi(e) : 22;  // measured: 2^20 4.48 ms / step, 2^21 4.34, 2^22 4.33 (fewer launches, slabs and tails)
+    if (l < 16 || l > 22) l = 22;
+    return 1 << l;
+  }();
+  return n;
+}
+#define kChunkEntries (chunk_entries())
 static const int kNoGradRecords = 1 << 8;  // internal flag of launch_shade_bwd
 static const int kWgradBlocks = 512;
 
@@ -1051,9 +1061,12 @@ struct WsLayout {
                           P1 = (size_t)C::MT * NT1 * 1024 + C::MT * 32, PB = 1 * NTB * 1024 + 32;
   static size_t rec_floats_per_chunk() { return (size_t)B::REC_FLOATS * kChunkEntries; }
   static size_t slab_floats_per_chunk() { return (P3 + P2 + P1 + PB) * kWgradBlocks; }
+  // records of all chunks are one contiguous tile-blocked array (a chunk is a whole number of 32-sample tiles), so
+  // they take what `cap` samples need, not whole chunks; the slabs follow
+  static size_t rec_floats(int cap) { return (size_t)B::REC_FLOATS * (((size_t)std::max(cap, 1) + 31) / 32 * 32); }
   static size_t bytes(int cap) {
     const int nchunks = (cap + kChunkEntries - 1) / kChunkEntries;
-    return (rec_floats_per_chunk() + slab_floats_per_chunk()) * (size_t)std::max(nchunks, 1) * sizeof(float);
+    return (rec_floats(cap) + slab_floats_per_chunk() * (size_t)std::max(nchunks, 1)) * sizeof(float);
   }
 };
 
@@ -1143,7 +1156,7 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_bwd<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   float* recs = ws;
-  float* slabs = ws + W::rec_floats_per_chunk() * (size_t)nchunks;
+  float* slabs = ws + W::rec_floats(cap);
   const size_t cstride = W::slab_floats_per_chunk();
   const int nb = kWgradBlocks;
   const char* abl_env = getenv("JT_ABLATE");  // profiling only: 1 = no scatter, 2 = no records, 4 = no wgrad
@@ -1151,25 +1164,23 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
                      ((flags & kNoGradRecords) ? 2 : 0);
   constexpr int NT3 = W::NT3, NT1 = W::NT1, NTB = W::NTB;
   constexpr int XF1 = (C::KIND == JT_MLP_FEA) ? 1 : 2;
-  // ---- per-sample backward of every chunk on the main stream ----
-  for (int ci = 0; ci < nchunks; ++ci) {
+  // ---- per chunk: the per-sample backward on the main stream, its weight-gradient GEMMs on the auxiliary stream ----
+  // (the GEMMs of chunk c stream the records of chunk c while the backward of chunk c + 1 runs: the backward holds
+  //  one 155 KB-LDS workgroup per CU at two waves per SIMD, the GEMMs need no LDS and fit beside it)
+  const bool use_aux = aux && ev_fork && ev_join && !(ablate & 4);
+  static const bool pipe = [] { const char* e = getenv("JT_WGRAD_PIPE"); return !e || atoi(e) != 0; }();
+  hipStream_t ws_st = use_aux ? aux : st;
+  const int RR = B::REC_FLOATS;
+  auto launch_bwd = [&](int ci) -> int {
     const int start = ci * chunk, ccap = std::min(chunk, cap - start);
     long tiles = ((long)ccap + 31) / 32;
     int blocks = (int)std::min<long>((tiles + B::NWAVE - 1) / B::NWAVE, 256);
     hipLaunchKernelGGL(k_shade_bwd<C>, dim3(blocks), dim3(512), lds, st, D, M, pm, G, offset, R, rgb_s, g_rgb_s,
                        g_xyz, recs + W::rec_floats_per_chunk() * ci, start, ccap, cap, ablate);
     JT_LAUNCH_CHECK();
-  }
-  if (ablate & 4) return JT_OK;
-  // ---- weight gradients: on the auxiliary stream when the caller provided one ----
-  hipStream_t ws_st = st;
-  if (aux && ev_fork && ev_join) {
-    if (hipEventRecord(ev_fork, st) != hipSuccess) return JT_ERR_ARG;
-    if (hipStreamWaitEvent(aux, ev_fork, 0) != hipSuccess) return JT_ERR_ARG;
-    ws_st = aux;
-  }
-  const int RR = B::REC_FLOATS;
-  for (int ci = 0; ci < nchunks; ++ci) {
+    return JT_OK;
+  };
+  auto launch_wgrad = [&](int ci) -> int {
     const int start = ci * chunk, ccap = std::min(chunk, cap - start);
     const float* rec = recs + W::rec_floats_per_chunk() * ci;
     // dW3/db3 = GO^T MID ; dW2/db2 = G2^T H1 ; dW1/db1 = G1^T X(F, d) ; dBasis = GF^T PROD
@@ -1189,6 +1200,27 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     hipLaunchKernelGGL((k_wgrad<1, NTB, 0>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_GF, C::APP, B::R_PROD, C::NC,
                        B::R_F, B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, sb);
     JT_LAUNCH_CHECK();
+    return JT_OK;
+  };
+  for (int ci = 0; ci < nchunks; ++ci) {
+    int rc = launch_bwd(ci);
+    if (rc) return rc;
+    if (use_aux && pipe) {
+      if (hipEventRecord(ev_fork, st) != hipSuccess) return JT_ERR_ARG;
+      if (hipStreamWaitEvent(aux, ev_fork, 0) != hipSuccess) return JT_ERR_ARG;
+      if ((rc = launch_wgrad(ci))) return rc;
+    }
+  }
+  if (ablate & 4) return JT_OK;
+  if (use_aux && !pipe) {
+    if (hipEventRecord(ev_fork, st) != hipSuccess) return JT_ERR_ARG;
+    if (hipStreamWaitEvent(aux, ev_fork, 0) != hipSuccess) return JT_ERR_ARG;
+  }
+  if (!(use_aux && pipe)) {
+    for (int ci = 0; ci < nchunks; ++ci) {
+      int rc = launch_wgrad(ci);
+      if (rc) return rc;
+    }
   }
   {
     float* s3 = slabs;
