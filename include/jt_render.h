@@ -279,6 +279,15 @@ int jt_render_loss_backward(const float* rgb, const float* image, const int64_t*
                             int n_views, int rays_per_view, int n_pixels, float edge_factor, float non_edge_factor,
                             const float* acc4, const float* g_loss, float* g_rgb, void* stream);
 
+/* The weighted sum of Model.summarize_loss (model/tensorf.py:31-47) over the photometric term and the three
+ * regularisers, one launch each way:  total = w_render render[0] + w_l1 reg3[0] + w_tv_density reg3[1] +
+ * w_tv_color reg3[2]  (reg3 = the out3 of jt_reg_losses_forward; a term with weight 0 is left out, as the reference
+ * leaves it out);  backward: g_render[0] = g_total[0] w_render, g_reg3[k] = g_total[0] w_k. */
+int jt_loss_sum_forward(const float* render, const float* reg3, float w_render, float w_l1, float w_tv_density,
+                        float w_tv_color, float* total, void* stream);
+int jt_loss_sum_backward(const float* g_total, float w_render, float w_l1, float w_tv_density, float w_tv_color,
+                         float* g_render, float* g_reg3, void* stream);
+
 /* All regularisers of one scene in one call (replaces the loop bodies of model/tensorf.py:127-130):
  *   out3 = { density_L1(), TV_loss_density(TVLoss()), TV_loss_app(TVLoss()) }   (tensoRF.py:212-228).
  * plane_hw_line[9] = {H_i, W_i, L_i} for i = 0..2; scratch36: 36 floats of device scratch.

@@ -86,6 +86,32 @@ __global__ __launch_bounds__(256) void k_render_loss_bwd(const float* __restrict
   }
 }
 
+// total = w_render * render + w_reg . reg3  and its backward: the weighted sum of model/tensorf.py:31-47 as one launch
+// each way (as stock ops: a multiply and an add per term, a select-backward fill + copy per regulariser, ...).
+__global__ void k_loss_sum_fwd(const float* __restrict__ render, const float* __restrict__ reg3, float wr, float w0,
+                               float w1, float w2, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float t = 0.f;
+    // a term whose weight is zero does not enter the sum (the reference skips it: a NaN there must not spread)
+    if (wr != 0.f) t += wr * render[0];
+    t += w0 * reg3[0];  // the L1 term is always added (model/tensorf.py:39-41)
+    if (w1 != 0.f) t += w1 * reg3[1];
+    if (w2 != 0.f) t += w2 * reg3[2];
+    out[0] = t;
+  }
+}
+
+__global__ void k_loss_sum_bwd(const float* __restrict__ g, float wr, float w0, float w1, float w2,
+                               float* __restrict__ g_render, float* __restrict__ g_reg3) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float gg = g[0];
+    g_render[0] = gg * wr;
+    g_reg3[0] = gg * w0;
+    g_reg3[1] = gg * w1;
+    g_reg3[2] = gg * w2;
+  }
+}
+
 }  // namespace jt
 
 using namespace jt;
@@ -120,6 +146,24 @@ extern "C" int jt_render_loss_backward(const float* rgb, const float* image, con
   int blocks = (int)min((n + 255) / 256, 512L);
   hipLaunchKernelGGL(k_render_loss_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rgb, image, ray_idx,
                      edge_mask, n_views, rays_per_view, n_pixels, acc4, edge_factor, non_edge_factor, g_loss, g_rgb);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
+extern "C" int jt_loss_sum_forward(const float* render, const float* reg3, float w_render, float w_l1,
+                                   float w_tv_density, float w_tv_color, float* total, void* stream) {
+  if (!render || !reg3 || !total) return JT_ERR_ARG;
+  hipLaunchKernelGGL(k_loss_sum_fwd, dim3(1), dim3(64), 0, (hipStream_t)stream, render, reg3, w_render, w_l1,
+                     w_tv_density, w_tv_color, total);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
+extern "C" int jt_loss_sum_backward(const float* g_total, float w_render, float w_l1, float w_tv_density,
+                                    float w_tv_color, float* g_render, float* g_reg3, void* stream) {
+  if (!g_total || !g_render || !g_reg3) return JT_ERR_ARG;
+  hipLaunchKernelGGL(k_loss_sum_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, g_total, w_render, w_l1, w_tv_density,
+                     w_tv_color, g_render, g_reg3);
   JT_LAUNCH_CHECK();
   return JT_OK;
 }

@@ -184,9 +184,12 @@ class Graph(torch.nn.Module):
     # ---- pose (model/bat.py:341-367) -------------------------------------------------------------
     def get_pose(self, opt, var, mode=None):
         if mode == "train":
-            var.se3_refine = self.se3_refine.weight[var.idx]
+            # all views in their own order (the BAT loops train on every view in every iteration): the gather
+            # weight[idx] and its scatter-add backward are the identity -- a dozen tiny launches saved per iteration
+            full = self._is_all_views(var.idx, self.se3_refine.weight.shape[0])
+            var.se3_refine = self.se3_refine.weight if full else self.se3_refine.weight[var.idx]
             if opt.data.dataset == "blender":
-                noise = self.pose_noise[var.idx] if opt.camera.noise else None
+                noise = (self.pose_noise if full else self.pose_noise[var.idx]) if opt.camera.noise else None
                 if noise is not None:
                     var.pose_noise = noise
                 return ops.train_pose(var.se3_refine, noise, var.pose)
@@ -204,6 +207,29 @@ class Graph(torch.nn.Module):
                 pose = torch.cat([pose[..., :3] @ pr[..., :3], pose[..., :3] @ pr[..., 3:] + pose[..., 3:]], -1)
             return pose
         return var.pose
+
+    def _is_all_views(self, idx, n):
+        """idx == arange(n)?  Decided once per index tensor (one host read), remembered by its storage."""
+        if not torch.is_tensor(idx) or idx.dim() != 1 or idx.shape[0] != n:
+            return False
+        key = (idx.data_ptr(), idx._version, n)
+        memo = self.__dict__.setdefault("_all_views_memo", {})
+        if key not in memo:
+            if len(memo) > 64:
+                memo.clear()
+            memo[key] = bool(torch.equal(idx, torch.arange(n, device=idx.device, dtype=idx.dtype)))
+        return memo[key]
+
+    def _lattice_base(self, opt, step, ny, nx):
+        """pixel indices of the (ny, nx) lattice at offset (0, 0), cached: the lattice of an iteration is base + ox +
+        oy W -- one launch instead of two aranges, a meshgrid and three elementwise kernels."""
+        key = (int(step), int(ny), int(nx), int(opt.W), str(opt.device))
+        memo = self.__dict__.setdefault("_lattice_memo", {})
+        if key not in memo:
+            sx = torch.arange(nx, device=opt.device) * step
+            sy = torch.arange(ny, device=opt.device) * step
+            memo[key] = (sx[None, :] + sy[:, None] * opt.W).reshape(-1)
+        return memo[key]
 
     @staticmethod
     def lattice_step(opt, batch_size):
@@ -233,11 +259,9 @@ class Graph(torch.nn.Module):
                     from ..dist import rank_lattice_offset
                     ox = rank_lattice_offset(ox, step, opt.W, *self.lattice_rank)
                     oy = rank_lattice_offset(oy, step, opt.H, *self.lattice_rank)
-                sx = torch.arange(ox, opt.W, step, device=opt.device)
-                sy = torch.arange(oy, opt.H, step, device=opt.device)
-                gY, gX = torch.meshgrid(sy, sx, indexing="ij")
-                var.ray_idx = (gX + gY * opt.W).view(-1)
-                var.ray_grid_step, var.grid_H, var.grid_W = step, len(sy), len(sx)
+                nx, ny = len(range(ox, opt.W, step)), len(range(oy, opt.H, step))
+                var.ray_idx = self._lattice_base(opt, step, ny, nx) + (ox + oy * opt.W)
+                var.ray_grid_step, var.grid_H, var.grid_W = step, ny, nx
             else:
                 assert strat == "single_view_rand_rays"
                 var.ray_idx = torch.randperm(opt.H * opt.W, device=opt.device)[:opt.nerf.n_rays]
@@ -406,6 +430,10 @@ class Model(torch.nn.Module):
         total = 0.0
         # ray-sharded data parallelism: only the photometric term is a mean over the (global) ray batch
         render_scale = float(getattr(self, "render_loss_scale", 1.0))
+        fused = self._summarize_fused(opt, loss, render_scale)
+        if fused is not None:
+            loss.update(all=fused)
+            return loss
         for key in loss:
             assert key in opt.loss_weight, f"loss {key} not in opt.loss_weight"
             if key == "L1":
@@ -420,6 +448,25 @@ class Model(torch.nn.Module):
                     total = total + w * loss[key]
         loss.update(all=total)
         return loss
+
+    def _summarize_fused(self, opt, loss, render_scale):
+        """The same weighted sum, same order of terms, as ONE launch each way (ops.loss_sum) when the terms are the
+        four of the BAT yamls and live on the GPU; None otherwise (the generic loop below then does it)."""
+        keys = list(loss.keys())
+        if not (len(keys) >= 4 and keys[:4] == ["render", "L1", "TV_density", "TV_color"]):
+            return None
+        if not (torch.is_tensor(loss.render) and loss.render.is_cuda and opt.loss_weight.render is not None):
+            return None
+        for key in keys[4:]:   # e.g. LLFF's TV_depth: fine as long as its weight keeps it out of the sum
+            assert key in opt.loss_weight, f"loss {key} not in opt.loss_weight"
+            if key == "all" or (opt.loss_weight[key] is not None and float(opt.loss_weight[key]) != 0.0):
+                return None
+        tf = self.graph.nerf.tensorf
+        first = opt.train_schedule.update_alphamask_iters[0]
+        w_l1 = float(opt.loss_weight.L1.rest if self.it > first else opt.loss_weight.L1.init)
+        w_tvd = float(opt.loss_weight.TV_density or 0.0) * float(getattr(self.graph.tvloss, "TVLoss_weight", 1))
+        w_tvc = float(opt.loss_weight.TV_color or 0.0) * float(getattr(self.graph.tvloss, "TVLoss_weight", 1))
+        return ops.loss_sum(loss.render, tf._reg(), float(opt.loss_weight.render) * render_scale, w_l1, w_tvd, w_tvc)
 
     def train_iteration(self, opt, var):
         """One optimisation step (model/bat.py:96-116 around model/base.py:154-172)."""

@@ -674,6 +674,35 @@ def reg_losses(density_plane, density_line, app_plane, app_line, with_tv_density
     return RegLosses.apply(with_tv_density, with_tv_app, *density_plane, *density_line, *app_plane, *app_line)
 
 
+class LossSum(torch.autograd.Function):
+    """total = w_render * render + (w_l1, w_tv_density, w_tv_color) . reg3 (Model.summarize_loss,
+    model/tensorf.py:31-47) in one launch each way; as stock ops the same sum is a multiply and an add per term
+    plus a select-backward (fill + copy) per regulariser -- twenty launches of a few microseconds each."""
+
+    @staticmethod
+    def forward(ctx, render, reg3, w_render, w_l1, w_tvd, w_tvc):
+        r = render.detach().reshape(1).float()
+        q = reg3.detach().contiguous().float()
+        out = torch.empty(1, device=r.device, dtype=torch.float32)
+        check(lib.jt_loss_sum_forward(ptr(r), ptr(q), w_render, w_l1, w_tvd, w_tvc, ptr(out), _stream()),
+              "jt_loss_sum_forward")
+        ctx.w = (float(w_render), float(w_l1), float(w_tvd), float(w_tvc))
+        ctx.render_shape = render.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        gc = g.contiguous().float().reshape(1)
+        g_render = torch.empty(1, device=gc.device, dtype=torch.float32)
+        g_reg = torch.empty(3, device=gc.device, dtype=torch.float32)
+        check(lib.jt_loss_sum_backward(ptr(gc), *ctx.w, ptr(g_render), ptr(g_reg), _stream()), "jt_loss_sum_backward")
+        return g_render.reshape(ctx.render_shape), g_reg, None, None, None, None
+
+
+def loss_sum(render, reg3, w_render, w_l1, w_tv_density, w_tv_color):
+    return LossSum.apply(render, reg3, float(w_render), float(w_l1), float(w_tv_density), float(w_tv_color))
+
+
 class RenderLoss(torch.autograd.Function):
     """nanmean squared error between rgb [B,r,3] and the GT pixels image[:, :, ray_idx], optionally with the
     hard edge-mask split (model/tensorf.py:112-124, base.py:259-261) -- one kernel each way."""

@@ -73,7 +73,7 @@ def test_graph_replay_follows_the_eager_trajectory(it0):
     l_g, sd_g, stats, rs_g = _run(True, K, it0)
     assert stats["captured"] >= 2 and stats["replayed"] >= K - 4, stats
     assert (rs_e == rs_g).all()  # the host random stream is consumed identically
-    np.testing.assert_allclose(l_g, l_e, rtol=1e-3, atol=1e-8)
+    np.testing.assert_allclose(l_g, l_e, rtol=5e-3, atol=1e-8)
     for k in sd_e:
         a, b = sd_e[k].float(), sd_g[k].float()
         tol = 1e-2 if "density" in k else 0.2
