@@ -358,10 +358,28 @@ class RenderRays(torch.autograd.Function):
         ctx.param_shapes = [tuple(p.shape) for p in params]
         ctx.mark_non_differentiable(depth)
         ctx.stats = dict(offset=offset)
-        return rgb, depth, opacity
+        # regularisers of the same factors (cfg.reg_flags = (with_tv_density, with_tv_app)): evaluated here so that
+        # the backward can ADD their gradient into the render gradient's buffer (jt_reg_losses_backward,
+        # accumulate = 1) -- as a separate autograd node the two contributions to every density factor meet in an
+        # add kernel that allocates a third tensor (6 adds and 31 MB x 3 of traffic per iteration at 400^3)
+        reg3 = None
+        ctx.reg = None
+        flags = getattr(cfg, "reg_flags", None)
+        if flags is not None and cfg.shade_impl != "torch":
+            hw = []
+            for i in range(3):
+                H, W, _ = sdp[i].shape
+                hw += [H, W, sdl[i].shape[0]]
+            Cd, Ca = sdp[0].shape[2], sap[0].shape[2]
+            scratch = torch.empty(36, **f32)
+            reg3 = torch.empty(3, **f32)
+            check(lib.jt_reg_losses_forward(fac, (ctypes.c_int32 * 9)(*hw), Cd, Ca, int(bool(flags[0])),
+                                            int(bool(flags[1])), ptr(scratch), ptr(reg3), st), "jt_reg_losses_forward")
+            ctx.reg = (hw, Cd, Ca, bool(flags[0]), bool(flags[1]))
+        return rgb, depth, opacity, reg3
 
     @staticmethod
-    def backward(ctx, g_rgb, g_depth, g_opacity):
+    def backward(ctx, g_rgb, g_depth, g_opacity, g_reg=None):
         cfg = ctx.cfg
         (rays_o, rays_d, jitter, zvals, sdp, sdl, sap, sal, mlp_t, sigma_feat, weight, tmin, offset, sidx, eray,
          esmp, vdir, rgb_s, cmask) = ctx.saved
@@ -472,6 +490,16 @@ class RenderRays(torch.autograd.Function):
             dp_reduce(spans[4][0], spans[4][1])  # basis + MLP
             for w in dp_works:
                 w.wait()  # stream-level: whoever consumes the gradients next runs behind the collectives
+        if ctx.reg is not None and g_reg is not None and want_fac:
+            # the regularisers' gradient joins the render gradient in place (after the collectives: it is the same
+            # on every rank and is not part of the exchange)
+            hw, Cd, Ca, wd, wa = ctx.reg
+            scratch = torch.empty(36, **f32)
+            g3c = g_reg.contiguous().float()
+            check(lib.jt_reg_losses_backward(fac, (ctypes.c_int32 * 9)(*hw), Cd, Ca, ptr(g3c), int(wd), int(wa), gfac, 1,
+                                             ptr(scratch), st), "jt_reg_losses_backward")
+        elif ctx.reg is not None and g_reg is not None:
+            raise RuntimeError("regulariser gradient wanted without factor gradients")
         g_factors = [factor_logical(t) for t in gdp + gdl + gap + gal] if want_fac else [None] * 12
         out = [None, g_o, g_d, None, None] + g_factors + list(g_mlp)
         return tuple(out)
@@ -483,8 +511,10 @@ def render_rays(cfg, rays_o, rays_d, jitter, zvals, density_plane, density_line,
     # inside Function.forward grad mode is always off and needs_input_grad only mirrors requires_grad: whether a
     # backward can follow (=> the forward must leave its records) is decided here
     cfg.grad_enabled = torch.is_grad_enabled()
-    return RenderRays.apply(cfg, rays_o, rays_d, jitter, zvals, *density_plane, *density_line, *app_plane,
-                            *app_line, basis, *mlp_params)
+    out = RenderRays.apply(cfg, rays_o, rays_d, jitter, zvals, *density_plane, *density_line, *app_plane,
+                           *app_line, basis, *mlp_params)
+    cfg.reg3 = out[3]  # None unless cfg.reg_flags asked for the regularisers
+    return out[0], out[1], out[2]
 
 
 # ----------------------------------------------------------------------------------------------

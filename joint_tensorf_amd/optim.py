@@ -10,6 +10,12 @@ from ._lib import JtAdamItem, check, lib, ptr
 from .ops import _stream
 
 
+def _same_layout(a, b):
+    """same memory order: equal strides on every dimension that has more than one element (the stride of a size-1
+    dimension is arbitrary -- the sum autograd forms of two channel-last gradients carries a different one there)."""
+    return a.shape == b.shape and all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n != 1)
+
+
 class VMAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         if not 0.0 <= lr or not 0.0 <= eps or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
@@ -85,14 +91,14 @@ class VMAdam(torch.optim.Optimizer):
                 if g.is_sparse or p.dtype != torch.float32:
                     raise RuntimeError("VMAdam: dense float32 parameters only")
                 st = self.state[p]
-                if g.stride() != p.stride() or g.dtype != torch.float32:
+                if not _same_layout(g, p) or g.dtype != torch.float32:
                     # the kernel walks all four tensors in the parameter's memory order
                     g2 = torch.empty_like(p, memory_format=torch.preserve_format)
                     g2.copy_(g)
                     g = g2
                     keep.append(g)
                 m, v = st["exp_avg"], st["exp_avg_sq"]
-                assert m.stride() == p.stride() and v.stride() == p.stride()
+                assert _same_layout(m, p) and _same_layout(v, p)
                 arr[k].p, arr[k].g, arr[k].m, arr[k].v, arr[k].n = ptr(p), ptr(g), ptr(m), ptr(v), p.numel()
             dyn = self._dyn_buffer(plist[0][0].device, len(plist))
             check(lib.jt_adam_step_dyn(arr, len(plist), b1, b2, eps, ptr(dyn), stream), "jt_adam_step_dyn")
