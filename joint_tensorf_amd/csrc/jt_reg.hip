@@ -11,13 +11,13 @@ __device__ inline float4 ld4z(const float* p, bool ok) { return ok ? ld4(p) : ma
 
 // out[0] += sum |x| ; out[1] += sum (down - x)^2 ; out[2] += sum (right - x)^2
 template <bool TV>
-__global__ __launch_bounds__(256) void k_factor_reg_fwd(const float* __restrict__ x, int H, int W, int C,
-                                                        float* __restrict__ out) {
+__device__ inline void factor_reg_fwd_body(const float* __restrict__ x, int H, int W, int C, float* __restrict__ out,
+                                           int bid, int nblocks) {
   __shared__ float red[4][3];
   const int C4 = C / 4;
   const long total = (long)H * W * C4;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+  for (long idx = bid * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)nblocks * blockDim.x) {
     const int c4 = (int)(idx % C4);
     const long tex = idx / C4;
     const int xx = (int)(tex % W), yy = (int)(tex / W);
@@ -51,15 +51,21 @@ __global__ __launch_bounds__(256) void k_factor_reg_fwd(const float* __restrict_
   }
 }
 
+template <bool TV>
+__global__ __launch_bounds__(256) void k_factor_reg_fwd(const float* __restrict__ x, int H, int W, int C,
+                                                        float* __restrict__ out) {
+  factor_reg_fwd_body<TV>(x, H, W, C, out, blockIdx.x, gridDim.x);
+}
+
 // g (+)= coef[0] * sign(x) + coef[1] * d/dx sum(down-x)^2 + coef[2] * d/dx sum(right-x)^2   (coef on the device)
-__global__ __launch_bounds__(256) void k_factor_reg_bwd(const float* __restrict__ x, int H, int W, int C,
-                                                        const float* __restrict__ coef, float* __restrict__ g,
-                                                        int accumulate) {
+__device__ inline void factor_reg_bwd_body(const float* __restrict__ x, int H, int W, int C,
+                                           const float* __restrict__ coef, float* __restrict__ g, int accumulate,
+                                           int bid, int nblocks) {
   const float c0 = coef[0], c1 = coef[1], c2 = coef[2];
   const int C4 = C / 4;
   const long total = (long)H * W * C4;
   const bool tv = (c1 != 0.f) || (c2 != 0.f);
-  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+  for (long idx = bid * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)nblocks * blockDim.x) {
     const int c4 = (int)(idx % C4);
     const long tex = idx / C4;
     const int xx = (int)(tex % W), yy = (int)(tex / W);
@@ -89,6 +95,46 @@ __global__ __launch_bounds__(256) void k_factor_reg_bwd(const float* __restrict_
     }
     *reinterpret_cast<float4*>(g + off) = r;
   }
+}
+
+__global__ __launch_bounds__(256) void k_factor_reg_bwd(const float* __restrict__ x, int H, int W, int C,
+                                                        const float* __restrict__ coef, float* __restrict__ g,
+                                                        int accumulate) {
+  factor_reg_bwd_body(x, H, W, C, coef, g, accumulate, blockIdx.x, gridDim.x);
+}
+
+// all tensors of a scene in ONE launch each way: block ranges per tensor, the same partition of every tensor as the
+// per-tensor launches (nine launches of 4-10 us become one)
+struct RegBatchItem {
+  const float* x;
+  float* g;
+  int H, W, C, tv, slot, block0, nblocks;
+};
+struct RegBatch {
+  RegBatchItem t[9];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void k_reg_batch_fwd(RegBatch B, float* __restrict__ scratch36) {
+  int it = 0;
+#pragma unroll 1
+  for (int i = 1; i < B.n; ++i)
+    if ((int)blockIdx.x >= B.t[i].block0) it = i;
+  const RegBatchItem& T = B.t[it];
+  const int bid = blockIdx.x - T.block0;
+  if (T.tv)
+    factor_reg_fwd_body<true>(T.x, T.H, T.W, T.C, scratch36 + T.slot * 3, bid, T.nblocks);
+  else
+    factor_reg_fwd_body<false>(T.x, T.H, T.W, T.C, scratch36 + T.slot * 3, bid, T.nblocks);
+}
+
+__global__ __launch_bounds__(256) void k_reg_batch_bwd(RegBatch B, const float* __restrict__ coef36, int accumulate) {
+  int it = 0;
+#pragma unroll 1
+  for (int i = 1; i < B.n; ++i)
+    if ((int)blockIdx.x >= B.t[i].block0) it = i;
+  const RegBatchItem& T = B.t[it];
+  factor_reg_bwd_body(T.x, T.H, T.W, T.C, coef36 + T.slot * 3, T.g, accumulate, blockIdx.x - T.block0, T.nblocks);
 }
 
 __global__ void k_reg_zero(float* __restrict__ p, int n) {
@@ -203,6 +249,9 @@ extern "C" int jt_reg_losses_forward(const JtFactors* factors, const int32_t* pl
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_reg_zero, dim3(1), dim3(64), 0, st, scratch36, 36);  // not a memset node: see jt_loss.hip
   JT_LAUNCH_CHECK();
+  RegBatch B;
+  B.n = 0;
+  int nblk = 0;
   for (int i = 0; i < 9; ++i) {  // app lines (9-11) enter no regulariser
     // a TV term whose weight is zero is not evaluated (it reads every texel three times): out3 carries 0 for it
     const bool tv = (i < 3 && with_tv_density) || (i >= 6 && with_tv_app);
@@ -210,12 +259,11 @@ extern "C" int jt_reg_losses_forward(const JtFactors* factors, const int32_t* pl
     const RegTensor& t = S.t[i];
     long total = (long)t.H * t.W * (t.C / 4);
     int blocks = (int)min((total + 255) / 256, 512L);  // every block ends in three same-address atomics
-    if (tv)
-      hipLaunchKernelGGL(k_factor_reg_fwd<true>, dim3(blocks), dim3(256), 0, st, t.x, t.H, t.W, t.C, scratch36 + i * 3);
-    else
-      hipLaunchKernelGGL(k_factor_reg_fwd<false>, dim3(blocks), dim3(256), 0, st, t.x, t.H, t.W, t.C, scratch36 + i * 3);
-    JT_LAUNCH_CHECK();
+    B.t[B.n++] = {t.x, nullptr, t.H, t.W, t.C, tv ? 1 : 0, i, nblk, blocks};
+    nblk += blocks;
   }
+  hipLaunchKernelGGL(k_reg_batch_fwd, dim3(nblk), dim3(256), 0, st, B, scratch36);
+  JT_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_reg_combine, dim3(1), dim3(64), 0, st, (const float*)scratch36, S, out3);
   JT_LAUNCH_CHECK();
   return JT_OK;
@@ -231,6 +279,9 @@ extern "C" int jt_reg_losses_backward(const JtFactors* factors, const int32_t* p
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_reg_coefs, dim3(1), dim3(64), 0, st, g3, S, scratch36);
   JT_LAUNCH_CHECK();
+  RegBatch B;
+  B.n = 0;
+  int nblk = 0;
   for (int i = 0; i < 9; ++i) {
     const bool dens = i < 6;
     const bool need = dens || (i >= 6 && with_tv_app);  // density tensors always carry the L1 term
@@ -240,9 +291,10 @@ extern "C" int jt_reg_losses_backward(const JtFactors* factors, const int32_t* p
     (void)with_tv_density;  // the TV coefficient of a density plane is on the device (0 when its weight is 0)
     long total = (long)t.H * t.W * (t.C / 4);
     int blocks = (int)min((total + 255) / 256, 2048L);
-    hipLaunchKernelGGL(k_factor_reg_bwd, dim3(blocks), dim3(256), 0, st, t.x, t.H, t.W, t.C,
-                       (const float*)(scratch36 + i * 3), t.g, accumulate ? 1 : 0);
-    JT_LAUNCH_CHECK();
+    B.t[B.n++] = {t.x, t.g, t.H, t.W, t.C, 0, i, nblk, blocks};
+    nblk += blocks;
   }
+  hipLaunchKernelGGL(k_reg_batch_bwd, dim3(nblk), dim3(256), 0, st, B, (const float*)scratch36, accumulate ? 1 : 0);
+  JT_LAUNCH_CHECK();
   return JT_OK;
 }

@@ -357,6 +357,7 @@ class RenderRays(torch.autograd.Function):
                      sidx, eray, esmp, vdir, rgb_s, cmask)
         ctx.param_shapes = [tuple(p.shape) for p in params]
         ctx.mark_non_differentiable(depth)
+        ctx.set_materialize_grads(False)  # an output nobody used arrives as None in backward, not as a zero tensor
         ctx.stats = dict(offset=offset)
         # regularisers of the same factors (cfg.reg_flags = (with_tv_density, with_tv_app)): evaluated here so that
         # the backward can ADD their gradient into the render gradient's buffer (jt_reg_losses_backward,
@@ -389,7 +390,7 @@ class RenderRays(torch.autograd.Function):
         fac = _factors_struct(sdp, sdl, sap, sal, cfg.alpha_mask[0] if cfg.alpha_mask is not None else None)
         st = _stream()
         f32 = dict(device=dev, dtype=torch.float32)
-        g_rgb = g_rgb.contiguous().float()
+        g_rgb = (torch.zeros(R, 3, **f32) if g_rgb is None else g_rgb.contiguous().float())
         g_op = None if g_opacity is None else g_opacity.contiguous().float()
         cap, n = ctx.cap, ctx.n
         cap_alloc = max(cap, 1)

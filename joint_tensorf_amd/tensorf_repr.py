@@ -225,10 +225,12 @@ class BAT_VMSplit(torch.nn.Module):
 
     def TV_loss_density(self, reg):
         """sum_i TVLoss(density_plane_i) * 1e-2 (tensoRF.py:218-222)."""
-        return self._reg()[1] * getattr(reg, "TVLoss_weight", 1)
+        w = getattr(reg, "TVLoss_weight", 1)
+        return self._reg()[1] if w == 1 else self._reg()[1] * w  # x * 1 is x; the multiply is a launch
 
     def TV_loss_app(self, reg):
-        return self._reg()[2] * getattr(reg, "TVLoss_weight", 1)
+        w = getattr(reg, "TVLoss_weight", 1)
+        return self._reg()[2] if w == 1 else self._reg()[2] * w
 
     # ---- resolution changes (tensoRF.py:274-295) --------------------------------------------------
     @torch.no_grad()
