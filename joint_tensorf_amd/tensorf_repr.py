@@ -401,7 +401,8 @@ class BAT_VMSplit(torch.nn.Module):
                 u = self.jitter_override if self.jitter_override is not None else torch.rand_like(zvals)
                 zvals = zvals + u.to(dev).view(1, -1) * ((far - near) / S)
         elif is_train:
-            jitter = self.jitter_override if self.jitter_override is not None else torch.rand(R, 1, device=dev)
+            # (tests pin the draws with a [>= R, 1] tensor; the first R rows are this batch's)
+            jitter = self.jitter_override[:R] if self.jitter_override is not None else torch.rand(R, 1, device=dev)
             jitter = jitter.to(dev)
         # blur kernels (batBase.py:91-101)
         self.c2f_mode = c2f_mode

@@ -1,13 +1,12 @@
 """hipGraph replay of the training iteration (joint_tensorf_amd/graphed.py) against the eager loop: same initial
-state, same host draws, no jitter -- parameters, pose refinements and losses must follow the same trajectory
+state, same host draws, pinned jitter -- parameters, pose refinements and losses must follow the same trajectory
 (differences: the order of float atomics only), across lattice shapes, the edge-loss parity and a signature change.
 
-Tolerances (calibrated with tools/graph_calib.py): the loop is chaotic at the level of single texels -- Adam turns
-the sign of a gradient that is pure atomics-order noise into a full +-lr step -- so two EAGER runs of these 12
-iterations are either bit-close (1e-7) or, after one such event, 1e-2 apart in the appearance planes (1e-5 in the
-losses, 1e-4 in the density planes); the graph-replayed run shows exactly the same two levels against eager.  A
-wrong graph (stale lattice offsets, stale Adam coefficients, a missed zero-fill) moves the LOSSES at the 1e-2
-level at once, which is what the test pins."""
+Tolerances (calibrated with tools/graph_calib.py): with the jitter pinned two EAGER runs of this loop agree to 3e-7
+in the losses and 1e-6 (norm) / 4e-6 (largest element) in every parameter tensor after 24 iterations (float atomics
+order only), and the graph-replayed run sits at exactly the same level.  (With the jitter OFF the first sample of a
+ray lies exactly on the box face and the last bit of the optimised pose decides whether it counts: two eager runs
+then jump 1e-4 apart in the loss within a few iterations.)"""
 import copy
 
 import numpy as np
@@ -25,7 +24,9 @@ def _build(seed=0):
     B, HW = 3, 42   # 42 px, stride 8: 5 or 6 lattice points per axis -> four lattice shapes
     opt = make_options("bat_blender_VM", device=DEV, data=dict(image_size=[HW, HW], num_views=B),
                        train_schedule=dict(n_voxel_init=14 ** 3, n_rays_init=96, n_rays_rest=96), nerf=dict(n_rays=96))
-    opt.nerf.sample_stratified = False          # no jitter: the two runs are comparable sample by sample
+    # Jitter ON, but pinned: without jitter the first sample of every ray lies exactly on the box face and the
+    # last bit of the (optimised) pose decides whether it is in -- a coin toss that makes two runs of the same loop
+    # differ by 1e-4 in the loss after a few iterations (discreteness note).
     opt.c2f_schedule_density = [0.0, 0.0]       # sharp stage (the blurred stages stay on the eager path)
     opt.c2f_schedule_color = [0.0, 0.0]
     torch.manual_seed(seed)
@@ -37,6 +38,8 @@ def _build(seed=0):
             p.mul_(22.0)
         model.graph.se3_refine.weight.copy_(0.01 * torch.randn(B, 6, device=DEV))
     var0 = make_views(opt, B, seed=3, device=DEV)
+    gj = torch.Generator().manual_seed(17)
+    model.graph.nerf.tensorf.jitter_override = torch.rand(256, 1, generator=gj).to(DEV)   # rows [:R] are used
     return opt, model, var0
 
 
@@ -68,16 +71,57 @@ def _run(use_graph, K, it0=0):
 
 @pytest.mark.parametrize("it0", [0, 9000])
 def test_graph_replay_follows_the_eager_trajectory(it0):
-    K = 12
+    K = 16
     l_e, sd_e, _, rs_e = _run(False, K, it0)
     l_g, sd_g, stats, rs_g = _run(True, K, it0)
     assert stats["captured"] >= 2 and stats["replayed"] >= K - 4, stats
     assert (rs_e == rs_g).all()  # the host random stream is consumed identically
-    np.testing.assert_allclose(l_g, l_e, rtol=5e-3, atol=1e-8)
+    np.testing.assert_allclose(l_g, l_e, rtol=2e-5, atol=1e-9)
     for k in sd_e:
         a, b = sd_e[k].float(), sd_g[k].float()
-        tol = 1e-2 if "density" in k else 0.2
-        assert float((a - b).norm()) <= tol * (float(a.norm()) + 1e-12), k
+        assert float((a - b).norm()) <= 1e-4 * (float(a.norm()) + 1e-12), k
+        assert float((a - b).abs().max()) <= 1e-3 * (float(a.abs().max()) + 1e-12), k
+
+
+@pytest.mark.parametrize("it0", [0, 9000])
+def test_one_replayed_step_equals_one_eager_step(it0):
+    """The strict check: two identical models take the same three eager iterations, then one takes an eager step and
+    the other the same step replayed from a freshly captured hipGraph.  One step cannot amplify atomics-order noise,
+    so the parameter UPDATES of that step must agree closely (a stale lattice offset, Adam coefficient or zero-fill
+    would show as an O(1) difference of the update)."""
+    from joint_tensorf_amd.graphed import GraphedTrainStep
+    from joint_tensorf_amd.options import Opt
+    runs = []
+    for use_graph in (False, True):
+        opt, model, var0 = _build()
+        model.it = it0
+        model.graph.nerf.set_progress(it0 / opt.max_iter)
+        np.random.seed(5)
+        stepper = GraphedTrainStep(model, min_repeats=0)
+        orig_randint = np.random.randint
+        np.random.randint = lambda *a, **kw: 0      # one lattice shape throughout
+        try:
+            for _ in range(3):
+                stepper.train_iteration(opt, Opt(dict(var0)), force_eager=True)
+                model.after_iteration(opt, model.it - 1)
+            before = {k: v.detach().clone() for k, v in model.graph.state_dict().items()}
+            loss = stepper.train_iteration(opt, Opt(dict(var0)), force_eager=not use_graph)
+            model.after_iteration(opt, model.it - 1)
+        finally:
+            np.random.randint = orig_randint
+        after = {k: v.detach().clone() for k, v in model.graph.state_dict().items()}
+        runs.append((before, after, float(loss.all.detach()), dict(stepper.stats)))
+    (b_e, a_e, l_e, _), (b_g, a_g, l_g, st) = runs
+    assert st["replayed"] == 1 and st["captured"] == 1, st
+    assert abs(l_g - l_e) <= 1e-5 * abs(l_e)
+    for k in a_e:
+        if not a_e[k].is_floating_point() or "progress" in k:
+            continue
+        up_e, up_g = (a_e[k] - b_e[k]).float(), (a_g[k] - b_g[k]).float()
+        if float(up_e.norm()) == 0.0:
+            assert float(up_g.norm()) == 0.0, k
+            continue
+        assert float((up_e - up_g).norm()) <= 2e-3 * float(up_e.norm()), (k, float((up_e - up_g).norm()), float(up_e.norm()))
 
 
 def test_graph_is_dropped_when_the_optimizer_is_rebuilt():
