@@ -24,7 +24,6 @@ change per iteration; LLFF: white-background coin, decaying TV weights, pose-gra
 runs) runs through `Model.train_iteration` unchanged.  Host draws are consumed in exactly the eager order, so a run
 switches between the two paths without changing its random streams.
 """
-import math
 import os
 
 import numpy as np

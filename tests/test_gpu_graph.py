@@ -7,7 +7,6 @@ in the losses and 1e-6 (norm) / 4e-6 (largest element) in every parameter tensor
 order only), and the graph-replayed run sits at exactly the same level.  (With the jitter OFF the first sample of a
 ray lies exactly on the box face and the last bit of the optimised pose decides whether it counts: two eager runs
 then jump 1e-4 apart in the loss within a few iterations.)"""
-import copy
 
 import numpy as np
 import pytest
