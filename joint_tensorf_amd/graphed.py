@@ -277,7 +277,8 @@ class GraphedTrainStep:
         # one stream inside the graph: the auxiliary stream of the eager backward (weight-gradient GEMMs next to the
         # density backward) buys 0.1 ms of a dense 4.8 ms step there, but as a fork / join inside a hipGraph it COSTS
         # 0.07-0.1 ms (measured, dense and sparse scene)
-        aux_was, ops.USE_AUX_STREAM = ops.USE_AUX_STREAM, False
+        aux_was = ops.USE_AUX_STREAM
+        ops.USE_AUX_STREAM = aux_was and os.environ.get("JT_GRAPH_AUX", "0") == "1"
         try:
             def body():
                 with stateless._reparametrize_module(g, subs):
