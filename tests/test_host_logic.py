@@ -121,3 +121,39 @@ def test_rank_lattice_offsets_keep_the_ray_count(step, extent):
             n_cls = sum(1 for x in range(step) if len(range(x, extent, step)) == len(range(o, extent, step)))
             if n_cls >= world:
                 assert len(set(offs)) == world
+
+
+def test_baked_blob_scene_is_an_exact_vm_field():
+    """synthetic.bake_blobs: every Gaussian blob is one rank-1 VM component (plane(x, y) x line(z)) and the last
+    component is the constant background -- checked by evaluating the density feature of the baked factors with the
+    oracle at the blob centres, between blobs and at a grid corner."""
+    import types
+    from joint_tensorf_amd.synthetic import bake_blobs
+    g = [33, 29, 31]                               # non-cubic on purpose: plane 0 is [1, C, g[1], g[0]], line 0 [1, C, g[2], 1]
+    C = 8
+    tf = types.SimpleNamespace(
+        aabb=torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]]),
+        density_plane=[torch.randn(1, C, g[1], g[0]), torch.randn(1, C, g[2], g[0]), torch.randn(1, C, g[2], g[1])],
+        density_line=[torch.randn(1, C, g[2], 1), torch.randn(1, C, g[1], 1), torch.randn(1, C, g[0], 1)])
+    n = bake_blobs(tf, n_blobs=5, seed=2, amplitude=40.0, radius=(0.3, 0.5), background=-12.0)
+    assert n == 5
+    cfg = O.SceneCfg(tf.aabb.view(-1).tolist(), g, [2.0, 6.0])
+    params = dict(density_plane=tf.density_plane, density_line=tf.density_line)
+    # centres the helper drew (same generator, same order of draws)
+    rng = np.random.RandomState(2)
+    lo, hi = tf.aabb[0], tf.aabb[1]
+    centres, sig = [], []
+    for _ in range(n):
+        centres.append(lo + (hi - lo) * torch.tensor(0.25 + 0.5 * rng.rand(3), dtype=torch.float32))
+        sig.append(float(0.3 + 0.2 * rng.rand()))
+    pts = torch.stack(centres + [hi.clone(), lo.clone()])
+    feat = O.density_feature(cfg, params, O.normalize_coord(cfg, pts))
+    expect = []
+    for p in pts:
+        v = -12.0
+        for c, s in zip(centres, sig):
+            v += 40.0 * math.exp(-float(((p - c) ** 2).sum()) / (2 * s * s))
+        expect.append(v)
+    # the grid is coarse (0.1 per texel): bilinear interpolation of a Gaussian of width >= 0.3 is good to a few %
+    np.testing.assert_allclose(feat.numpy(), np.array(expect), rtol=0.08, atol=0.3)
+    assert float(feat[-1]) < -11.0 and float(feat[:n].min()) > 20.0
