@@ -252,9 +252,9 @@ def main():
     var_all = make_views(opt, n_views, seed=0, device=dev)
     nerf = model.graph.nerf
     res, S = nerf.resolution, nerf.n_samples
-    # the lattice draw is SHARED by all ranks; each rank shifts it inside the draw's class (dist.rank_lattice_offset):
-    # different pixels per GPU, the same ray count on every GPU in every iteration (no straggler at the all-reduce)
-    lattice_rng = np.random.RandomState(1000)
+    # the host draws (lattice offsets, blur scale) come from NumPy's global generator, seeded identically on every
+    # rank; each rank shifts the lattice draw inside the draw's class (dist.rank_lattice_offset): different pixels per
+    # GPU, the same ray count on every GPU in every iteration (no straggler at the all-reduce)
     if world > 1:
         model.graph.lattice_rank = (rank, world)
     if args.probe_only:
@@ -278,13 +278,9 @@ def main():
         nonlocal rays_total
         from joint_tensorf_amd.options import Opt
         var = Opt(dict(var_all))
-        state = np.random.get_state()
-        np.random.set_state(lattice_rng.get_state())
         g = model.graph
         if stepper is not None:
             stepper.train_iteration(opt, var, force_eager=not use_graph[0])
-            lattice_rng.set_state(np.random.get_state())
-            np.random.set_state(state)
             model.after_iteration(opt, model.it - 1)
             rgb = stepper.last_var.rgb
             rays_total += rgb.shape[0] * rgb.shape[1]
@@ -292,8 +288,6 @@ def main():
         g.it = model.it
         model.optim.zero_grad()
         var = g.forward(opt, var, mode="train")
-        lattice_rng.set_state(np.random.get_state())
-        np.random.set_state(state)
         loss = g.compute_loss(opt, var, mode="train")
         loss = model.summarize_loss(opt, var, loss)
         if OVERLAP:

@@ -131,7 +131,8 @@ class GraphedTrainStep:
         if not (opt.model in ("bat", "bat_hip") and opt.c2f_mode != "None"):
             return False
         p = self.model.graph.nerf.progress_host
-        return interp_schedule(p, opt.c2f_schedule_color) >= 0.001
+        # the random scale of the density blur is <= 1: below the cut-off without it means below the cut-off with it
+        return max(interp_schedule(p, opt.c2f_schedule_color), interp_schedule(p, opt.c2f_schedule_density)) >= 0.001
 
     def _signature(self, opt, var, ny, nx):
         m, g = self.model, self.model.graph
@@ -161,6 +162,14 @@ class GraphedTrainStep:
                 float(fea_pe), float(getattr(m, "render_loss_scale", 1.0)), tf.alphaMask is not None,
                 tuple(float(v) for v in tf.near_far), id(tf.jitter_override))
 
+    def _lattice_shapes(self, H, W, step):
+        memo = self.__dict__.setdefault("_shape_memo", {})
+        key = (H, W, step)
+        if key not in memo:
+            memo[key] = sorted({(len(range(oy, H, step)), len(range(ox, W, step))) for oy in range(step)
+                                for ox in range(step)})
+        return memo[key]
+
     def _drop_all(self):
         self.cache.clear()
         self.seen.clear()
@@ -173,26 +182,28 @@ class GraphedTrainStep:
         if force_eager or not self._eligible(opt) or self._blur_scheduled(opt):
             self.stats["eager"] += 1
             return self._eager(opt, var)
-        np_state = np.random.get_state()
         g.it = m.it
         batch_size = len(var.idx)
         step = g.lattice_step(opt, batch_size)
+        epoch = (id(m.optim), ops.workspace_generation())
+        if epoch != self.epoch:  # optimizer rebuilt (grid upsampled) or a workspace moved: every graph is stale
+            self._drop_all()
+            self.epoch = epoch
+        # NumPy's state is saved (40 us) only while this iteration could still end on the eager path, i.e. until the
+        # graphs of all lattice shapes of the current signature exist
+        base = self._signature(opt, var, 0, 0)
+        shapes = self._lattice_shapes(int(opt.H), int(opt.W), step)
+        complete = all((base[:6] + s + base[8:]) in self.cache for s in shapes)
+        np_state = None if complete else np.random.get_state()
         ox, oy = np.random.randint(step), np.random.randint(step)
         if g.lattice_rank is not None:
             from .dist import rank_lattice_offset
             ox = rank_lattice_offset(ox, step, opt.W, *g.lattice_rank)
             oy = rank_lattice_offset(oy, step, opt.H, *g.lattice_rank)
         blur = g.resolve_blur(opt, "train")  # consumes the blur-scale draw exactly like the eager path
-        if blur[2] is not None:
-            np.random.set_state(np_state)
-            self.stats["eager"] += 1
-            return self._eager(opt, var)
+        assert blur[2] is None  # _blur_scheduled() said so
         nx, ny = len(range(ox, opt.W, step)), len(range(oy, opt.H, step))
-        epoch = (id(m.optim), ops.workspace_generation())
-        if epoch != self.epoch:  # optimizer rebuilt (grid upsampled) or a workspace moved: every graph is stale
-            self._drop_all()
-            self.epoch = epoch
-        sig = self._signature(opt, var, ny, nx)
+        sig = base[:6] + (ny, nx) + base[8:]
         e = self.cache.get(sig)
         if e is None:
             if len(self.seen) > 4096:
