@@ -359,7 +359,7 @@ class GraphedTestOptim:
         self.se3.grad = None
         st = self.optim.state[self.se3]
         if st:
-            st["step"].zero_()
+            st["step"] = 0.0
             st["exp_avg"].zero_()
             st["exp_avg_sq"].zero_()
         self.optim.param_groups[0]["lr"] = float(opt.optim.lr_pose)

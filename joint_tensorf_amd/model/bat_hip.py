@@ -22,11 +22,17 @@ from .. import tensorf_repr
 from ..options import Opt
 
 
+_SCHEDULE_XS = {}
+
+
 def interp_schedule(x, schedule, left=0.0, right=1.0):
     """util.interp_schedule (util.py:217-225) on host floats."""
     x = float(x)
     assert left <= x <= right
-    xs = np.linspace(left, right, len(schedule))
+    key = (left, right, len(schedule))
+    xs = _SCHEDULE_XS.get(key)
+    if xs is None:
+        xs = _SCHEDULE_XS[key] = np.linspace(left, right, len(schedule))
     return float(np.interp(x, xs, schedule))
 
 

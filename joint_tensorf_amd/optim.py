@@ -38,6 +38,17 @@ class VMAdam(torch.optim.Optimizer):
                 batches.setdefault(key, []).append((p, group))
         return batches
 
+    def _layout_ok(self, a, p):
+        """_same_layout(a, p), remembered per (parameter, shape and strides of the other tensor)."""
+        memo = self.__dict__.setdefault("_layout_memo", {})
+        key = (id(p), a.shape, a.stride(), p.stride())
+        r = memo.get(key)
+        if r is None:
+            if len(memo) > 4096:
+                memo.clear()
+            r = memo[key] = _same_layout(a, p)
+        return r
+
     def _dyn_buffer(self, dev, n_items):
         d = self.__dict__.setdefault("_dyn", {})
         key = str(dev)
@@ -63,11 +74,14 @@ class VMAdam(torch.optim.Optimizer):
                 dev = p.device
                 st = self.state[p]
                 if len(st) == 0:
-                    st["step"] = torch.tensor(0.0)
+                    st["step"] = 0.0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                t = float(st["step"])
+                # `step` is kept as a Python float (a 0-dim tensor loaded from a torch.optim.Adam checkpoint is
+                # converted on first use; torch's Adam converts the other way in __setstate__): 19 tensor updates and
+                # read-backs per iteration are 40 us of host time
+                t = float(st["step"]) + 1.0
+                st["step"] = t
                 coefs.append(float(group["lr"]) / (1.0 - b1 ** t))
                 coefs.append(1.0 / math.sqrt(1.0 - b2 ** t))
         if not coefs:
@@ -91,14 +105,14 @@ class VMAdam(torch.optim.Optimizer):
                 if g.is_sparse or p.dtype != torch.float32:
                     raise RuntimeError("VMAdam: dense float32 parameters only")
                 st = self.state[p]
-                if not _same_layout(g, p) or g.dtype != torch.float32:
+                if g.dtype != torch.float32 or not self._layout_ok(g, p):
                     # the kernel walks all four tensors in the parameter's memory order
                     g2 = torch.empty_like(p, memory_format=torch.preserve_format)
                     g2.copy_(g)
                     g = g2
                     keep.append(g)
                 m, v = st["exp_avg"], st["exp_avg_sq"]
-                assert _same_layout(m, p) and _same_layout(v, p)
+                assert self._layout_ok(m, p) and self._layout_ok(v, p)
                 arr[k].p, arr[k].g, arr[k].m, arr[k].v, arr[k].n = ptr(p), ptr(g), ptr(m), ptr(v), p.numel()
             dyn = self._dyn_buffer(plist[0][0].device, len(plist))
             check(lib.jt_adam_step_dyn(arr, len(plist), b1, b2, eps, ptr(dyn), stream), "jt_adam_step_dyn")

@@ -86,8 +86,9 @@ def test_graph_replay_follows_the_eager_trajectory(it0):
 def test_one_replayed_step_equals_one_eager_step(it0):
     """The strict check: two identical models take the same three eager iterations, then one takes an eager step and
     the other the same step replayed from a freshly captured hipGraph.  One step cannot amplify atomics-order noise,
-    so the parameter UPDATES of that step must agree closely (a stale lattice offset, Adam coefficient or zero-fill
-    would show as an O(1) difference of the update)."""
+    so the parameter UPDATES of that step must agree closely: within 1 % of the update's norm (the fourth Adam step is still
+    almost a sign step, so the few texels whose gradient is atomics-order noise move by +-lr: 0.1-0.3 % of the norm
+    observed; a stale lattice offset, Adam coefficient or zero-fill shows as an O(1) difference)."""
     from joint_tensorf_amd.graphed import GraphedTrainStep
     from joint_tensorf_amd.options import Opt
     runs = []
@@ -120,7 +121,7 @@ def test_one_replayed_step_equals_one_eager_step(it0):
         if float(up_e.norm()) == 0.0:
             assert float(up_g.norm()) == 0.0, k
             continue
-        assert float((up_e - up_g).norm()) <= 2e-3 * float(up_e.norm()), (k, float((up_e - up_g).norm()), float(up_e.norm()))
+        assert float((up_e - up_g).norm()) <= 1e-2 * float(up_e.norm()), (k, float((up_e - up_g).norm()), float(up_e.norm()))
 
 
 def test_graph_is_dropped_when_the_optimizer_is_rebuilt():
