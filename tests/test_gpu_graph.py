@@ -85,10 +85,14 @@ def test_graph_replay_follows_the_eager_trajectory(it0):
 @pytest.mark.parametrize("it0", [0, 9000])
 def test_one_replayed_step_equals_one_eager_step(it0):
     """The strict check: two identical models take the same three eager iterations, then one takes an eager step and
-    the other the same step replayed from a freshly captured hipGraph.  One step cannot amplify atomics-order noise,
-    so the parameter UPDATES of that step must agree closely: within 1 % of the update's norm (the fourth Adam step is still
-    almost a sign step, so the few texels whose gradient is atomics-order noise move by +-lr: 0.1-0.3 % of the norm
-    observed; a stale lattice offset, Adam coefficient or zero-fill shows as an O(1) difference)."""
+    the other the same step replayed from a freshly captured hipGraph.  Compared are the loss and Adam's FIRST
+    MOMENTS after the step -- linear in the step's gradients, so float-atomics noise stays at 1e-6 of the norm (and a
+    sample whose weight sits on rayMarch_weight_thres, shaded in one run and not in the other, at 2e-3: seen in one run
+    of five; the tolerance is 1e-2), while
+    the parameter update itself is almost a sign step this early (a weight whose gradient is noise moves by +-lr: 1-2 %
+    of an MLP matrix's update norm was observed between two eager runs).  A stale lattice offset or a missed
+    zero-fill shows as an O(1) difference of the moments; the Adam coefficients are pinned by the trajectory test
+    above and by tests/test_gpu_units.py."""
     from joint_tensorf_amd.graphed import GraphedTrainStep
     from joint_tensorf_amd.options import Opt
     runs = []
@@ -104,24 +108,23 @@ def test_one_replayed_step_equals_one_eager_step(it0):
             for _ in range(3):
                 stepper.train_iteration(opt, Opt(dict(var0)), force_eager=True)
                 model.after_iteration(opt, model.it - 1)
-            before = {k: v.detach().clone() for k, v in model.graph.state_dict().items()}
             loss = stepper.train_iteration(opt, Opt(dict(var0)), force_eager=not use_graph)
             model.after_iteration(opt, model.it - 1)
         finally:
             np.random.randint = orig_randint
-        after = {k: v.detach().clone() for k, v in model.graph.state_dict().items()}
-        runs.append((before, after, float(loss.all.detach()), dict(stepper.stats)))
-    (b_e, a_e, l_e, _), (b_g, a_g, l_g, st) = runs
+        moments = {}
+        for n, p in model.graph.named_parameters():
+            st = model.optim.state.get(p) or model.optim_pose.state.get(p)
+            if st:
+                moments[n] = (st["exp_avg"].detach().clone().float(), st["exp_avg_sq"].detach().clone().float())
+        runs.append((moments, float(loss.all.detach()), dict(stepper.stats)))
+    (m_e, l_e, _), (m_g, l_g, st) = runs
     assert st["replayed"] == 1 and st["captured"] == 1, st
     assert abs(l_g - l_e) <= 1e-5 * abs(l_e)
-    for k in a_e:
-        if not a_e[k].is_floating_point() or "progress" in k:
-            continue
-        up_e, up_g = (a_e[k] - b_e[k]).float(), (a_g[k] - b_g[k]).float()
-        if float(up_e.norm()) == 0.0:
-            assert float(up_g.norm()) == 0.0, k
-            continue
-        assert float((up_e - up_g).norm()) <= 1e-2 * float(up_e.norm()), (k, float((up_e - up_g).norm()), float(up_e.norm()))
+    assert len(m_e) >= 20 and set(m_e) == set(m_g)
+    for k in m_e:
+        for a, b in zip(m_e[k], m_g[k]):
+            assert float((a - b).norm()) <= 1e-2 * (float(a.norm()) + 1e-20), (k, float((a - b).norm()), float(a.norm()))
 
 
 def test_graph_is_dropped_when_the_optimizer_is_rebuilt():
