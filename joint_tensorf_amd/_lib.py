@@ -6,6 +6,11 @@ NO fallback: if the shared object is missing or a symbol is absent, importing th
 import ctypes
 import os
 
+# torch FIRST: it ships its own libamdhip64 and must be the one that brings the HIP runtime into the process.  Loaded
+# the other way round, libjt_render.so pulls /opt/rocm's copy in, torch adds its own, and kernels launched through the
+# library see "no device" (hipErrorNoDevice) for memory and streams that belong to the other runtime.
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libjt_render.so")
 

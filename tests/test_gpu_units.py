@@ -413,3 +413,24 @@ def test_adam_entry_points_by_value_and_device_coefficients_agree():
     ops.poke_words(buf, [7, 11, 13], offset=5)
     assert buf.tolist() == [-1] * 5 + [7, 11, 13] + [-1] * 8
     assert lib.jt_poke(None, None, 1, None) != 0 and lib.jt_poke(ptr(buf), (ctypes.c_uint32 * 1)(), 257, None) != 0
+
+
+def test_library_import_order_does_not_split_the_hip_runtime():
+    """A fresh process that imports joint_tensorf_amd BEFORE torch (as __graft_entry__.build() followed by smoke()
+    does) must still launch kernels on torch's tensors: the binding imports torch first so that the process has ONE HIP
+    runtime (torch ships its own libamdhip64; libjt_render.so alone would pull /opt/rocm's in and every launch through
+    it would fail with hipErrorNoDevice)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import joint_tensorf_amd\n"
+            "from joint_tensorf_amd import ops\n"
+            "import torch\n"
+            "x = torch.zeros(4, device='cuda', dtype=torch.int32)\n"
+            "ops.poke_words(x, [5, 6, 7])\n"
+            "assert x.tolist() == [5, 6, 7, 0], x.tolist()\n"
+            "print('ok')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
