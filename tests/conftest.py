@@ -16,6 +16,13 @@ def pytest_configure(config):
     spec = importlib.util.spec_from_file_location("jt_build", os.path.join(ROOT, "joint_tensorf_amd", "build.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
+    # The golden fixtures were captured from the reference on an 8-CPU machine: the CPU oracle's reductions (scatter-add
+    # backward of grid_sample, cumprod) depend on torch's intra-op thread count in the last bits, and the tightest
+    # gradient tolerance (5e-5 of the tensor max) is calibrated there -- a 256-core GPU host would otherwise run the
+    # oracle on 128 threads and land at 5.6e-5.
+    import torch
+    if torch.get_num_threads() > 8:
+        torch.set_num_threads(8)
     try:
         if not os.path.exists(mod.LIB):
             mod.build(verbose=False)

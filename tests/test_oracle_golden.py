@@ -9,7 +9,10 @@ from tests.golden_util import CASES, Fixture, GOLDEN, replay_oracle
 
 # tolerances (fp32): values abs, gradients relative to the tensor's max-abs
 TOL_VAL = 2e-6
-TOL_GRAD_REL = 5e-5
+# 5e-5 of the tensor max holds on the machine the fixtures were captured on (Intel, 8 threads); the same replay on
+# the GPU box's host (AMD EPYC: other vector code paths of exp / softplus) lands at 5.6e-5 for one tensor whose
+# gradient is 1e-10 in size -- fp32 round-off either way
+TOL_GRAD_REL = 1e-4
 
 
 def _rel(a, b):
@@ -26,7 +29,7 @@ def test_fixture_replay(name, use_taps):
     tol_g = 5e-4 if use_taps else TOL_GRAD_REL
     if "dense" in name:
         # acc == 1 (saturated): the render gradient is a cancellation residue ~1e-3 of the L1 term
-        tol_g = 5e-3 if use_taps else 5e-4
+        tol_g = 5e-3 if use_taps else 1e-3  # 5e-4 on the capture host, 6.2e-4 on the GPU box's EPYC host
     np.testing.assert_allclose(out["pose"].detach().numpy(), fx.arrays["mid.current_pose"], atol=1e-6)
     np.testing.assert_allclose(out["center"].detach().reshape(-1, 3).numpy(), fx.arrays["mid.center"], atol=2e-6)
     np.testing.assert_allclose(out["ray"].detach().reshape(-1, 3).numpy(), fx.arrays["mid.ray_dir"], atol=2e-6)
@@ -111,6 +114,10 @@ def test_prealign_cameras_golden():
 
 
 def test_test_time_optim_and_eval_render_golden():
+    """NOTE: calibrated on the host the fixture was captured on (this build container).  Test-time optimisation renders
+    without jitter, so the first sample of every ray lies exactly on the box face and the last bit of the CPU's pose
+    / ray arithmetic decides whether it counts (discreteness note): on the GPU box's EPYC host the
+    very first loss of the trace differs by 1e-3 from the captured one.  The driver runs the CPU suite here."""
     fx = _eval_fx()
     m = fx.meta
     cfg = fx.cfg()
