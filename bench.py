@@ -121,19 +121,17 @@ def allreduce_grads(model, world):
         jdist.allreduce_gradients(list(model.graph.parameters()), world, force=FORCE_DIST)
 
 
-def cpu_baseline(opt_name, seconds_budget=24.0):
-    """The reference algorithm (torch-CPU oracle port, parity-pinned) on config C1 of SURVEY §8(d):
-    grid 64^3, 512 rays (4 views x 128), S = 221, fwd + loss + bwd, blur off.  A few intra-op thread counts
-    are tried (the path is thousands of small ops; all cores of a big host oversubscribe it badly) and the
-    best one is reported with the thread count it used."""
+def _cpu_oracle_rate(grid, S, rays_per_view, seconds_budget, blur_off=True):
+    """fwd + loss + bwd of the reference algorithm (torch-CPU oracle port, parity-pinned) on 4 views x
+    `rays_per_view` rays: median over up to 9 repetitions for each of a few intra-op thread counts (the path is
+    thousands of small ops; all cores of a big host oversubscribe it badly), best thread count reported."""
     from oracle import tensorf_oracle as O
     g = torch.Generator().manual_seed(0)
-    grid = [64, 64, 64]
     cfg = O.SceneCfg([-1.5] * 3 + [1.5] * 3, grid, [2.0, 6.0])
     params = O.init_params(grid, scale=0.1, bias=0.0, generator=g)
     for _, v in O.flat_params(params):
         v.requires_grad_(True)
-    B, r, S, H, W = 4, 128, 221, 400, 400
+    B, r, H, W = 4, rays_per_view, 400, 400
     from joint_tensorf_amd.synthetic import look_at
     poses = []
     for i in range(B):
@@ -147,6 +145,8 @@ def cpu_baseline(opt_name, seconds_budget=24.0):
     target = torch.rand(B, r, 3, generator=g)
 
     def step():
+        for _, v in O.flat_params(params):
+            v.grad = None
         ray_idx = torch.randperm(H * W, generator=g)[:r]
         pose = O.train_pose(se3, noise, pose_gt)
         c, d = O.rays_for_pixels(pose, intr.inverse(), ray_idx, W)
@@ -175,10 +175,25 @@ def cpu_baseline(opt_name, seconds_budget=24.0):
         if best is None or med < best[0]:
             best = (med, nt, times)
     med, nt, times = best
-    return dict(value=B * r / med, unit="rays/s", cores=nt, kind="port",
-                sample="C1: grid 64^3, 512 rays x 221 samples, fwd+loss+bwd, blur off; best of thread counts %s: "
-                       "%d threads, %d reps, median %.0f ms (min %.0f / max %.0f); host has %d logical CPUs"
-                       % (cands, nt, len(times), med * 1e3, min(times) * 1e3, max(times) * 1e3, ncpu))
+    return dict(value=B * r / med, cores=nt, threads_tried=cands, reps=len(times), median_ms=med * 1e3,
+                min_ms=min(times) * 1e3, max_ms=max(times) * 1e3, rays=B * r, host_cpus=ncpu)
+
+
+def cpu_baseline(res, S):
+    """The reference algorithm on the box's host cores, same run.  `value`: a BOUNDED SAMPLE OF THE BENCH
+    WORKLOAD -- the same grid and samples per ray, 4 views x 32 rays per step instead of 100 x ~20 (a step of the full
+    ray batch would take minutes on the CPU).  `c1`: the reference's own CPU-sized configuration C1 (64^3, 512 rays,
+    S = 221), the figure earlier lines of this file quoted."""
+    main = _cpu_oracle_rate([int(v) for v in res], int(S), 32, seconds_budget=18.0)
+    c1 = _cpu_oracle_rate([64, 64, 64], 221, 128, seconds_budget=8.0)
+    return dict(value=main["value"], unit="rays/s", cores=main["cores"], kind="port",
+                sample="bench workload at reduced ray count: grid %s, S = %d, %d rays per step (4 views x 32), fwd+loss+bwd, "
+                       "blur off; best of thread counts %s: %d threads, %d reps, median %.0f ms (min %.0f / max %.0f); host "
+                       "has %d logical CPUs" % ("x".join(str(int(v)) for v in res), int(S), main["rays"],
+                                                 main["threads_tried"], main["cores"], main["reps"], main["median_ms"],
+                                                 main["min_ms"], main["max_ms"], main["host_cpus"]),
+                c1=dict(value=c1["value"], unit="rays/s", cores=c1["cores"],
+                        sample="C1: grid 64^3, 512 rays x 221 samples, median %.0f ms over %d reps" % (c1["median_ms"], c1["reps"])))
 
 
 def measure_roofline(model, opt, var, reps=20):
@@ -411,7 +426,7 @@ def main():
             except Exception as e:  # keep the bench line even if the probe is unavailable
                 out["roofline"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.config)
+            out["cpu_baseline"] = cpu_baseline(res, S)
         print(json.dumps(out))
     if world > 1 or FORCE_DIST:
         import torch.distributed as dist
