@@ -240,6 +240,18 @@ size_t jt_march_backward_workspace_bytes(const JtScene* scene, int n_rays);
  * kernels) and ev_join is recorded on aux_stream at their end; the caller makes whoever consumes g_mlp wait
  * for ev_join.  This lets the MFMA-bound GEMMs overlap the atomics-bound density backward. */
 size_t jt_shade_workspace_bytes(const JtScene* scene, int n_entries_max);
+/* Shaded samples per backward launch ("chunk": batBase.py has no counterpart, it is how the build bounds the
+ * per-launch record block).  jt_shade_chunk_entries() = the current value (2^22 unless JT_SHADE_CHUNK_LOG2 says
+ * otherwise); jt_shade_set_chunk_log2(l) sets 2^l for l in 16..22 and returns the previous log2 (any other l only
+ * queries).  jt_shade_workspace_bytes depends on it: re-query after a change, never change it between a forward
+ * and its backward. */
+/* Where the training forward leaves the ReLU sign words of the two hidden layers inside `workspace` (test / debug
+ * readers): out[0] = record rows per 32-sample tile, out[1] = first of the four sign rows (2 * layer + lane half),
+ * out[2] = hidden width, out[3] = samples per tile.  Bit mt * 16 + r of the word of half h stands for hidden unit
+ * mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h (tensorBase.py:101-126: the ReLUs of MLPRender_Fea). */
+int jt_shade_record_layout(const JtScene* scene, int32_t* out);
+int jt_shade_chunk_entries(void);
+int jt_shade_set_chunk_log2(int log2_entries);
 int jt_shade_forward(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp, const float* rays_o,
                      const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
                      const int32_t* shade_offset, int n_rays, const int32_t* entry_ray,

@@ -85,6 +85,9 @@ SIGNATURES = {
     "jt_march_backward": (I, [SP, FP, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, FP, P, P, P, ctypes.c_size_t, P]),
     "jt_march_backward_workspace_bytes": (ctypes.c_size_t, [SP, I]),
     "jt_shade_workspace_bytes": (ctypes.c_size_t, [SP, I]),
+    "jt_shade_record_layout": (I, [SP, P]),
+    "jt_shade_chunk_entries": (I, []),
+    "jt_shade_set_chunk_log2": (I, [I]),
     "jt_render_loss_forward": (I, [P, P, P, P, I, I, I, F, F, P, P, P]),
     "jt_render_loss_backward": (I, [P, P, P, P, I, I, I, F, F, P, P, P, P]),
     "jt_loss_sum_forward": (I, [P, P, F, F, F, F, P, P]),

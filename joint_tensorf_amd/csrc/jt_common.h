@@ -155,10 +155,13 @@ __device__ inline bool sample_valid(const Dev& D, const Ray& r, float z, float p
   return v;
 }
 
-// normalize_coord (tensorBase.py:502-503)
+// normalize_coord (tensorBase.py:502-503): (xyz - aabb[0]) * invaabbSize - 1 as three separately rounded torch ops.
+// Un-fused on purpose: the texel cell of a sample is floor() of this value scaled by (size - 1) / 2, and a sample within
+// one ulp of a cell border would otherwise land in the neighbouring cell -- same interpolated value, but a different
+// slope, i.e. a different coordinate (pose) gradient for that sample (measured at 400^3: a few rays per batch).
 __device__ inline void normalize(const Dev& D, const float p[3], float n[3]) {
 #pragma unroll
-  for (int a = 0; a < 3; ++a) n[a] = (p[a] - D.lo[a]) * D.inv[a] - 1.f;
+  for (int a = 0; a < 3; ++a) n[a] = add_rn(mul_rn(add_rn(p[a], -D.lo[a]), D.inv[a]), -1.f);
 }
 
 // ---- bilinear / linear taps: grid_sample(bilinear, align_corners=True, zeros) ------------------

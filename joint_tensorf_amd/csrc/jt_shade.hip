@@ -1040,14 +1040,24 @@ static int shade_kind(const JtScene* s) {
 // on an auxiliary stream, concurrently with whatever the caller enqueues next on the main stream (the
 // density backward: atomics / VALU bound, while the GEMMs are MFMA bound).
 // shaded samples per backward launch (and per set of weight-gradient GEMMs); JT_SHADE_CHUNK_LOG2 overrides (16..22)
+static int g_chunk_log2 = 0;  // 0 = not yet initialised from the environment
 static int chunk_entries() {
-  static const int n = [] {
+  if (!g_chunk_log2) {
     const char* e = getenv("JT_SHADE_CHUNK_LOG2");
     int l = e ? atoi(e) : 22;  // measured: 2^20 4.48 ms / step, 2^21 4.34, 2^22 4.33 (fewer launches, slabs and tails)
     if (l < 16 || l > 22) l = 22;
-    return 1 << l;
-  }();
-  return n;
+    g_chunk_log2 = l;
+  }
+  return 1 << g_chunk_log2;
+}
+extern "C" int jt_shade_chunk_entries(void) { return chunk_entries(); }
+// returns the previous log2; values outside 16..22 only query.  The caller re-sizes its workspace afterwards
+// (jt_shade_workspace_bytes depends on the chunk size); not to be changed between a forward and its backward.
+extern "C" int jt_shade_set_chunk_log2(int log2_entries) {
+  (void)chunk_entries();
+  const int prev = g_chunk_log2;
+  if (log2_entries >= 16 && log2_entries <= 22) g_chunk_log2 = log2_entries;
+  return prev;
 }
 #define kChunkEntries (chunk_entries())
 static const int kNoGradRecords = 1 << 8;  // internal flag of launch_shade_bwd
@@ -1074,6 +1084,22 @@ extern "C" size_t jt_shade_workspace_bytes(const JtScene* scene, int n_entries_m
   const int kind = shade_kind(scene);
   if (kind < 0 || n_entries_max < 1) return 0;
   return (kind == 0) ? WsLayout<CfgBlender>::bytes(n_entries_max) : WsLayout<CfgLlff>::bytes(n_entries_max);
+}
+
+// layout of the per-tile records for readers outside this file (tests pin the ReLU signs the kernels took):
+// out = {rows per tile, first of the four ReLU sign rows (2 * layer + lane half), hidden width, samples per tile}.
+// Sign word of (layer, half h), sample j of tile t: float index (t * rows + row0 + 2 * layer + h) * 32 + j;
+// bit mt * 16 + r  <->  hidden unit mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h.
+extern "C" int jt_shade_record_layout(const JtScene* scene, int32_t* out) {
+  const int kind = shade_kind(scene);
+  if (kind < 0 || !out) return JT_ERR_UNSUPPORTED;
+  if (kind == 0) {
+    out[0] = BwdCfg<CfgBlender>::REC_FLOATS; out[1] = BwdCfg<CfgBlender>::R_MASK; out[2] = CfgBlender::HID;
+  } else {
+    out[0] = BwdCfg<CfgLlff>::REC_FLOATS; out[1] = BwdCfg<CfgLlff>::R_MASK; out[2] = CfgLlff::HID;
+  }
+  out[3] = 32;
+  return JT_OK;
 }
 
 template <class C, int REC>

@@ -43,6 +43,7 @@ def poke_floats(dst, values, offset=0):
           "jt_poke")
 
 
+KEEP_INTERMEDIATES = False
 _AUX = {}
 _WS = {}
 _WS_EPOCH = {}
@@ -358,7 +359,11 @@ class RenderRays(torch.autograd.Function):
         ctx.param_shapes = [tuple(p.shape) for p in params]
         ctx.mark_non_differentiable(depth)
         ctx.set_materialize_grads(False)  # an output nobody used arrives as None in backward, not as a zero tensor
-        ctx.stats = dict(offset=offset)
+        # which samples were shaded (device tensors, no sync): offset [R+1] exclusive scan of the per-ray counts, sidx [R,S]
+        # the shaded sample indices of a ray in ascending order (uint16 stored as int16).  Read by tests and by stats code.
+        cfg.shade_lists = (offset, sidx)
+        if KEEP_INTERMEDIATES:  # diagnostics only (tools/diag_*.py): per-sample density feature / weight of this call
+            cfg.intermediates = dict(sigma_feat=sigma_feat, weight=weight, tmin=tmin)
         # regularisers of the same factors (cfg.reg_flags = (with_tv_density, with_tv_app)): evaluated here so that
         # the backward can ADD their gradient into the render gradient's buffer (jt_reg_losses_backward,
         # accumulate = 1) -- as a separate autograd node the two contributions to every density factor meet in an
@@ -882,7 +887,6 @@ class KernelProbe:
     samples of one ray batch.  Algorithmic bytes per shaded sample: forward gather
     4*3*Ca*6 B; backward = the same bytes re-read + the same bytes added to the gradients."""
 
-    CHUNK = 1 << 20  # entries of one backward launch (kChunkEntries in jt_shade.hip)
 
     def __init__(self, tf, rays_o, rays_d, n_samples, white_bg=True, ndc=False):
         dev = rays_o.device
@@ -953,7 +957,7 @@ class KernelProbe:
             scene, fac, mlp, ptr(self.o), ptr(self.d), ptr(self.jitter), ptr(zv), ptr(tmin), ptr(offset), R, ptr(eray),
             ptr(esmp), ptr(vdir), ptr(rgb_s), n, ptr(ws), nbytes, 0, st), "jt_shade_forward"))
         # one backward launch = one chunk of shaded samples
-        nb = min(n, self.CHUNK)
+        nb = min(n, int(lib.jt_shade_chunk_entries()))  # one backward launch = one chunk
         g_rgb_s = torch.rand(max(n, 1), 3, **f32)
         gfac = _factors_struct(*[[torch.zeros_like(t) for t in lst] for lst in sd])
         self._keep = gfac

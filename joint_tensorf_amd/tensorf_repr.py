@@ -453,6 +453,7 @@ class BAT_VMSplit(torch.nn.Module):
             cfg.reg_flags = (float(lw.get("TV_density", 0) or 0) != 0.0, float(lw.get("TV_color", 0) or 0) != 0.0)
         rgb, depth, opacity = ops.render_rays(cfg, center, ray_dir, jitter, zvals, dP, dL, aP, aL,
                                               self.basis_mat.weight, self.renderModule.weights())
+        self.last_render_cfg = cfg  # the scene description of the last forward (incl. cfg.shade_lists)
         if fuse_reg and cfg.reg3 is not None:
             self.reg_with_tv = cfg.reg_flags
             self._reg_cache.update(key=self._reg_key(), val=cfg.reg3)

@@ -395,7 +395,37 @@ def positional_encoding(x, freqs, progress=1.0):
     return pts.reshape(x.shape[:-1] + (freqs * 2 * x.shape[-1],))
 
 
-def mlp_fea(cfg, mlp, feat, viewdirs, view_pe_progress=1.0, fea_pe_progress=1.0):
+# Test knob: evaluate the Linear layers in this dtype and round the result back (None = plain F.linear).  A ReLU whose
+# pre-activation is within rounding of zero is a discrete decision that depends on the GEMM's summation order; two fp32
+# evaluations of the same reference algorithm that differ only in that order disagree on a handful of units out of
+# 10^8, and each disagreement moves the gradient of the few texels that sample touches.  tests/test_gpu_fullsize.py
+# measures that sensitivity (fp32 GEMMs vs fp64-accumulated GEMMs) next to the error of the implementation under test.
+LINEAR_DTYPE = None
+
+
+def _linear(x, w, b):
+    if LINEAR_DTYPE is None or LINEAR_DTYPE == x.dtype:
+        return F.linear(x, w, b)
+    return F.linear(x.to(LINEAR_DTYPE), w.to(LINEAR_DTYPE), b.to(LINEAR_DTYPE)).to(x.dtype)
+
+
+def _relu(x, mask, report):
+    """ReLU, or -- when a test pins the discrete decision -- multiplication by the 0/1 `mask` the implementation under
+    test used; `report` collects how many units the oracle itself would have decided differently and how far from zero
+    the farthest of those pre-activations is (they must all be within rounding of zero)."""
+    if mask is None:
+        return F.relu(x)
+    own = x.detach() > 0
+    diff = own != mask
+    if report is not None:
+        report["units"] = report.get("units", 0) + x.numel()
+        report["flips"] = report.get("flips", 0) + int(diff.sum())
+        if diff.any():
+            report["max_abs"] = max(report.get("max_abs", 0.0), float(x.detach()[diff].abs().max()))
+    return x * mask.to(x.dtype)
+
+
+def mlp_fea(cfg, mlp, feat, viewdirs, view_pe_progress=1.0, fea_pe_progress=1.0, relu_masks=None, relu_report=None):
     """MLPRender_Fea (tensorBase.py:116-126): [f, d, PE(f), PE(d)] -> 3x Linear -> sigmoid."""
     x = [feat, viewdirs]
     if cfg.fea_pe > 0:
@@ -403,24 +433,27 @@ def mlp_fea(cfg, mlp, feat, viewdirs, view_pe_progress=1.0, fea_pe_progress=1.0)
     if cfg.view_pe > 0:
         x.append(positional_encoding(viewdirs, cfg.view_pe, view_pe_progress))
     x = torch.cat(x, -1)
-    h = F.relu(F.linear(x, mlp["w1"], mlp["b1"]))
-    h = F.relu(F.linear(h, mlp["w2"], mlp["b2"]))
-    return torch.sigmoid(F.linear(h, mlp["w3"], mlp["b3"]))
+    m1, m2 = relu_masks if relu_masks is not None else (None, None)
+    h = _relu(_linear(x, mlp["w1"], mlp["b1"]), m1, relu_report)
+    h = _relu(_linear(h, mlp["w2"], mlp["b2"]), m2, relu_report)
+    return torch.sigmoid(_linear(h, mlp["w3"], mlp["b3"]))
 
 
-def mlp_weakview(cfg, mlp, feat, viewdirs, view_pe_progress=1.0, fea_pe_progress=1.0):
+def mlp_weakview(cfg, mlp, feat, viewdirs, view_pe_progress=1.0, fea_pe_progress=1.0, relu_masks=None,
+                 relu_report=None):
     """MLPRender_Fea_WeakView (tensorBase.py:198-214): view PE joins only at the last layer."""
     x = [feat]
     if cfg.fea_pe > 0:
         x.append(positional_encoding(feat, cfg.fea_pe, fea_pe_progress))
     x = torch.cat(x, -1)
-    h = F.relu(F.linear(x, mlp["w1"], mlp["b1"]))
-    h = F.relu(F.linear(h, mlp["w2"], mlp["b2"]))
+    m1, m2 = relu_masks if relu_masks is not None else (None, None)
+    h = _relu(_linear(x, mlp["w1"], mlp["b1"]), m1, relu_report)
+    h = _relu(_linear(h, mlp["w2"], mlp["b2"]), m2, relu_report)
     mid = []
     if cfg.view_pe > 0:
         mid.append(positional_encoding(viewdirs, cfg.view_pe, view_pe_progress))
     mid.append(h)
-    return torch.sigmoid(F.linear(torch.cat(mid, -1), mlp["w3"], mlp["b3"]))
+    return torch.sigmoid(_linear(torch.cat(mid, -1), mlp["w3"], mlp["b3"]))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -428,7 +461,8 @@ def mlp_weakview(cfg, mlp, feat, viewdirs, view_pe_progress=1.0, fea_pe_progress
 # ----------------------------------------------------------------------------------------------
 def render(cfg, params, center, ray_dir, N_samples, white_bg=True, jitter=None, ndc_ray=False,
            kernel_density=None, kernel_color=None, view_pe_progress=1.0, fea_pe_progress=1.0,
-           use_taps=False, return_aux=False, alpha_mask=None):
+           use_taps=False, return_aux=False, alpha_mask=None, app_mask_override=None, relu_masks_override=None,
+           relu_report=None):
     """rgb [R,3], depth [R], opacity [R] for rays (center, ray_dir) [R,3].
 
     `white_bg` is the already-resolved flag `white_bg or (is_train and coin<0.5)` (batBase.py:154);
@@ -461,10 +495,17 @@ def render(cfg, params, center, ray_dir, N_samples, white_bg=True, jitter=None, 
         sigma = torch.zeros_like(sigma).index_put((valid,), feature2density(cfg, sigma_feat))
     alpha, weight, bg_weight = raw2alpha(sigma, dists * cfg.distance_scale)
     app_mask = weight > cfg.rayMarch_weight_thres
+    own_app_mask = app_mask
+    if app_mask_override is not None:
+        # tests pin this discrete decision (a weight within rounding of the threshold) to the one the implementation
+        # under test took, and check separately that every sample decided differently is such a near-tie
+        app_mask = app_mask_override
     if app_mask.any():
         feat = app_feature(cfg, params, xyz_n[app_mask], kernel_color, use_taps)
         mlp = mlp_weakview if cfg.shadingMode == "MLP_Fea_WeakView" else mlp_fea
-        rgbs = mlp(cfg, params["mlp"], feat, viewdirs[app_mask], view_pe_progress, fea_pe_progress)
+        # relu_masks_override: ([n, hidden] 0/1, [n, hidden] 0/1) for the shaded samples in row-major (ray, sample) order
+        rgbs = mlp(cfg, params["mlp"], feat, viewdirs[app_mask], view_pe_progress, fea_pe_progress,
+                   relu_masks=relu_masks_override, relu_report=relu_report)
         rgb = rgb.index_put((app_mask,), rgbs)
     acc = torch.sum(weight, -1)
     rgb_map = torch.sum(weight[..., None] * rgb, -2)
@@ -476,6 +517,7 @@ def render(cfg, params, center, ray_dir, N_samples, white_bg=True, jitter=None, 
     rgb_map = rgb_map.clamp(0, 1)
     if return_aux:
         aux = dict(xyz=xyz, z=z, valid=valid, sigma=sigma, alpha=alpha, weight=weight, app_mask=app_mask,
+                   own_app_mask=own_app_mask,
                    rgb_samples=rgb, dists=dists, sigma_feat=sigma_feat)
         return rgb_map, depth, acc, aux
     return rgb_map, depth, acc

@@ -1,0 +1,191 @@
+"""GPU parity at the REAL shapes of BASELINE.json's configs ("What's weak" #1): the HIP path through
+bat_hip.Model / the C ABI against the parity-pinned oracle (stock torch ops, fp32) on the same device, same
+parameters, same rays, same draws.
+
+  (i)   bat_blender_VM final stage: 400^3, S = 1000, one ~2 000-ray lattice -- blur off, and one blurred iteration
+  (ii)  the parent yaml's variant BASELINE.json configs[1] quotes: 299^3, 4 096 nominal rays (two 2^22 backward chunks)
+  (iii) bat_llff_VM_MLP stage 0 with 20 480 nominal rays (two chunks), and the final 771 x 859 x 771 grid
+  (iv)  configs[3]: the 62 500-ray iteration (10 chunks) and one 8 192-nominal-ray shard of it
+  (v)   configs[4]: one 32 768-pixel x S = 1 024 eval slice (mode "vis", no gradient)
+  (vi)  a small scene whose shaded samples cross several backward chunks (chunk = 2^16 entries)
+
+The oracle runs the ray batch in slices of a few thousand rays and accumulates gradients (the loss is a sum over
+rays with a global normalisation), so its temporaries stay at a few GB whatever the batch size.  The rays the
+oracle marches are pinned to the VALUES the HIP ray generator produced (autograd graph kept; see
+tests/golden_util.replay_oracle) so that the in-box test of every sample is decided on identical numbers.
+Every test prints the achieved error of each tensor; the assertions are a few times the measured values
+(recorded in profiles/round2_fullsize_parity.txt)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tensorf_oracle as O  # checker only
+from tests import fullsize_util as U
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+# Tolerances = a few times the errors measured on MI355X (profiles/round2_fullsize_parity.txt).  Three discrete decisions
+# sit on the path and each is treated explicitly instead of being absorbed into a loose tolerance:
+#  * in-box test / texel cell of a sample: the product path rounds sample positions and normalised coordinates
+#    exactly like the torch ops (un-fused mul / add), and the oracle marches the product path's ray VALUES;
+#  * `weight > rayMarch_weight_thres`: the oracle is handed the product path's mask; samples it would have decided
+#    differently are counted and must be near-ties (relative distance from the threshold below TOL_TIE);
+#  * ReLU signs of the two hidden layers: a pre-activation within rounding of zero flips with the GEMM's summation
+#    order, and one flipped unit moves the gradient of the ~900 factor elements that sample touches (measured: two
+#    fp32 evaluations of the ORACLE that differ only in the accumulation type of its Linear layers disagree by up to
+#    5e-3 of a plane gradient's max on a handful of texels).  The oracle is handed the sign words the product path
+#    left in its records (jt_shade_record_layout); the units it would have decided differently are counted and
+#    their pre-activations must be within TOL_RELU of zero.
+# With the decisions pinned, what is left is floating-point summation order.
+TOL_VAL = 2e-5       # rgb / opacity, absolute
+TOL_DEPTH = 2e-4
+TOL_GRAD = 1e-4      # every gradient tensor: max |diff| / max |ref|, and relative l2
+TOL_TIE = 1e-4
+TOL_RELU = 2e-5      # |pre-activation| of a unit the two sides decided differently (activations are O(1))
+MAX_FLIP_FRACTION = 1e-4
+
+
+def _train_case(name, opt, model, var, it0, **kw):
+    hip = U.run_hip(opt, model, var, **kw)
+    ref = U.run_oracle(opt, model, var, hip["ctx"])
+    rep = U.compare(name, opt, model, hip, ref)
+    assert rep["values"]["rgb"] <= TOL_VAL and rep["values"]["opacity"] <= TOL_VAL, rep["values"]
+    assert rep["values"]["depth"] <= TOL_DEPTH, rep["values"]
+    np.testing.assert_allclose(hip["total"], ref["total"], rtol=2e-5)
+    assert rep["mask_flips"] <= MAX_FLIP_FRACTION * max(rep["shaded"], 1) + 2, rep["mask_flips"]
+    assert rep["mask_flip_max_rel_distance_from_threshold"] <= TOL_TIE
+    assert rep["relu_flips"] <= MAX_FLIP_FRACTION * rep["relu_units"] + 2, (rep["relu_flips"], rep["relu_units"])
+    assert rep["relu_flip_max_abs_preactivation"] <= TOL_RELU
+    bad = {k: v for k, v in rep["grads"].items() if v[0] > TOL_GRAD or v[1] > TOL_GRAD}
+    if bad:
+        # Two fp32 evaluations cannot be asked to agree better than either agrees with the exact result: where a tensor
+        # misses TOL_GRAD against the fp32 oracle, both are measured against the fp64 oracle (same pinned decisions) and
+        # the product path must be as close to it as the fp32 oracle is (within 2x).  Seen on MI355X for (a) dW of a
+        # hidden layer over > 10^6 samples (rocBLAS' fp32 accumulation is the less accurate side), (b) the density-line
+        # gradients of the 771 x 859 x 771 LLFF grid (10^4 signed float-atomic contributions per element on both sides)
+        # and (c) the random-init field, whose alpha = 1 - exp(-5e-6) is a multiple of the fp32 quantum 6e-8: a last-bit
+        # difference in sigma moves a sample's weight by 1 %.
+        truth = U.run_oracle(opt, model, var, hip["ctx"], dtype=torch.float64)
+        still = {}
+        for k in bad:
+            h, a, t = hip["grads"][k], ref["grads"][k], truth["grads"][k]
+            eh, ea = (U.rel_max(h, t), U.rel_l2(h, t)), (U.rel_max(a, t), U.rel_l2(a, t))
+            print("   grad %-18s vs fp64 oracle: product path %.2e / %.2e, fp32 oracle %.2e / %.2e" % (k, *eh, *ea))
+            rep["grads"][k] += [*eh, *ea]
+            if eh[0] > 2 * ea[0] + 1e-6 or eh[1] > 2 * ea[1] + 1e-6:
+                still[k] = (bad[k], eh, ea)
+        U.record(rep)
+        assert not still, still
+    else:
+        U.record(rep)
+    return rep
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def test_blender_stage4_sharp_400cube():
+    """(i) the bench workload: 400^3, S = 1000, ~2 000 rays, blur off; semi-transparent field (density planes x 25:
+    every in-box sample is shaded and the transmittance decays over the whole ray)."""
+    opt, model, var, it0 = U.build("bat_blender_VM", stage=-1, density_scale=25.0)
+    _train_case("blender_stage4_sharp", opt, model, var, it0)
+
+
+def test_blender_stage4_sharp_random_init():
+    """(i') the same with the untouched random-init field (what bench.py times)."""
+    opt, model, var, it0 = U.build("bat_blender_VM", stage=-1)
+    _train_case("blender_stage4_sharp_random_init", opt, model, var, it0)
+
+
+def test_blender_stage4_blurred_400cube():
+    """(i) the first iteration of the final stage: 65-tap blur of all twelve 400^2 factors (it 9000)."""
+    opt, model, var, it0 = U.build("bat_blender_VM", stage=-1, it=9001, density_scale=25.0)
+    assert model.graph.resolve_blur(opt, "vis")[2] is not None
+    _train_case("blender_stage4_blurred", opt, model, var, it0, blur_scale=0.6)
+
+
+def test_blender_parent_yaml_299cube_4096rays():
+    """(ii) 299^3, 4 096 nominal rays (3 600-4 900 lattice rays x 1 000 samples: two backward chunks)."""
+    opt, model, var, it0 = U.build("bat_blender_VM", stage=-1, n_rays=4096, n_voxel_final=27000000, density_scale=25.0)
+    _train_case("blender_299cube_4096rays", opt, model, var, it0, offsets=(0, 0))
+
+
+def test_llff_stage0_20480rays():
+    """(iii) bat_llff_VM_MLP stage 0: [48,53,48], S = 287, 20 480 nominal NDC rays, blurred, TV regularisers."""
+    opt, model, var, it0 = U.build("bat_llff_VM_MLP", stage=0, it=1)
+    _train_case("llff_stage0_20480rays", opt, model, var, it0, offsets=(2, 3), blur_scale=0.8)
+
+
+def test_llff_final_grid():
+    """(iii) the final LLFF grid 771 x 859 x 771 (planes of 2.7 M texels x 20 / 16 channels), 4 096 nominal rays."""
+    opt, model, var, it0 = U.build("bat_llff_VM_MLP", stage=-1)
+    _train_case("llff_final_grid", opt, model, var, it0, offsets=(2, 3), coin=0.7)
+
+
+def test_configs3_62500rays_and_shard():
+    """(iv) BASELINE.json configs[3]: 65 536 nominal = 62 500 lattice rays (40 M shaded samples: 10 backward chunks), then one
+    8 192-nominal-ray shard (what one of eight ranks renders)."""
+    opt, model, var, it0 = U.build("bat_blender_VM", stage=-1, n_rays=65536, density_scale=25.0)
+    rep = _train_case("configs3_62500rays", opt, model, var, it0, offsets=(3, 5))
+    assert rep["rays"] == 62500 and rep["shaded"] > 9 * (1 << 22)
+    del model
+    U.drop_workspaces()
+    opt, model, var, it0 = U.build("bat_blender_VM", stage=-1, n_rays=8192, density_scale=25.0)
+    _train_case("configs3_shard_8192", opt, model, var, it0, offsets=(3, 5))
+
+
+def test_eval_slice_32768x1024():
+    """(v) BASELINE.json configs[4]: one 32 768-pixel slice of an 800 x 800 view, S = 1 024, 400^3, mode "vis"."""
+    opt, model, var_all, it0 = U.build("bat_blender_VM", stage=-1, density_scale=25.0,
+                                      overrides=dict(data=dict(image_size=[800, 800], num_views=2),
+                                                     nerf=dict(sample_intvs=1024)))
+    g = model.graph
+    tf = g.nerf.tensorf
+    g.nerf.n_samples = g.nerf._find_n_samples(opt, g.nerf.resolution)
+    S = g.nerf.n_samples
+    assert S == 1024
+    ray_idx = torch.arange(200 * 800, 200 * 800 + 32768, device=DEV)
+    with torch.no_grad():
+        pose = var_all.pose[:1]
+        ret = g.render(opt, pose, intr_inv=var_all.intr_inv[:1], ray_idx=ray_idx, mode="vis", intr=var_all.intr[:1])
+        from joint_tensorf_amd import ops
+        c_hip, r_hip = ops.ray_gen(pose, var_all.intr_inv[:1], var_all.intr[:1], ray_idx, opt.W)
+        cfg = U.oracle_cfg(opt, tf)
+        params = U.oracle_params(tf)
+        ref = dict(rgb=[], depth=[], opacity=[])
+        for a in range(0, 32768, 4096):
+            rgb, depth, acc = O.render(cfg, params, c_hip[0, a:a + 4096], r_hip[0, a:a + 4096], S, white_bg=True)
+            ref["rgb"].append(rgb)
+            ref["depth"].append(depth)
+            ref["opacity"].append(acc)
+    rep = dict(case="eval_slice_32768x1024", rays=32768, samples_per_ray=S, grid=tf.gridSize.tolist(), blur=False,
+               loss_hip=0.0, loss_oracle=0.0, values={}, grads={})
+    for k in ("rgb", "depth", "opacity"):
+        r = torch.cat(ref[k]).reshape(ret[k].shape)
+        rep["values"][k] = float((ret[k] - r).abs().max())
+    U.report(rep)
+    U.record(rep)
+    assert rep["values"]["rgb"] <= 2e-5 and rep["values"]["opacity"] <= 2e-5 and rep["values"]["depth"] <= 2e-4, rep
+
+
+def test_backward_chunk_boundaries_small_chunks():
+    """(vi) 2^16-entry backward chunks on a 150^3 scene: ~780 rays x 519 samples, > 2^17 shaded samples, so chunk
+    indices 0, 1, 2(+) all carry samples, a tile straddles no chunk (chunks are whole tiles) and the cross-chunk
+    weight-gradient reduction sums several slabs -- against the oracle, and against the same batch in ONE chunk."""
+    from joint_tensorf_amd._lib import lib
+    prev = lib.jt_shade_set_chunk_log2(16)
+    try:
+        assert lib.jt_shade_chunk_entries() == 1 << 16
+        opt, model, var, it0 = U.build("bat_blender_VM", stage=-1, n_rays=768, n_voxel_final=150 ** 3, density_scale=25.0,
+                                      overrides=dict(data=dict(num_views=4)))
+        rep16 = _train_case("chunk16_150cube", opt, model, var, it0, offsets=(1, 2))
+        g16 = {k: p.grad.detach().clone() for k, p in model.graph.nerf.tensorf.named_parameters() if p.grad is not None}
+    finally:
+        lib.jt_shade_set_chunk_log2(prev)
+    assert lib.jt_shade_chunk_entries() == 1 << prev
+    assert rep16["shaded"] > (1 << 17), rep16["shaded"]
+    opt, model, var, it0 = U.build("bat_blender_VM", stage=-1, n_rays=768, n_voxel_final=150 ** 3, density_scale=25.0,
+                                  overrides=dict(data=dict(num_views=4)))
+    _train_case("chunk22_150cube", opt, model, var, it0, offsets=(1, 2))
+    for k, p in model.graph.nerf.tensorf.named_parameters():
+        if p.grad is not None:
+            assert U.rel_max(g16[k], p.grad) <= 2e-5, (k, U.rel_max(g16[k], p.grad))

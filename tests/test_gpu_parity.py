@@ -1,9 +1,10 @@
 """GPU parity: the HIP path (through the drop-in scene class and the C ABI) against
   (a) the golden vectors captured from the reference, and
   (b) the CPU oracle on the same inputs.
-Tolerances (fp32, different reduction order, float atomics): values 2e-5 abs, gradients 2e-3 of the
-tensor's max-abs (5e-2 for the saturated `dense` fixtures whose render gradient is a cancellation
-residue)."""
+Tolerances = ~4x the errors measured on MI355X (printed per case; round 2: rgb / opacity <= 4.8e-7, gradients
+<= 8.7e-5 of the tensor's max-abs on the Blender fixtures, <= 2.1e-4 on the LLFF ones, 2.1e-3 on the saturated
+`dense` fixtures whose render gradient is a cancellation residue): values 2e-6 abs, gradients 5e-4 / 8e-3.
+The full-size configurations are in tests/test_gpu_fullsize.py."""
 import numpy as np
 import pytest
 import torch
@@ -12,8 +13,8 @@ from tests.golden_util import CASES, Fixture, replay_oracle
 
 pytestmark = pytest.mark.gpu
 
-TOL_VAL = 2e-5
-TOL_GRAD = 2e-3
+TOL_VAL = 2e-6
+TOL_GRAD = 5e-4
 
 
 def _rel(a, b):
@@ -96,19 +97,13 @@ def replay_hip(fx, shade_impl, pin_rays=True, device="cuda"):
                 opacity=acc.view(B, r, 1), total=total, grads=grads, grad_se3=se3.grad)
 
 
-def _supported(fx):
-    return True
-
-
 @pytest.mark.parametrize("name", CASES)
 @pytest.mark.parametrize("shade_impl", ["mfma", "torch"])
 def test_hip_vs_golden_and_oracle(name, shade_impl):
     fx = Fixture(name)
-    if not _supported(fx):
-        pytest.skip("non-cubic blur quirk not built yet")
     out = replay_hip(fx, shade_impl)
     ref = replay_oracle(fx)
-    tol_g = 5e-2 if "dense" in name else TOL_GRAD
+    tol_g = 8e-3 if "dense" in name else TOL_GRAD
     np.testing.assert_allclose(out["pose"].detach().cpu().numpy(), fx.arrays["mid.current_pose"], atol=2e-6)
     np.testing.assert_allclose(out["center"].detach().cpu().reshape(-1, 3).numpy(), fx.arrays["mid.center"], atol=5e-6)
     np.testing.assert_allclose(out["ray"].detach().cpu().reshape(-1, 3).numpy(), fx.arrays["mid.ray_dir"], atol=5e-6)
@@ -118,7 +113,7 @@ def test_hip_vs_golden_and_oracle(name, shade_impl):
     np.testing.assert_allclose(out["depth"].detach().cpu().numpy(), fx.arrays["out.depth"], atol=1e-4)
     if fx.meta["mode"] != "vis":
         np.testing.assert_allclose(float(out["total"].detach()), float(fx.arrays["loss.all"]), rtol=1e-4)
-    bad = []
+    bad, worst = [], ("", 0.0)
     for n, g in out["grads"].items():
         key = fx.grad_key(n)
         assert g is not None, n
@@ -126,7 +121,11 @@ def test_hip_vs_golden_and_oracle(name, shade_impl):
         e2 = _rel(g.detach().cpu().numpy(), ref["grads"][n].numpy())
         if max(e1, e2) > tol_g:
             bad.append((n, e1, e2))
+        if max(e1, e2) > worst[1]:
+            worst = (n, max(e1, e2))
     e = _rel(out["grad_se3"].cpu().numpy(), fx.arrays["grad.se3_refine.weight"])
     if e > tol_g:
         bad.append(("se3", e, _rel(out["grad_se3"].cpu().numpy(), ref["grad_se3"].numpy())))
+    ev = max(float(np.abs(out[k].detach().cpu().numpy() - fx.arrays[g_]).max()) for k, g_ in (("rgb", "out.rgb"), ("opacity", "out.opacity")))
+    print("\n[parity] %-28s %-5s rgb/opacity %.1e  worst gradient %s %.1e  se3 %.1e" % (name, shade_impl, ev, worst[0], worst[1], e))
     assert not bad, bad
