@@ -50,6 +50,16 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--probe-only", action="store_true",
                     help="run only the single-launch kernel probe (the target of the rocprofv3 --pmc passes)")
+    ap.add_argument("--no-probe", action="store_true", help="skip the isolated-launch probe (roofline.probe)")
+    ap.add_argument("--no-torch-baseline", action="store_true",
+                    help="skip the stock-torch-ops GPU baseline (the oracle on device=cuda, same workload)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary workloads (stage 0 / stage 4 blurred, LLFF final grid, blob scene eager + "
+                         "hipGraph), each run as a short child process after the headline")
+    ap.add_argument("--weak", action="store_true",
+                    help="N > 1: every rank renders the yaml's own ray count (weak scaling) instead of the default, "
+                         "BASELINE.json configs[3]: 65 536 nominal rays per iteration sharded N ways (strong scaling)")
+    ap.add_argument("--total-rays", type=int, default=65536, help="nominal rays per iteration of the strong-scaling mode")
     return ap.parse_args()
 
 
@@ -204,8 +214,11 @@ def measure_roofline(model, opt, var, reps=20):
     tf = g.nerf.tensorf
     with torch.no_grad():
         pose = g.get_pose(opt, var, mode="train")
-        ray_idx = torch.arange(0, opt.H * opt.W, max(1, (opt.H * opt.W) // max(1, opt.nerf.n_rays // len(var.idx))),
-                               device=opt.device)[:max(1, opt.nerf.n_rays // len(var.idx))]
+        # the pixel lattice of a training iteration (model/nerf.py:655-673), offsets at half a stride
+        step = g.lattice_step(opt, len(var.idx))
+        sx = torch.arange(step // 2, opt.W, step, device=opt.device)
+        sy = torch.arange(step // 2, opt.H, step, device=opt.device)
+        ray_idx = (sx[None, :] + sy[:, None] * opt.W).reshape(-1)
         center, ray = ops.ray_gen(pose, var.intr_inv, var.intr, ray_idx, opt.W, ndc=bool(opt.camera.ndc))
     probe = ops.KernelProbe(tf, center.reshape(-1, 3), ray.reshape(-1, 3), g.nerf.n_samples,
                             white_bg=bool(opt.nerf.setbg_opaque), ndc=bool(opt.camera.ndc))
@@ -233,6 +246,128 @@ def pmc_traffic(roof):
             "traffic_detail": rec}
 
 
+def instep_roofline(timers, n_comp_app):
+    """roofline block of the dominant kernel from the HIP events recorded around its launches INSIDE the timed steps
+    (ops.STEP_TIMERS): algorithmic bytes of SURVEY 8(d) (backward: the gather bytes re-read + the same bytes added to the
+    gradients) times the shaded samples of every launch, over the summed launch durations."""
+    per = 4 * 3 * n_comp_app * 6
+    out = {}
+    for kind, mult, name in (("bwd", 2, "k_shade_bwd (fused appearance backward: MLP backward on the fp32 matrix cores + "
+                                       "run-length scatter of the factor gradients), inside the timed training steps"),
+                             ("fwd", 1, "k_shade_fwd<train> (gather + basis + MLP + layer-input records), inside the timed "
+                                        "training steps")):
+        rows = [(a.elapsed_time(b) * 1e-3, int(off[-1])) for k, a, b, off in timers if k == kind]
+        if not rows:
+            continue
+        t, n = sum(r[0] for r in rows), sum(r[1] for r in rows)
+        ach = n * mult * per / t / 1e9
+        out[kind] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                     "launch_ms": t / len(rows) * 1e3, "launches": len(rows), "samples_per_launch": n / len(rows),
+                     "samples_per_launch_min_max": [min(r[1] for r in rows), max(r[1] for r in rows)],
+                     "bytes_per_sample": mult * per, "timing": "HIP events on the launch stream around every launch of the "
+                                                                "timed steps"}
+    return out
+
+
+def pmc_traffic_instep(roof):
+    """HBM-side bytes per launch of k_shade_bwd from the committed rocprofv3 --pmc passes over THIS command (separate
+    FETCH_SIZE / WRITE_SIZE runs of `bench.py --no-cpu-baseline --no-probe --no-torch-baseline --no-extras`,
+    tools/pmc_traffic.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), per shaded sample, scaled
+    by the samples of the live launches; null when no in-step file is committed."""
+    path = os.path.join(ROOT, "profiles", "round2_pmc_traffic_instep.json")
+    try:
+        rec = json.load(open(path))
+        k = rec["k_shade_bwd"]
+        return {"traffic": k["hbm_bytes_per_sample"] * roof["samples_per_launch"], "traffic_unit": "bytes/launch",
+                "traffic_source": "profiles/round2_pmc_traffic_instep.json", "traffic_detail": rec}
+    except Exception:
+        return {"traffic": None}
+
+
+def torch_gpu_baseline(opt, model, var_all, steps=3):
+    """The reference ALGORITHM in stock torch ops on this GPU (the parity-pinned oracle, device=cuda: grid_sample /
+    conv1d / cumprod / Linear + autograd + torch.optim.Adam), on the workload just timed: same grid, samples per ray,
+    views and lattice.  This is the "reference single-GPU PyTorch rays/s" of BASELINE.json's north_star."""
+    from oracle import tensorf_oracle as O
+    dev = opt.device
+    tf = model.graph.nerf.tensorf
+    res, S = model.graph.nerf.resolution, model.graph.nerf.n_samples
+    cfg = O.SceneCfg(opt.data.scene_bbox, res, list(opt.nerf.depth.range), step_ratio=opt.nerf.step_ratio).to(dev)
+    sd = {k: v.detach().clone().contiguous() for k, v in tf.state_dict().items()}
+    params = O.params_from_state_dict(sd, prefix="")
+    leaves = [v for _, v in O.flat_params(params)]
+    for v in leaves:
+        v.requires_grad_(True)
+    B, H, W = len(var_all.idx), opt.H, opt.W
+    se3 = torch.zeros(B, 6, device=dev, requires_grad=True)
+    noise = model.graph.pose_noise.detach()
+    optim = torch.optim.Adam(leaves, lr=1e-2, betas=(0.9, 0.99))
+    optim_pose = torch.optim.Adam([se3], lr=1e-3)
+    image = var_all.image.view(B, 3, H * W).permute(0, 2, 1)
+    step_px = model.graph.lattice_step(opt, B)
+    rays = [0]
+
+    def step():
+        ox, oy = np.random.randint(step_px), np.random.randint(step_px)
+        sx = torch.arange(ox, W, step_px, device=dev)
+        sy = torch.arange(oy, H, step_px, device=dev)
+        ray_idx = (sx[None, :] + sy[:, None] * W).reshape(-1)
+        pose = O.train_pose(se3, noise, var_all.pose)
+        c, r = O.rays_for_pixels(pose, var_all.intr_inv, ray_idx, W)
+        jit = torch.rand(c.shape[0] * c.shape[1], 1, device=dev)
+        rgb, _, _ = O.render(cfg, params, c.reshape(-1, 3), r.reshape(-1, 3), S, white_bg=True, jitter=jit)
+        rgb = rgb.view(B, -1, 3)
+        loss = O.render_loss(rgb, image[:, ray_idx]) + 8e-5 * O.density_L1(params)
+        optim.zero_grad()
+        optim_pose.zero_grad()
+        loss.backward()
+        optim.step()
+        optim_pose.step()
+        rays[0] += rgb.shape[0] * rgb.shape[1]
+
+    step()
+    torch.cuda.synchronize()
+    rays[0] = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dict(value=rays[0] / dt, unit="rays/s", ms_per_step=dt / steps * 1e3, steps=steps,
+                rays_per_iter=rays[0] / steps, kind="stock torch ops (parity-pinned oracle) on the same GPU, same grid / "
+                                                     "samples per ray / views / lattice, fwd+loss+bwd+Adam, blur off")
+
+
+def run_extras():
+    """Secondary workloads, each a short child process of this script (its own model, 10 timed steps): numbers DESIGN.md
+    quotes, driver-visible here."""
+    import subprocess
+    base = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-probe",
+            "--no-torch-baseline", "--no-extras"]
+    cases = [("stage0_blurred", ["--stage", "0"], {}),
+             ("stage4_blurred_it9000", ["--stage", "4", "--it", "9000"], {}),
+             ("parent_yaml_299cube_4096rays", ["--n-voxel-final", "27000000", "--n-rays", "4096"], {}),
+             ("llff_final_grid", ["--config", "bat_llff_VM_MLP"], {}),
+             ("blobs_eager", ["--scene", "blobs"], {}),
+             ("blobs_hipgraph", ["--scene", "blobs"], {"JT_GRAPH": "1"})]
+    out = {}
+    for name, flags, env in cases:
+        try:
+            e = dict(os.environ)
+            e.update(env)
+            r = subprocess.run(base + flags, env=e, capture_output=True, text=True, timeout=300)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+            j = json.loads(line)
+            out[name] = {"rays_per_s": j["value"], "ms_per_step": j["ms_per_step"], "workload": j["config"]["workload"],
+                         "launch": j["config"]["launch"]}
+            if "roofline" in j and "launch_ms" in j["roofline"]:
+                out[name]["k_shade_bwd_ms"] = j["roofline"]["launch_ms"]
+                out[name]["roofline_frac"] = j["roofline"]["frac"]
+        except Exception as ex:  # a secondary number must never cost the headline line
+            out[name] = {"error": repr(ex)[:200]}
+    return out
+
+
 def main():
     args = parse()
     world, rank, local = setup_dist(args)
@@ -255,6 +390,9 @@ def main():
         opt.nerf.n_rays = opt.train_schedule.n_rays_rest
     if args.n_rays:
         opt.nerf.n_rays = args.n_rays
+    strong = world > 1 and not args.weak and not args.n_rays
+    if strong:  # BASELINE.json configs[3]: one 65 536-nominal-ray iteration, ray-sharded over the ranks
+        opt.nerf.n_rays = args.total_rays // world
     n_views = int(opt.data.num_views)
     model = build_model(opt, it0, n_views)
     if args.scene == "blobs":
@@ -363,11 +501,46 @@ def main():
         one_step()
     barrier()
     rays_total = 0
+    from joint_tensorf_amd import ops as jops_t
+    # count the C-ABI calls of one step (every call is one to a few kernel launches) -- untimed
+    n_calls = [0]
+    orig_check = jops_t.check
+
+    def counting_check(rc, what):
+        n_calls[0] += 1
+        return orig_check(rc, what)
+    if rank == 0 and stepper is None:
+        jops_t.check = counting_check
+        one_step()
+        jops_t.check = orig_check
+        barrier()
+        rays_total = 0
+    if not args.no_roofline and stepper is None:
+        jops_t.STEP_TIMERS = []  # HIP events around every k_shade_fwd<train> / k_shade_bwd launch of the timed steps
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     barrier()
     dt = time.perf_counter() - t0
+    timers, jops_t.STEP_TIMERS = jops_t.STEP_TIMERS, None
+    # the gradient exchange alone: the three collectives of a backward (appearance factors, density factors, basis +
+    # MLP; ops.RenderRays.backward) on buffers of the same sizes, not overlapped with anything, median of 5
+    allreduce_ms = None
+    if (world > 1 or FORCE_DIST) and OVERLAP and jops_t._DP.get("span_elems"):
+        import torch.distributed as dist
+        allreduce_ms = {}
+        for (lo, hi), n in sorted(jops_t._DP["span_elems"].items()):
+            buf = torch.zeros(n, device=dev)
+            ts = []
+            for _ in range(6):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                dist.barrier()
+                a.record()
+                dist.all_reduce(buf, group=jops_t._DP["group"])
+                b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b))
+            allreduce_ms["%.1f MB" % (n * 4 / 1e6)] = sorted(ts[1:])[2]
     t = torch.tensor([dt, float(rays_total)], device=dev, dtype=torch.float64)
     if world > 1 or FORCE_DIST:
         import torch.distributed as dist
@@ -389,7 +562,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (%s, random-init appearance factors / MLP, random images, 100 cameras on a radius-4 "
@@ -407,8 +580,15 @@ def main():
                 "shade_impl": args.shade_impl,
                 "launch": ("hipGraph replay (%(replayed)d replayed / %(captured)d captured / %(eager)d eager steps)"
                            % stepper.stats) if stepper is not None else "eager",
+                "abi_calls_per_step": n_calls[0] or None,
+                "parallelism": ("ray-sharded data parallel x%d, %d nominal rays per iteration in total, RCCL all-reduce "
+                                "of the VM-factor / basis / MLP gradients inside the backward + pose gradients"
+                                % (world, args.total_rays)) if strong else
+                               ("ray-sharded data parallel x%d, yaml ray count on every rank" % world if world > 1 else "1 GPU"),
             },
         }
+        if allreduce_ms is not None:
+            out["allreduce_ms"] = allreduce_ms
         if os.environ.get("JT_BENCH_CHECKSUM") == "1":  # validation of the N > 1 paths against each other
             with torch.no_grad():
                 tf = model.graph.nerf.tensorf
@@ -418,15 +598,42 @@ def main():
                     "app": float(sum(p.double().abs().sum() for p in tf.app_plane)),
                     "mlp": float(sum(p.double().abs().sum() for p in tf.renderModule.weights())),
                     "se3": float(model.graph.se3_refine.weight.double().abs().sum())}
-        if not args.no_roofline:  # single-launch probe on rank 0 (independent of N)
+        if not args.no_roofline:
             try:
                 from joint_tensorf_amd.options import Opt
-                out["roofline"] = measure_roofline(model, opt, Opt(dict(var_all)))
-                out["roofline"].update(pmc_traffic(out["roofline"]))
-            except Exception as e:  # keep the bench line even if the probe is unavailable
+                tf_ = model.graph.nerf.tensorf
+                ins = instep_roofline(timers or [], tf_.app_n_comp[0])
+                if "bwd" in ins:
+                    out["roofline"] = ins["bwd"]
+                    out["roofline"].update(pmc_traffic_instep(out["roofline"]))
+                    if "fwd" in ins:
+                        out["roofline"]["forward"] = ins["fwd"]
+                else:
+                    out["roofline"] = {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None,
+                                       "traffic": None, "note": "no in-step launch timed (hipGraph replay)"}
+                if not args.no_probe:  # the same kernels as isolated back-to-back launches on one fixed lattice batch
+                    out["roofline"]["probe"] = measure_roofline(model, opt, Opt(dict(var_all)))
+            except Exception as e:  # keep the bench line even if the timing is unavailable
                 out["roofline"] = {"error": repr(e)}
+        if world == 1 and not args.no_torch_baseline and args.config == "bat_blender_VM" and args.scene == "random" \
+                and not model.graph.resolve_blur(opt, "vis")[2]:
+            try:
+                from joint_tensorf_amd.options import Opt
+                out["torch_gpu_baseline"] = torch_gpu_baseline(opt, model, Opt(dict(var_all)))
+                out["vs_baseline"] = out["value"] / out["torch_gpu_baseline"]["value"]
+                out["vs_baseline_note"] = ("BASELINE.md holds no published number for this metric; the denominator is the "
+                                           "reference algorithm in stock torch ops on the same GPU, measured in this run "
+                                           "(torch_gpu_baseline)")
+            except Exception as e:
+                out["torch_gpu_baseline"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(res, S)
+        if world == 1 and not args.no_extras:
+            # free this process' device memory first: the children build their own models
+            del model
+            jops_t._WS.clear()
+            torch.cuda.empty_cache()
+            out["extra"] = run_extras()
         print(json.dumps(out))
     if world > 1 or FORCE_DIST:
         import torch.distributed as dist

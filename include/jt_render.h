@@ -238,7 +238,9 @@ size_t jt_march_backward_workspace_bytes(const JtScene* scene, int n_rays);
  * aux_stream / ev_fork / ev_join (hipStream_t / hipEvent_t, all three or none): when given, the MLP / basis
  * weight-gradient GEMMs are enqueued on aux_stream behind ev_fork (recorded on `stream` after the per-sample
  * kernels) and ev_join is recorded on aux_stream at their end; the caller makes whoever consumes g_mlp wait
- * for ev_join.  This lets the MFMA-bound GEMMs overlap the atomics-bound density backward. */
+ * for ev_join.  This lets the MFMA-bound GEMMs overlap the atomics-bound density backward.  ev_fork alone (no
+ * aux_stream): recorded on `stream` behind the per-sample backward kernels, in front of the weight-gradient GEMMs
+ * (a timing mark). */
 size_t jt_shade_workspace_bytes(const JtScene* scene, int n_entries_max);
 /* Shaded samples per backward launch ("chunk": batBase.py has no counterpart, it is how the build bounds the
  * per-launch record block).  jt_shade_chunk_entries() = the current value (2^22 unless JT_SHADE_CHUNK_LOG2 says

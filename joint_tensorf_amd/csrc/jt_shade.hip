@@ -1242,6 +1242,9 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     if (hipEventRecord(ev_fork, st) != hipSuccess) return JT_ERR_ARG;
     if (hipStreamWaitEvent(aux, ev_fork, 0) != hipSuccess) return JT_ERR_ARG;
   }
+  // no auxiliary stream but an event: it marks the end of the per-sample backward kernels on `stream` (callers time
+  // k_shade_bwd inside a training step with it: bench.py's in-step roofline)
+  if (!use_aux && ev_fork && hipEventRecord(ev_fork, st) != hipSuccess) return JT_ERR_ARG;
   if (!(use_aux && pipe)) {
     for (int ci = 0; ci < nchunks; ++ci) {
       int rc = launch_wgrad(ci);

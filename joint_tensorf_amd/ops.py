@@ -44,6 +44,10 @@ def poke_floats(dst, values, offset=0):
 
 
 KEEP_INTERMEDIATES = False
+# In-step kernel timing (bench.py's roofline): while STEP_TIMERS is a list, every training render appends
+# (kind, start event, end event, shade_offset tensor) for its k_shade_fwd<train> and k_shade_bwd launches -- HIP events on
+# the launch stream, read by the caller after its own synchronisation (no sync is added here).
+STEP_TIMERS = None
 _AUX = {}
 _WS = {}
 _WS_EPOCH = {}
@@ -346,9 +350,16 @@ class RenderRays(torch.autograd.Function):
                 ws_args = (ptr(ws), nbytes, _lib.JT_SHADE_POSE_ONLY if ctx.pose_only else 0)
             else:
                 ws_args = (None, 0, 0)
+            timed = STEP_TIMERS is not None and ws_args[0] is not None
+            if timed:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record()
             check(lib.jt_shade_forward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
                                        ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(rgb_s),
                                        cap, *ws_args, st), "jt_shade_forward")
+            if timed:
+                t1.record()
+                STEP_TIMERS.append(("fwd", t0, t1, offset))
         rgb = torch.empty(R, 3, **f32)
         cmask = torch.empty(R, device=dev, dtype=torch.int32)
         check(lib.jt_composite_forward(scene, R, ptr(offset), ptr(sidx), ptr(weight), ptr(rgb_s), ptr(opacity),
@@ -427,6 +438,7 @@ class RenderRays(torch.autograd.Function):
 
         def dp_reduce(lo, hi):
             import torch.distributed as dist
+            _DP.setdefault("span_elems", {})[(lo, hi)] = hi - lo  # sizes of the collectives (bench.py times them)
             dp_works.append(dist.all_reduce(gflat[lo:hi], op=dist.ReduceOp.SUM, group=_DP["group"], async_op=True))
         if cfg.shade_impl == "torch":
             g_mlp = [torch.zeros_like(t) for t in mlp_t]
@@ -474,6 +486,13 @@ class RenderRays(torch.autograd.Function):
                 join = ev_join
             else:
                 h_aux = (None, None, None)
+            if STEP_TIMERS is not None and not ctx.pose_only:
+                # the fork event doubles as the end mark of k_shade_bwd (jt_render.h); a fresh timing-enabled pair per call
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record()
+                t1.record()  # creates the handle; the library records it again behind k_shade_bwd
+                h_aux = (h_aux[0], ctypes.c_void_p(t1.cuda_event), h_aux[2])
+                STEP_TIMERS.append(("bwd", t0, t1, offset))
             check(lib.jt_shade_backward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
                                         ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(rgb_s),
                                         ptr(g_rgb_s), gfac, gm, ptr(g_xyz), cap, ptr(ws), nbytes, 0, st, *h_aux),
