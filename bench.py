@@ -225,27 +225,6 @@ def measure_roofline(model, opt, var, reps=20):
     return probe.run(reps)
 
 
-def pmc_traffic(roof):
-    """HBM-side bytes per launch of the probed kernels from the committed rocprofv3 --pmc passes
-    (profiles/round1_pmc_traffic.json, made by tools/pmc_traffic.py from separate FETCH_SIZE and WRITE_SIZE passes
-    over `bench.py --probe-only`; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters
-    cannot be read from inside the timed process, so the figure is the recorded bytes per shaded sample of the
-    same launch shape times the samples of the live launch; it is dropped (null) when the live launch differs
-    from the recorded one by more than 5 % in samples."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
-    try:
-        rec = json.load(open(path))
-    except Exception:
-        return {"traffic": None}
-    k = rec.get("k_shade_bwd")
-    n = roof.get("samples_per_launch")
-    if not k or not n or abs(k["samples_per_launch"] - n) > 0.05 * n:
-        return {"traffic": None}
-    return {"traffic": k["hbm_bytes_per_sample"] * n, "traffic_unit": "bytes/launch",
-            "traffic_source": "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-            "traffic_detail": rec}
-
-
 def instep_roofline(timers, n_comp_app):
     """roofline block of the dominant kernel from the HIP events recorded around its launches INSIDE the timed steps
     (ops.STEP_TIMERS): algorithmic bytes of SURVEY 8(d) (backward: the gather bytes re-read + the same bytes added to the
@@ -488,6 +467,10 @@ def main():
         finally:
             np.random.randint = orig_randint
 
+    if not args.no_roofline and stepper is None:
+        from joint_tensorf_amd import ops as _jops
+        # HIP events around every k_shade_fwd<train> / k_shade_bwd launch; the ones of the timed steps make the roofline
+        _jops.STEP_TIMERS = []
     # priming (untimed, in front of the warm-up): one eager step on the densest lattice (offsets 0, 0) so that every
     # persistent workspace and allocator block reaches its final size, then one step per lattice shape so that the
     # hipGraph of each shape is captured before the clock starts
@@ -515,14 +498,14 @@ def main():
         jops_t.check = orig_check
         barrier()
         rays_total = 0
-    if not args.no_roofline and stepper is None:
-        jops_t.STEP_TIMERS = []  # HIP events around every k_shade_fwd<train> / k_shade_bwd launch of the timed steps
+    n_untimed = len(jops_t.STEP_TIMERS) if jops_t.STEP_TIMERS is not None else 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     barrier()
     dt = time.perf_counter() - t0
-    timers, jops_t.STEP_TIMERS = jops_t.STEP_TIMERS, None
+    all_timers, jops_t.STEP_TIMERS = jops_t.STEP_TIMERS, None
+    timers = all_timers[n_untimed:] if all_timers is not None else None
     # the gradient exchange alone: the three collectives of a backward (appearance factors, density factors, basis +
     # MLP; ops.RenderRays.backward) on buffers of the same sizes, not overlapped with anything, median of 5
     allreduce_ms = None
@@ -605,6 +588,10 @@ def main():
                 ins = instep_roofline(timers or [], tf_.app_n_comp[0])
                 if "bwd" in ins:
                     out["roofline"] = ins["bwd"]
+                    # every k_shade_bwd launch of the process (priming and warm-up included): what a profiler sees
+                    alls = [int(off[-1]) for k, a, b, off in all_timers if k == "bwd"]
+                    out["roofline"]["process_launches"] = len(alls)
+                    out["roofline"]["process_samples_per_launch"] = sum(alls) / max(len(alls), 1)
                     out["roofline"].update(pmc_traffic_instep(out["roofline"]))
                     if "fwd" in ins:
                         out["roofline"]["forward"] = ins["fwd"]
