@@ -413,7 +413,7 @@ def main():
         g = model.graph
         if stepper is not None:
             stepper.train_iteration(opt, var, force_eager=not use_graph[0])
-            model.after_iteration(opt, model.it - 1)
+            model.after_iteration(opt)
             rgb = stepper.last_var.rgb
             rays_total += rgb.shape[0] * rgb.shape[1]
             return
@@ -445,7 +445,7 @@ def main():
         if model.sched_pose is not None:
             model.sched_pose.step()
         nerf.set_progress(model.it / opt.max_iter)
-        model.after_iteration(opt, it)
+        model.after_iteration(opt)
         rays_total += var.rgb.shape[0] * var.rgb.shape[1]
 
     def barrier():

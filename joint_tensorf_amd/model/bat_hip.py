@@ -74,7 +74,7 @@ class NeRF(torch.nn.Module):
 
     def reset(self, opt, bbox, n_voxel_list, n_voxels, alphamask_resolution, lr_basis, lr_index, TV_weight_color,
               TV_weight_density):
-        self.bbox = torch.as_tensor(bbox).to(torch.float).view(2, 3)
+        self.bbox = torch.as_tensor(bbox).to(torch.float).view(2, 3).cpu()  # host state (a checkpoint may hand a device tensor)
         self.n_voxel_list = list(n_voxel_list)
         self.n_voxels = n_voxels
         self.resolution = self._find_resolution(opt, self.n_voxels)
@@ -173,6 +173,27 @@ class NeRF(torch.nn.Module):
     def unfreeze_scene(self, opt):
         self.tensorf.unfreeze_scene(opt)
 
+    # ---- state besides the state_dict (model/tensorf.py:491-524) ---------------------------------------------------
+    def get_reset_kwargs(self):
+        return {"bbox": self.bbox, "n_voxel_list": self.n_voxel_list, "n_voxels": self.n_voxels,
+                "alphamask_resolution": self.alphamask_resolution, "lr_basis": self.lr_basis, "lr_index": self.lr_index,
+                "TV_weight_color": self.TV_weight_color, "TV_weight_density": self.TV_weight_density}
+
+    def save_param_state(self):
+        ckpt = self.tensorf.save_param_state()
+        ckpt.update({"nerf_reset_kwargs": self.get_reset_kwargs()})
+        return ckpt
+
+    def load_param_state(self, opt, ckpt):
+        """Resize the scene to the checkpointed grid (the state_dict that follows would not fit a fresh model after
+        an upsampling or a shrink) and, when training resumes, rebuild the optimizer at the checkpointed rates."""
+        kw = dict(ckpt["nerf_reset_kwargs"])
+        self.reset(opt=opt, **kw)
+        self.tensorf.load_param_state(ckpt)
+        self.tensorf.to(opt.device)
+        if self.register_new_optimizer is not None:
+            self.register_new_optimizer(self._get_optimizer(opt, ckpt["iter"], kw["lr_basis"], kw["lr_index"]))
+
 
 class Graph(torch.nn.Module):
     def __init__(self, opt):
@@ -186,6 +207,13 @@ class Graph(torch.nn.Module):
         self.lattice_rank = None  # (rank, world) under ray-sharded data parallelism (dist.rank_lattice_offset)
         self.eval_graph = None
         self.lattice_override = None  # callable(step) -> (ray_idx, grid_H, grid_W); see graphed.GraphedTrainStep
+
+    def save_param_state(self):
+        """model/tensorf.py:270-276"""
+        return self.nerf.save_param_state()
+
+    def load_param_state(self, opt, ckpt):
+        self.nerf.load_param_state(opt, ckpt)
 
     # ---- pose (model/bat.py:341-367) -------------------------------------------------------------
     def get_pose(self, opt, var, mode=None):
@@ -401,8 +429,35 @@ class Model(torch.nn.Module):
     def __init__(self, opt):
         super().__init__()
         self.it = 0
+        self.iter_start = self.epoch_start = 0
+        self.train_data = self.test_data = None
 
-    def build_networks(self, opt, n_views):
+    # ---- the lifecycle train_3d.py:70-80,95-107 drives ---------------------------------------------------------
+    def load_dataset(self, opt, eval_split="val", train_split="train"):
+        """base.Model.load_dataset + nerf.Model.load_dataset (model/base.py:25-34, model/nerf.py:35-40): the training
+        views are prefetched and kept resident on the device.  `opt.data.train_views` / `opt.data.test_views` may hold
+        ready-made `var`-layout dicts (idx, image, pose, intr, intr_inv); otherwise joint_tensorf_amd.data.load picks the
+        reference's loader when importable and the synthetic scene of SURVEY 8(d) if not."""
+        from .. import data as jdata
+        sub = opt.data.get("train_sub", None)
+        tv = opt.data.get("train_views", None)
+        self.train_data = jdata.DictDataset(opt, tv, train_split) if tv is not None else jdata.load(opt, train_split, sub)
+        self.train_loader = self.train_data.setup_loader(opt, shuffle=False)
+        if opt.data.get("val_on_test", False):
+            eval_split = "test"
+        sub = opt.data.get("test_sub" if eval_split == "test" else "val_sub", None)
+        ev = opt.data.get("test_views", None)
+        self.test_data = jdata.DictDataset(opt, ev, eval_split) if ev is not None else jdata.load(opt, eval_split, sub)
+        self.test_loader = self.test_data.setup_loader(opt, shuffle=False)
+        self.train_data.prefetch_all_data(opt)
+        self.train_data.all = Opt({k: (v.to(opt.device) if torch.is_tensor(v) else v)
+                                   for k, v in dict(self.train_data.all).items()})
+        self.n_train_views = len(self.train_data.all.idx)
+
+    def build_networks(self, opt, n_views=None):
+        """model/bat.py:30-47; n_views defaults to the loaded training set (the reference reads len(self.train_data))."""
+        if n_views is None:
+            n_views = len(self.train_data)
         self.graph = Graph(opt).to(opt.device)
         if opt.camera.noise:
             se3_noise = torch.randn(n_views, 6, device=opt.device) * opt.camera.noise
@@ -482,6 +537,8 @@ class Model(torch.nn.Module):
             pg = self.optim_pose.param_groups[0]
             pg["lr_orig"] = pg["lr"]
             pg["lr"] *= min(1, self.it / opt.optim.warmup_pose)
+        # (reproduced quirk, SURVEY App. B-15: base.train_iteration zeroes the scene gradients at the top of EVERY
+        #  iteration, model/base.py:118, so opt.optim.grad_accum_iter > 1 only thins out the optimizer steps)
         self.optim.zero_grad()
         var = g.forward(opt, var, mode="train")
         loss = g.compute_loss(opt, var, mode="train")
@@ -501,9 +558,167 @@ class Model(torch.nn.Module):
         g.nerf.set_progress(self.it / opt.max_iter)
         return loss
 
-    def after_iteration(self, opt, it):
-        """the part of nerf.Model.train's loop body that follows train_iteration (model/nerf.py:258-260)."""
-        self.graph.nerf.update_schedule(opt, it)
+    def after_iteration(self, opt, it=None):
+        """The part of nerf.Model.train's loop body that follows train_iteration (model/nerf.py:258-260).  The
+        reference calls update_schedule with self.it AFTER base.train_iteration has incremented it:
+        the grid therefore grows right after the training step with index upsample_iters[k] - 1."""
+        self.graph.nerf.update_schedule(opt, self.it if it is None else it)
+
+    def before_iteration(self, opt, it=None):
+        """The per-iteration schedule glue at the top of nerf.Model.train's loop body (model/nerf.py:171-205): 2-D blur
+        cache refresh is select_supervision's; here the ray count, the pose / scene gradient-accumulation periods, the
+        pose resets and the sampling-strategy switches."""
+        it = self.it if it is None else it
+        ts = opt.train_schedule
+        if _has(ts, "change_n_rays_after_n_iters"):
+            opt.nerf.n_rays = ts.n_rays_init if it < ts.change_n_rays_after_n_iters else ts.n_rays_rest
+        if _has(ts, "change_n_AccumPoseGrad_after_n_iters"):
+            opt.optim.pose_grad_accum_iter = (ts.n_AccumPoseGrad_init if it < ts.change_n_AccumPoseGrad_after_n_iters
+                                              else ts.n_AccumPoseGrad_rest)
+        if _has(ts, "change_n_AccumGrad_after_n_iters"):
+            opt.optim.grad_accum_iter = (ts.n_AccumGrad_init if it < ts.change_n_AccumGrad_after_n_iters
+                                         else ts.n_AccumGrad_rest)
+        if (_has(ts, "reset_pose_on_iter") and ts.reset_pose_on_iter == it) or \
+                (_has(ts, "reset_pose_on_iters") and it in ts.reset_pose_on_iters):
+            self.interrupt_pose(opt)
+        if _has(ts, "all_view_sample_after_n_iters") and it == ts.all_view_sample_after_n_iters:
+            opt.nerf.ray_sampling_strategy = "all_view_rand_rays"
+        if _has(ts, "single_view_sample_after_n_iters") and it == ts.single_view_sample_after_n_iters:
+            opt.nerf.ray_sampling_strategy = "single_view_rand_rays"
+
+    @torch.no_grad()
+    def interrupt_pose(self, opt):
+        """model/bat.py:78-81"""
+        self.graph.se3_refine.weight.mul_(0.0)
+
+    def freeze_poses(self, opt):
+        """model/bat.py:82-83 sets `requires_grad` on the Embedding MODULE (an attribute nobody reads); the evident
+        intent -- no pose gradients during evaluation -- is applied to its weight as well."""
+        self.graph.se3_refine.requires_grad = False
+        self.graph.se3_refine.weight.requires_grad_(False)
+
+    def unfreeze_poses(self, opt):
+        self.graph.se3_refine.requires_grad = True
+        self.graph.se3_refine.weight.requires_grad_(True)
+
+    def freeze_scene(self, opt):
+        self.graph.nerf.freeze_scene(opt)
+
+    def unfreeze_scene(self, opt):
+        self.graph.nerf.unfreeze_scene(opt)
+
+    def save_param_state(self):
+        """model/tensorf.py:77-83"""
+        return self.graph.save_param_state()
+
+    def load_param_state(self, opt, ckpt):
+        self.graph.load_param_state(opt, ckpt)
+
+    def save_checkpoint(self, opt, ep=0, it=0, latest=False):
+        """model/base.py:235-238, file format of util.py:162-184"""
+        from ..checkpoint import save_checkpoint
+        return save_checkpoint(opt, self, ep=ep, it=it, latest=latest)
+
+    def restore_checkpoint(self, opt):
+        """model/base.py:60-71"""
+        from ..checkpoint import restore_checkpoint
+        ep = it = None
+        if opt.get("resume", False):
+            ep, it = restore_checkpoint(opt, self, resume=opt.resume)
+        elif opt.get("load", None) is not None:
+            ep, it = restore_checkpoint(opt, self, load_name=opt.load)
+        self.epoch_start, self.iter_start = ep or 0, it or 0
+
+    def setup_visualizer(self, opt):
+        """model/base.py:73-88: TensorBoard / visdom / wandb writers are the reference engine's (out of scope, SURVEY
+        section 2); a run with opt.tb / opt.visdom set says so instead of silently dropping them."""
+        if opt.get("tb", False) or opt.get("visdom", False):
+            print("joint_tensorf_amd: TensorBoard / visdom logging is not part of this build (scalars are returned by "
+                  "train_iteration and printed every opt.freq.scalar iterations)")
+
+    @torch.no_grad()
+    def validate(self, opt, ep=None):
+        """model/bat.py:118-122: the Procrustes alignment of the current poses, which eval-mode get_pose needs (the
+        image-space validation render and its logging are the reference engine's)."""
+        pose, pose_GT = self.get_all_training_poses(opt)
+        _, self.graph.sim3 = self.prealign_cameras(opt, pose, pose_GT)
+
+    def train(self, opt):
+        """nerf.Model.train (model/nerf.py:150-278) without the logging / visualisation side effects: schedule glue,
+        2-D supervision choice, train_iteration, update_schedule, periodic validate and checkpoints.  Returns the last
+        loss dict."""
+        import time
+        self.graph.train()
+        self.ep = 0
+        if self.iter_start == 0:
+            self.validate(opt, 0)
+        if _has(opt, "view_sampling_n_groups"):
+            ng = opt.view_sampling_n_groups
+            all_views = torch.randperm(self.n_train_views, device=opt.device)
+            self.group_idx = [all_views[i::ng] for i in range(ng)]
+        freq = opt.get("freq", Opt())
+        f_scalar, f_val, f_ckpt = (int(freq.get(k, 0) or 0) for k in ("scalar", "val", "ckpt"))
+        images_all = self.train_data.all.image
+        loss, t0 = None, time.time()
+        for it in range(int(opt.max_iter)):
+            self.it = it
+            if _has(opt, "early_stop_iter") and opt.early_stop_iter == it:
+                break
+            self.graph.it = it
+            if it < self.iter_start:
+                # a resumed run passes through the skipped iterations' cache refreshes (model/nerf.py:172-176 sits in
+                # front of the `continue`): the 2-D supervision cache is the one the uninterrupted run would hold
+                if it % 500 == 0 and _has(opt, "blur_2d") and opt.blur_2d:
+                    self.blurred_gt_cached_images = self.process_GT_images(opt, images_all)
+                    self.blurred_edge_masks = self.get_edge_mask(opt, self.blurred_gt_cached_images)
+                continue
+            self.before_iteration(opt, it)
+            train_images, train_edge_masks, sc = self.select_supervision(opt, images_all)
+            var = Opt(dict(self.train_data.all))
+            var.image, var.train_edge_masks = train_images, train_edge_masks
+            if _has(opt, "sync_2d_3d_scales") and opt.sync_2d_3d_scales:
+                var.scale = sc
+                self.graph.scale = sc
+            view_idx = None
+            if opt.nerf.ray_sampling_strategy == "single_view_rand_rays":
+                self.view_index = self.graph.view_index = it % self.n_train_views
+                view_idx = [self.view_index]
+            elif _has(opt, "view_sampling_n_groups"):
+                view_idx = self.group_idx[it % opt.view_sampling_n_groups]
+            if view_idx is not None:
+                for k in ("image", "pose", "intr_inv", "idx", "intr"):
+                    var[k] = var[k][view_idx]
+            loss = self.train_iteration(opt, var)
+            self.after_iteration(opt)  # self.it is it + 1 here, as in the reference
+            if f_scalar and self.it % f_scalar == 0:
+                self.check_finite(opt, loss)  # one host read per opt.freq.scalar iterations (model/tensorf.py:43-44)
+                print("it %d  loss %.6f  (%.1f it/s)" % (self.it, float(loss.all.detach()), (it + 1) / (time.time() - t0)))
+            if f_val and self.it % f_val == 0:
+                self.validate(opt, self.it)
+            if f_ckpt and self.it % f_ckpt == 0 and _has(opt, "output_path"):
+                self.save_checkpoint(opt, ep=None, it=self.it)
+        if _has(opt, "output_path") and opt.output_path:
+            self.save_checkpoint(opt, ep=None, it=self.it, latest=True)
+        return loss
+
+    def check_finite(self, opt, loss):
+        """The reference asserts finite loss terms every iteration (model/tensorf.py:43-44) and raises on NaN poses
+        (model/tensorf.py:147-151); each is a device->host read.  Here both are checked through one device-side flag
+        word (Graph.nonfinite: set by the loss / pose kernels' outputs) read when the caller asks."""
+        bad = []
+        for k, v in loss.items():
+            if torch.is_tensor(v) and not bool(torch.isfinite(v.detach()).all()):
+                bad.append(k)
+        if not bool(torch.isfinite(self.graph.se3_refine.weight.detach()).all()):
+            bad.append("se3_refine")
+        if bad:
+            raise FloatingPointError("non-finite values in: %s (iteration %d)" % (", ".join(bad), self.it))
+
+    def generate_videos_synthesis(self, opt, eps=1e-10, it=None):
+        """model/nerf.py:574-640 writes novel-view videos through ffmpeg / wandb: reference engine, out of scope.  Kept
+        as a callable no-op so that the train_3d.py sequence runs through."""
+        print("joint_tensorf_amd: generate_videos_synthesis is not part of this build (evaluate_full renders the test views)")
+        return None
 
     # ---- evaluation (SURVEY 8(f) N1) ---------------------------------------------------------------------------
     @torch.no_grad()
@@ -617,9 +832,13 @@ class Model(torch.nn.Module):
         psnr = -10 * g.MSE_loss(rgb_map, var.image).log10().item()
         return Opt(psnr=psnr, rgb_map=rgb_map, invdepth_map=invdepth_map, var=var)
 
-    def evaluate_full(self, opt, test_views, pose_GT=None):
-        """model/bat.py:241-263 + model/nerf.py:525-572 on an iterable of per-view batches (idx, pose, intr,
-        intr_inv, image): camera alignment errors, then PSNR per held-out view."""
+    def evaluate_full(self, opt, test_views=None, pose_GT=None, eps=1e-10):
+        """model/bat.py:241-263 + model/nerf.py:525-572: camera alignment errors, then PSNR per held-out view.
+        `test_views`: an iterable of per-view batches (idx, pose, intr, intr_inv, image); default self.test_loader, as
+        in the reference's `evaluate_full(opt)`."""
+        if test_views is None:
+            test_views = [{k: (v.to(opt.device) if torch.is_tensor(v) else v) for k, v in dict(b).items()}
+                          for b in self.test_loader]
         self.graph.eval()
         pose, pose_GT = self.get_all_training_poses(opt, pose_GT)
         pose_aligned, self.graph.sim3 = self.prealign_cameras(opt, pose, pose_GT)

@@ -384,6 +384,12 @@ class BAT_VMSplit(torch.nn.Module):
                   "convolve_positive_only", "ignore_negative_split"):
             if bool(getattr(arch, k, False) if not isinstance(arch, dict) else arch.get(k, False)):
                 raise NotImplementedError("arch.%s=true is outside the hot path (false in every BAT yaml)" % k)
+        # the ray generator always applies the attached NDC centre shift (camera.py:308-314 with the BAT yamls' values)
+        get = (lambda k, d: arch.get(k, d)) if isinstance(arch, dict) else (lambda k, d: getattr(arch, k, d))
+        if not bool(get("ndc_center_shift", True)):
+            raise NotImplementedError("arch.ndc_center_shift=false is not built (true in bat_llff_VM_MLP)")
+        if bool(get("detach_ndc_center_shift", False)):
+            raise NotImplementedError("arch.detach_ndc_center_shift=true is not built (false in bat_llff_VM_MLP)")
 
     # ---- the renderer (batBase.py:44-165) -----------------------------------------------------------
     def forward(self, opt, center, ray_dir, white_bg=True, is_train=False, ndc_ray=False, N_samples=-1,

@@ -63,7 +63,7 @@ def _run(use_graph, K, it0=0):
         finally:
             np.random.randint = orig_randint
         losses.append([float(loss.all.detach()), float(loss.render.detach()), float(loss.L1.detach())])
-        model.after_iteration(opt, model.it - 1)
+        model.after_iteration(opt)
     sd = {k: v.detach().clone() for k, v in model.graph.state_dict().items()}
     return np.array(losses), sd, (stepper.stats if use_graph else None), np.random.get_state()[1][:8].copy()
 
@@ -107,9 +107,9 @@ def test_one_replayed_step_equals_one_eager_step(it0):
         try:
             for _ in range(3):
                 stepper.train_iteration(opt, Opt(dict(var0)), force_eager=True)
-                model.after_iteration(opt, model.it - 1)
+                model.after_iteration(opt)
             loss = stepper.train_iteration(opt, Opt(dict(var0)), force_eager=not use_graph)
-            model.after_iteration(opt, model.it - 1)
+            model.after_iteration(opt)
         finally:
             np.random.randint = orig_randint
         moments = {}
@@ -137,7 +137,7 @@ def test_graph_is_dropped_when_the_optimizer_is_rebuilt():
     stepper = GraphedTrainStep(model, min_repeats=0)
     for _ in range(30):
         stepper.train_iteration(opt, Opt(dict(var0)))
-        model.after_iteration(opt, model.it - 1)
+        model.after_iteration(opt)
     assert stepper.stats["replayed"] >= 20
     res = model.graph.nerf.resolution
     assert res[0] > 14  # the grid was upsampled in the middle and the run went on (graphs re-captured)

@@ -80,7 +80,7 @@ def test_training_trajectory_matches_oracle_loop():
             jit = torch.rand(B * n_lattice, 1, generator=gj)
             tf.jitter_override = jit.to(DEV)
             loss = model.train_iteration(opt, Opt(dict(var0)))
-            model.after_iteration(opt, it)
+            model.after_iteration(opt)
             loss_hip.append(float(loss.all.detach()))
             assert not ints and not ch
 
@@ -201,7 +201,7 @@ def test_training_trajectory_llff_matches_oracle_loop():
             tf.jitter_override = jit.to(DEV)
             tf.coin_override = coins[k]
             loss = model.train_iteration(opt, Opt(dict(var0)))
-            model.after_iteration(opt, it)
+            model.after_iteration(opt)
             loss_hip.append(float(loss.all.detach()))
             assert not ints and not ch
 
@@ -292,14 +292,14 @@ def test_plain_tensorf_trains_through_an_alpha_mask_update():
     losses = []
     for it in range(5):
         loss = model.train_iteration(opt, Opt(dict(var0)))
-        if it == 3:  # the update iteration: a threshold that keeps the densest part of the current field
+        if model.it == 3:  # the update iteration (update_schedule sees the incremented counter)
             with torch.no_grad():
                 a, _ = tf.getDenseAlpha(tf.gridSize.tolist())
             tf.alphaMask_thres = float(torch.quantile(a.flatten(), 0.985))
-        model.after_iteration(opt, it)
+        model.after_iteration(opt)
         losses.append(float(loss.all.detach()))
         assert np.isfinite(losses[-1])
-        if it == 3:
+        if it == 2:
             assert tf.alphaMask is not None and tf.gridSize.tolist() != grid0  # mask built, box shrunk
             assert 0.0 < float(tf.alphaMask.alpha_volume.mean()) < 0.9
     # one more forward with fixed draws, against the oracle on the shrunk scene with the same mask

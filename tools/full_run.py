@@ -45,15 +45,12 @@ def main():
     torch.cuda.synchronize()
     t_all = time.perf_counter()
     for it in range(last):
-        if it < opt.train_schedule.change_n_rays_after_n_iters:
-            opt.nerf.n_rays = opt.train_schedule.n_rays_init
-        else:
-            opt.nerf.n_rays = opt.train_schedule.n_rays_rest
+        model.before_iteration(opt, it)   # ray count, pose-gradient accumulation period, pose resets (model/nerf.py:177-205)
         images, masks, sc = model.select_supervision(opt, views.image)      # model/nerf.py:172-176,209-227
         var = Opt(dict(views))
         var.image, var.train_edge_masks = images, masks
         loss = stepper.train_iteration(opt, var) if stepper is not None else model.train_iteration(opt, var)
-        model.after_iteration(opt, it)
+        model.after_iteration(opt)
         if (it + 1) in marks or (it + 1) % 2000 == 0:
             torch.cuda.synchronize()
             lv = float(loss.all)

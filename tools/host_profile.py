@@ -25,7 +25,7 @@ var_all = make_views(opt, 100, seed=0, device="cuda:0")
 
 def step():
     model.train_iteration(opt, Opt(dict(var_all)))
-    model.after_iteration(opt, model.it - 1)
+    model.after_iteration(opt)
 
 
 for _ in range(5):

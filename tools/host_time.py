@@ -18,7 +18,7 @@ var_all = make_views(opt, 100, seed=0, device=dev)
 def step():
     var = Opt(dict(var_all))
     model.train_iteration(opt, var)
-    model.after_iteration(opt, model.it - 1)
+    model.after_iteration(opt)
 for _ in range(5): step()
 torch.cuda.synchronize()
 N = 20

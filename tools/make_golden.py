@@ -625,6 +625,102 @@ def known_answers(camera, kernels, bat, out_path):
     print("wrote", out_path)
 
 
+def ckpt_case(bat, camera, options, out_path, seed=41):
+    """A checkpoint as the reference's own util.save_checkpoint writes it (util.py:162-184), taken AFTER a grid
+    upsampling (so that its tensors no longer fit a freshly built model) and two optimizer steps, unpacked into plain
+    arrays + JSON: graph state_dict, manually tracked parameters, Adam state; plus what the reference renders from the
+    restored state (mode "vis") -- the target of the build's restore_checkpoint."""
+    import json
+    import shutil
+    import util
+    B = 3
+    opt = make_opt(options, "bat_blender_VM", H=32, W=32, n_voxel_init=10 ** 3,
+                   extra=dict(nerf=dict(n_rays=60)))
+    opt.train_schedule.n_voxel_final, opt.train_schedule.upsample_iters = 16 ** 3, [2, 50]
+    opt.output_path = "/tmp/jt_golden_ckpt"
+    shutil.rmtree(opt.output_path, ignore_errors=True)
+    graph = build_graph(bat, camera, opt, B, seed=seed)
+    var = make_var(opt, B, seed=seed)
+    nerf = graph.nerf
+
+    class M:
+        pass
+    m = M()
+    m.graph = graph
+    m.train_data = list(range(B))
+    m.optim = nerf._get_optimizer(opt)
+    nerf.get_current_optimizer = lambda: m.optim
+
+    def register(o):
+        m.optim = o
+    nerf.register_new_optimizer = register
+    m.save_param_state = lambda: graph.save_param_state()
+    with torch.no_grad():
+        for p in nerf.tensorf.density_plane:
+            p.mul_(22.0)
+    rs = np.random.RandomState(seed)
+    for it in range(1, 5):  # iterations 1..4: the upsampling happens at update_schedule(opt, 2)
+        graph.it = it
+        nerf.progress.data.fill_(it / opt.max_iter)
+        m.optim.zero_grad()
+        np.random.seed(int(rs.randint(1 << 30)))
+        torch.manual_seed(int(rs.randint(1 << 30)))
+        v = graph.forward(opt, EasyDict(var), mode="train")
+        loss = graph.compute_loss(opt, v, mode="train")
+        (loss.render + float(opt.loss_weight.L1.init) * loss.L1).backward()
+        m.optim.step()
+        nerf.update_schedule(opt, it)
+    it_saved = 4
+    util.save_checkpoint(opt, m, ep=None, it=it_saved, latest=True)
+    ck = torch.load("{}/model.ckpt".format(opt.output_path), map_location="cpu", weights_only=False)
+    out = {}
+    for k, t in ck["graph"].items():
+        out["graph." + k] = t.detach().cpu().numpy()
+    mt = ck["manually_tracked_parameters"]
+    trk = {k: (v.tolist() if torch.is_tensor(v) else v) for k, v in mt["tensorf_reset_kwargs"].items()}
+    nrk = {k: (v.tolist() if torch.is_tensor(v) else v) for k, v in mt["nerf_reset_kwargs"].items()}
+    groups = []
+    for gi, g in enumerate(ck["optim"]["param_groups"]):
+        groups.append({k: v for k, v in g.items() if k != "params"} | {"params": list(g["params"])})
+    for pid, st in ck["optim"]["state"].items():
+        out["optim.state.%d.step" % pid] = np.float32(float(st["step"]))
+        out["optim.state.%d.exp_avg" % pid] = st["exp_avg"].numpy()
+        out["optim.state.%d.exp_avg_sq" % pid] = st["exp_avg_sq"].numpy()
+    # what the reference renders after restoring this file into a FRESH model (the path train_3d.py:95-103 takes)
+    opt2 = make_opt(options, "bat_blender_VM", H=32, W=32, n_voxel_init=10 ** 3,
+                    extra=dict(nerf=dict(n_rays=60)))
+    opt2.train_schedule.n_voxel_final, opt2.train_schedule.upsample_iters = 16 ** 3, [2, 50]
+    opt2.output_path = opt.output_path
+    graph2 = build_graph(bat, camera, opt2, B, seed=seed + 1)
+    m2 = M()
+    m2.graph = graph2
+    m2.train_data = list(range(B))
+    m2.load_param_state = lambda o, c: graph2.load_param_state(o, c)
+    _load = torch.load  # the reference targets torch 1.13, where torch.load unpickles arbitrary objects (its `opt`)
+    torch.load = lambda *a, **k: _load(*a, **{**k, "weights_only": False})
+    try:
+        util.restore_checkpoint(opt2, m2, load_name="{}/model.ckpt".format(opt.output_path))
+    finally:
+        torch.load = _load
+    graph2.eval()
+    with torch.no_grad():
+        pose = graph2.get_pose(opt2, EasyDict(var), mode="train")
+        ray_idx = torch.arange(0, opt2.H * opt2.W, 5)[:40]
+        ret = graph2.render(opt2, pose, intr_inv=var.intr_inv, ray_idx=ray_idx, mode="vis", intr=var.intr)
+    out["in.pose_gt"], out["in.intr"], out["in.intr_inv"] = var.pose.numpy(), var.intr.numpy(), var.intr_inv.numpy()
+    out["in.ray_idx"] = ray_idx.numpy()
+    out["out.rgb"], out["out.depth"], out["out.opacity"] = (ret[k].numpy() for k in ("rgb", "depth", "opacity"))
+    out["out.current_pose"] = pose.numpy()
+    meta = dict(iter=it_saved, epoch=None, tensorf_reset_kwargs=trk, nerf_reset_kwargs=nrk, optim_param_groups=groups,
+                gridSize=graph2.nerf.tensorf.gridSize.tolist(), n_samples=int(graph2.nerf.n_samples), H=opt.H, W=opt.W,
+                n_views=B, progress=float(graph2.nerf.progress),
+                overrides=dict(image_size=[32, 32], n_voxel_init=10 ** 3, n_voxel_final=16 ** 3, upsample_iters=[2, 50],
+                               n_rays=60))
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(out_path, **out)
+    print("wrote", out_path, "grid", meta["gridSize"], "lr", [g["lr"] for g in groups])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden"))
@@ -635,6 +731,7 @@ def main():
     torch.set_num_threads(4)
 
     known_answers(camera, kernels, bat, os.path.join(outdir, "known_answers.npz"))
+    ckpt_case(bat, camera, options, os.path.join(outdir, "reference_checkpoint.npz"))
 
     # ---- Blender (bat_blender_VM): cubic grid, MLP_Fea, softplus, white bg -----------------------
     B = 3

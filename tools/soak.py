@@ -38,7 +38,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         loss = model.train_iteration(opt, Opt(dict(views)))
-        model.after_iteration(opt, it)
+        model.after_iteration(opt)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) * 1e3
         tf = model.graph.nerf.tensorf
