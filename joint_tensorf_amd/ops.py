@@ -129,6 +129,29 @@ def _zeros_flat(groups, with_flat=False):
 _DP = {"world": 1, "group": None, "force": False}
 
 
+class DpReducer:
+    """The gradient exchange of one backward: all gradient tensors of the backward live in ONE flat buffer, group after
+    group (density planes, density lines, appearance planes, appearance lines, basis + MLP; `spans[k]` = the [start,
+    end) float range of group k, ops._zeros_flat), so a run of consecutive groups is one SUM-all-reduce on a slice of
+    it.  The collectives are asynchronous (RCCL's own stream); `wait()` makes the current stream wait for them -- the
+    host never blocks."""
+
+    def __init__(self, gflat, spans, group=None):
+        self.gflat, self.spans, self.group, self.works = gflat, spans, group, []
+
+    def reduce(self, first, last):
+        """all-reduce groups first..last (inclusive) as one collective"""
+        import torch.distributed as dist
+        lo, hi = self.spans[first][0], self.spans[last][1]
+        _DP.setdefault("span_elems", {})[(lo, hi)] = hi - lo  # sizes of the collectives (bench.py times them alone)
+        self.works.append(dist.all_reduce(self.gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
 def set_data_parallel(world, group=None, force=False):
     """force=True issues the collectives even for a group of one rank (exercises the RCCL path on a one-GPU box)."""
     _DP["world"], _DP["group"], _DP["force"] = int(world), group, bool(force)
@@ -430,16 +453,12 @@ class RenderRays(torch.autograd.Function):
         g_xyz = torch.empty(cap_alloc, 3, **f32)
         join = None
         g_mlp = [None] * 7
-        dp_works = []
         dp_on = _DP["world"] > 1 or _DP["force"]
         dp = dp_on and fused_mlp_zero
         if dp_on and not dp and (want_fac or want_mlp):
             raise RuntimeError("data-parallel render backward needs the fused path with all scene gradients wanted")
 
-        def dp_reduce(lo, hi):
-            import torch.distributed as dist
-            _DP.setdefault("span_elems", {})[(lo, hi)] = hi - lo  # sizes of the collectives (bench.py times them)
-            dp_works.append(dist.all_reduce(gflat[lo:hi], op=dist.ReduceOp.SUM, group=_DP["group"], async_op=True))
+        reducer = DpReducer(gflat, spans, _DP["group"]) if dp else None
         if cfg.shade_impl == "torch":
             g_mlp = [torch.zeros_like(t) for t in mlp_t]
             if n > 0:
@@ -498,7 +517,7 @@ class RenderRays(torch.autograd.Function):
                                         ptr(g_rgb_s), gfac, gm, ptr(g_xyz), cap, ptr(ws), nbytes, 0, st, *h_aux),
                   "jt_shade_backward")
             if dp:
-                dp_reduce(spans[2][0], spans[3][1])  # appearance planes + lines are final
+                reducer.reduce(2, 3)  # appearance planes + lines are final
         g_o = torch.empty(R, 3, **f32)
         g_d = torch.empty(R, 3, **f32)
         mws_bytes = lib.jt_march_backward_workspace_bytes(scene, R)
@@ -508,13 +527,12 @@ class RenderRays(torch.autograd.Function):
                                     ptr(cmask), ptr(g_rgb), ptr(g_op), ptr(g_xyz), gfac, ptr(g_o), ptr(g_d),
                                     ptr(mws), mws_bytes, st), "jt_march_backward")
         if dp:
-            dp_reduce(spans[0][0], spans[1][1])  # density planes + lines are final
+            reducer.reduce(0, 1)  # density planes + lines are final
         if join is not None:
             torch.cuda.current_stream().wait_event(join)  # weight gradients done before anyone reads them
         if dp:
-            dp_reduce(spans[4][0], spans[4][1])  # basis + MLP
-            for w in dp_works:
-                w.wait()  # stream-level: whoever consumes the gradients next runs behind the collectives
+            reducer.reduce(4, 4)  # basis + MLP
+            reducer.wait()  # stream-level: whoever consumes the gradients next runs behind the collectives
         if ctx.reg is not None and g_reg is not None and want_fac:
             # the regularisers' gradient joins the render gradient in place (after the collectives: it is the same
             # on every rank and is not part of the exchange)

@@ -55,3 +55,80 @@ def test_allreduce_gradients_world2():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def _worker_flat(rank, world, port, ret):
+    """The exchange the renderer's backward really issues (ops.DpReducer over the one flat gradient buffer of
+    ops._zeros_flat: three collectives -- appearance factors, density factors, basis + MLP -- then the regulariser
+    gradient added on every rank), with a CPU stand-in for the kernels that fill the buffer."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from joint_tensorf_amd import ops
+    # the tensors of a (small, non-cubic) scene in storage layout: planes [H,W,C], lines [L,C], basis + MLP; odd sizes
+    # so that the 16-byte rounding of the offsets inside the flat buffer is exercised
+    dp = [torch.zeros(7, 9, 16), torch.zeros(5, 9, 16), torch.zeros(5, 7, 16)]
+    dl = [torch.zeros(5, 16), torch.zeros(7, 16), torch.zeros(9, 16)]
+    ap = [torch.zeros(7, 9, 20), torch.zeros(5, 9, 20), torch.zeros(5, 7, 20)]
+    al = [torch.zeros(5, 20), torch.zeros(7, 20), torch.zeros(9, 20)]
+    mlp = [torch.zeros(20, 60), torch.zeros(32, 100), torch.zeros(32), torch.zeros(32, 32), torch.zeros(32),
+           torch.zeros(3, 44), torch.zeros(3)]
+    groups = [dp, dl, ap, al, mlp]
+    views, gflat, spans = ops._zeros_flat(groups, with_flat=True)
+    assert len(spans) == 5 and spans[0][0] == 0 and all(spans[k][1] == spans[k + 1][0] for k in range(4))
+    assert all(o % 4 == 0 for s_ in spans for o in s_) and spans[4][1] == gflat.numel()
+
+    def fill(r):  # what rank r's render backward leaves in the views
+        g = torch.Generator().manual_seed(7 + r)
+        return [[torch.randn(t.shape, generator=g) for t in grp] for grp in groups]
+    mine = fill(rank)
+    for vg, mg in zip(views, mine):
+        for v, m_ in zip(vg, mg):
+            v.copy_(m_)
+    red = ops.DpReducer(gflat, spans)
+    red.reduce(2, 3)   # appearance planes + lines
+    red.reduce(0, 1)   # density planes + lines
+    red.reduce(4, 4)   # basis + MLP
+    red.wait()
+    reg = [torch.full(t.shape, 0.25) for t in dp]  # the regulariser gradient: same on every rank, added AFTER the exchange
+    for v, r_ in zip(views[0], reg):
+        v.add_(r_)
+    every = [fill(r) for r in range(world)]
+    ok = True
+    for gi, vg in enumerate(views):
+        for ti, v in enumerate(vg):
+            exp = sum(every[r][gi][ti] for r in range(world))
+            if gi == 0:
+                exp = exp + reg[ti]
+            ok = ok and torch.allclose(v, exp, atol=1e-6)
+    # padding floats between tensors stay zero (they are part of the collectives)
+    used = torch.zeros(gflat.numel(), dtype=torch.bool)
+    for vg in views:
+        for v in vg:
+            off = (v.data_ptr() - gflat.data_ptr()) // 4
+            used[off:off + v.numel()] = True
+    ok = ok and bool((gflat[~used] == 0).all())
+    ret[rank] = bool(ok) and sorted(ops._DP["span_elems"].values()) == sorted(
+        [spans[3][1] - spans[2][0], spans[1][1] - spans[0][0], spans[4][1] - spans[4][0]])
+    dist.destroy_process_group()
+
+
+def test_flat_buffer_exchange_world2():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_flat, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_rank_lattice_offsets_keep_the_ray_count_and_differ():
+    """dist.rank_lattice_offset: every rank renders the same number of lattice points as the shared draw would, on
+    other pixels (the rank-sharding statement of SURVEY 8(e))."""
+    from joint_tensorf_amd.dist import rank_lattice_offset
+    for step, extent in ((90, 400), (45, 400), (16, 400), (17, 640)):
+        for o in range(step):
+            n = len(range(o, extent, step))
+            offs = [rank_lattice_offset(o, step, extent, r, 8) for r in range(8)]
+            assert all(len(range(x, extent, step)) == n for x in offs) and offs[0] == o
+            cls = [x for x in range(step) if len(range(x, extent, step)) == n]
+            assert len(set(offs)) == min(8, len(cls))
