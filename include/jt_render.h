@@ -293,6 +293,19 @@ int jt_render_loss_backward(const float* rgb, const float* image, const int64_t*
                             int n_views, int rays_per_view, int n_pixels, float edge_factor, float non_edge_factor,
                             const float* acc4, const float* g_loss, float* g_rgb, void* stream);
 
+/* Non-finite guard without a host sync: ORs items[k].bit into *status_word (device memory, caller-owned, cleared by
+ * the caller) for every item whose `data[0..n)` holds a NaN or an infinity; one launch for up to JT_FINITE_MAX
+ * tensors.  Stands in for the per-iteration `pose.isnan().any()` / `assert not torch.isnan(loss[key])` host reads of
+ * model/tensorf.py:43-44,147-151; the host reads the word when it wants to. */
+#define JT_FINITE_MAX 8
+typedef struct JtFiniteItem {
+  const float* data;
+  int64_t n;
+  int32_t bit;
+  int32_t pad_;
+} JtFiniteItem;
+int jt_finite_check(const JtFiniteItem* items, int n_items, int32_t* status_word, void* stream);
+
 /* The weighted sum of Model.summarize_loss (model/tensorf.py:31-47) over the photometric term and the three
  * regularisers, one launch each way:  total = w_render render[0] + w_l1 reg3[0] + w_tv_density reg3[1] +
  * w_tv_color reg3[2]  (reg3 = the out3 of jt_reg_losses_forward; a term with weight 0 is left out, as the reference

@@ -55,6 +55,10 @@ class JtBlurItem(ctypes.Structure):
                 ("n_taps", ctypes.c_int32)]
 
 
+class JtFiniteItem(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("n", ctypes.c_int64), ("bit", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
 class JtAdamItem(ctypes.Structure):
     _fields_ = [("p", ctypes.c_void_p), ("g", ctypes.c_void_p), ("m", ctypes.c_void_p), ("v", ctypes.c_void_p),
                 ("n", ctypes.c_int64), ("lr", ctypes.c_float), ("bias_correction1", ctypes.c_float),
@@ -86,6 +90,7 @@ SIGNATURES = {
     "jt_march_backward_workspace_bytes": (ctypes.c_size_t, [SP, I]),
     "jt_shade_workspace_bytes": (ctypes.c_size_t, [SP, I]),
     "jt_shade_record_layout": (I, [SP, P]),
+    "jt_finite_check": (I, [P, I, P, P]),
     "jt_shade_chunk_entries": (I, []),
     "jt_shade_set_chunk_log2": (I, [I]),
     "jt_render_loss_forward": (I, [P, P, P, P, I, I, I, F, F, P, P, P]),

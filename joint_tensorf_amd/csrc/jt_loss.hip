@@ -3,6 +3,8 @@
 // nanmean of squared error (model/base.py:259-261): the GT pixel gather `image[:, ray_idx]`, the hard
 // edge-mask split  edge_factor * MSE(rgb*m, img*m) + non_edge_factor * MSE(rgb*(1-m), img*(1-m))  and the
 // plain MSE; the stock-op version is ~30 tiny launches forward + backward.
+#include <algorithm>
+
 #include "jt_common.h"
 
 namespace jt {
@@ -146,6 +148,51 @@ extern "C" int jt_render_loss_backward(const float* rgb, const float* image, con
   int blocks = (int)min((n + 255) / 256, 512L);
   hipLaunchKernelGGL(k_render_loss_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rgb, image, ray_idx,
                      edge_mask, n_views, rays_per_view, n_pixels, acc4, edge_factor, non_edge_factor, g_loss, g_rgb);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
+// ---- device-side non-finite guard ------------------------------------------------------------------------------
+// The reference raises on a NaN pose (model/tensorf.py:147-151) and asserts finite loss terms (model/tensorf.py:43-44)
+// with one device->host read each per iteration.  Here ONE launch per iteration ORs a bit per checked tensor into a
+// status word that stays on the device; the host reads the word when it chooses to (every opt.freq.scalar iterations).
+struct FiniteArgs {
+  const float* p[JT_FINITE_MAX];
+  long n[JT_FINITE_MAX];
+  int bit[JT_FINITE_MAX];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void k_finite_check(FiniteArgs A, int32_t* __restrict__ flag) {
+  int bits = 0;
+  for (int k = 0; k < A.count; ++k) {
+    const float* p = A.p[k];
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < A.n[k]; i += (long)gridDim.x * blockDim.x) {
+      const float v = p[i];
+      if (!(fabsf(v) <= 3.402823466e38f)) bits |= A.bit[k];  // NaN or +-Inf
+    }
+  }
+  if (__any(bits != 0)) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) bits |= __shfl_xor(bits, o);
+    if ((threadIdx.x & 63) == 0) atomicOr(flag, bits);
+  }
+}
+
+extern "C" int jt_finite_check(const JtFiniteItem* items, int n_items, int32_t* status_word, void* stream) {
+  if (!items || !status_word || n_items < 1 || n_items > JT_FINITE_MAX) return JT_ERR_ARG;
+  FiniteArgs A;
+  long total = 0;
+  for (int k = 0; k < n_items; ++k) {
+    if (!items[k].data || items[k].n < 0) return JT_ERR_ARG;
+    A.p[k] = items[k].data;
+    A.n[k] = items[k].n;
+    A.bit[k] = items[k].bit;
+    total = std::max(total, (long)items[k].n);
+  }
+  A.count = n_items;
+  const int blocks = (int)std::min<long>((total + 255) / 256, 256);
+  hipLaunchKernelGGL(k_finite_check, dim3(std::max(blocks, 1)), dim3(256), 0, (hipStream_t)stream, A, status_word);
   JT_LAUNCH_CHECK();
   return JT_OK;
 }

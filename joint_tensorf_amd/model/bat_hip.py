@@ -494,6 +494,10 @@ class Model(torch.nn.Module):
         fused = self._summarize_fused(opt, loss, render_scale)
         if fused is not None:
             loss.update(all=fused)
+            if not (_has(opt, "finite_checks") and not opt.finite_checks):
+                # device-side guard: NaN pose / render / loss leave a bit in the status word (read by check_finite)
+                ops.finite_check([(var.get("current_pose"), ops.FINITE_POSE), (var.get("rgb"), ops.FINITE_RENDER),
+                                  (fused, ops.FINITE_LOSS)])
             return loss
         for key in loss:
             assert key in opt.loss_weight, f"loss {key} not in opt.loss_weight"
@@ -689,6 +693,8 @@ class Model(torch.nn.Module):
                 for k in ("image", "pose", "intr_inv", "idx", "intr"):
                     var[k] = var[k][view_idx]
             loss = self.train_iteration(opt, var)
+            if _has(opt, "finite_checks_every_iteration") and opt.finite_checks_every_iteration:
+                self.check_finite(opt, loss)
             self.after_iteration(opt)  # self.it is it + 1 here, as in the reference
             if f_scalar and self.it % f_scalar == 0:
                 self.check_finite(opt, loss)  # one host read per opt.freq.scalar iterations (model/tensorf.py:43-44)
@@ -697,22 +703,22 @@ class Model(torch.nn.Module):
                 self.validate(opt, self.it)
             if f_ckpt and self.it % f_ckpt == 0 and _has(opt, "output_path"):
                 self.save_checkpoint(opt, ep=None, it=self.it)
+        self.check_finite(opt, loss)
         if _has(opt, "output_path") and opt.output_path:
             self.save_checkpoint(opt, ep=None, it=self.it, latest=True)
         return loss
 
-    def check_finite(self, opt, loss):
-        """The reference asserts finite loss terms every iteration (model/tensorf.py:43-44) and raises on NaN poses
-        (model/tensorf.py:147-151); each is a device->host read.  Here both are checked through one device-side flag
-        word (Graph.nonfinite: set by the loss / pose kernels' outputs) read when the caller asks."""
-        bad = []
-        for k, v in loss.items():
-            if torch.is_tensor(v) and not bool(torch.isfinite(v.detach()).all()):
-                bad.append(k)
-        if not bool(torch.isfinite(self.graph.se3_refine.weight.detach()).all()):
-            bad.append("se3_refine")
-        if bad:
-            raise FloatingPointError("non-finite values in: %s (iteration %d)" % (", ".join(bad), self.it))
+    def check_finite(self, opt, loss=None):
+        """The reference raises on a NaN pose (model/tensorf.py:147-151) and asserts finite loss terms
+        (model/tensorf.py:43-44) every iteration, each a device->host read.  Here every training iteration leaves its
+        verdict in a device-side status word (ops.finite_check inside summarize_loss: pose, rendered colours, total loss);
+        this is the one host read, taken every opt.freq.scalar iterations by train() or whenever a caller asks (set
+        opt.finite_checks_every_iteration to get the reference's timing).  Raises FloatingPointError naming the culprit."""
+        bits = ops.read_status(opt.device)
+        if bits:
+            what = [n for b, n in ((ops.FINITE_POSE, "camera pose (se3_refine / pose composition)"),
+                                   (ops.FINITE_RENDER, "rendered colours"), (ops.FINITE_LOSS, "loss")) if bits & b]
+            raise FloatingPointError("non-finite values since the last check in: %s (iteration %d)" % ("; ".join(what), self.it))
 
     def generate_videos_synthesis(self, opt, eps=1e-10, it=None):
         """model/nerf.py:574-640 writes novel-view videos through ffmpeg / wandb: reference engine, out of scope.  Kept

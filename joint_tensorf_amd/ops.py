@@ -35,6 +35,41 @@ def poke_words(dst, words, offset=0):
     check(lib.jt_poke(ctypes.c_void_p(dst.data_ptr() + 4 * offset), arr, n, _stream()), "jt_poke")
 
 
+# ---- non-finite guard (model/tensorf.py:43-44,147-151 without the per-iteration host reads) ----------------------
+FINITE_POSE, FINITE_RENDER, FINITE_LOSS = 1, 2, 4
+_STATUS = {}
+
+
+def status_word(dev):
+    """the device's status word (int32[1], zero until a check finds a NaN / infinity)"""
+    d = torch.device(dev)
+    key = d.index if d.index is not None else torch.cuda.current_device()  # "cuda" and "cuda:0" are one device
+    if key not in _STATUS:
+        _STATUS[key] = torch.zeros(1, device=torch.device("cuda", key), dtype=torch.int32)
+    return _STATUS[key]
+
+
+def finite_check(tensors_and_bits):
+    """one launch: OR `bit` into the device's status word for every (tensor, bit) that holds a non-finite value"""
+    items = [(t.detach(), b) for t, b in tensors_and_bits if t is not None and t.numel() > 0]
+    if not items:
+        return
+    keep = [t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float() for t, _ in items]
+    arr = (_lib.JtFiniteItem * len(items))()
+    for k, (t, (_, b)) in enumerate(zip(keep, items)):
+        arr[k].data, arr[k].n, arr[k].bit = ptr(t), t.numel(), int(b)
+    check(lib.jt_finite_check(arr, len(items), ptr(status_word(keep[0].device)), _stream()), "jt_finite_check")
+
+
+def read_status(dev, clear=True):
+    """host read of the status word (synchronises the stream)"""
+    w = status_word(dev)
+    v = int(w.item())
+    if v and clear:
+        w.zero_()
+    return v
+
+
 def poke_floats(dst, values, offset=0):
     n = len(values)
     assert dst.dtype == torch.float32 and dst.is_contiguous() and offset + n <= dst.numel()
