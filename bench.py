@@ -45,7 +45,6 @@ def parse():
                     help="random = the reference's random-init factors (every in-box sample is shaded: the worst case "
                          "and the default); blobs = a few opaque Gaussian blobs baked into the density factors "
                          "(SURVEY 8(d) structured scene: a few per cent of the samples shaded, like a trained field)")
-    ap.add_argument("--shade-impl", default="mfma", choices=["mfma", "torch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--probe-only", action="store_true",
@@ -357,7 +356,7 @@ def main():
 
     torch.manual_seed(0)
     np.random.seed(1234)  # host draws (blur scale) identical on every rank
-    opt = make_options(args.config, device=dev, shade_impl=args.shade_impl)
+    opt = make_options(args.config, device=dev)
     if args.n_voxel_final:
         opt.train_schedule.n_voxel_final = args.n_voxel_final
     stage, it0 = stage_setup(opt, args.stage)
@@ -401,7 +400,7 @@ def main():
     # measures the same 4.8 ms.  Data-parallel runs issue their collectives from the eager backward.
     stepper = None
     if world == 1 and not FORCE_DIST and os.environ.get("JT_GRAPH", "0") == "1" \
-            and os.environ.get("JT_BENCH_CHECKSUM") != "1" and args.shade_impl == "mfma":
+            and os.environ.get("JT_BENCH_CHECKSUM") != "1":
         from joint_tensorf_amd.graphed import GraphedTrainStep
         stepper = GraphedTrainStep(model, min_repeats=0)
     use_graph = [False]
@@ -560,7 +559,7 @@ def main():
                 "rays_per_iter_per_gpu": rays_all / args.steps / world,
                 "samples_per_ray": S,
                 "Msamples_per_s": rays_all * S / dt / 1e6,
-                "shade_impl": args.shade_impl,
+                "shade_impl": "mfma",
                 "launch": ("hipGraph replay (%(replayed)d replayed / %(captured)d captured / %(eager)d eager steps)"
                            % stepper.stats) if stepper is not None else "eager",
                 "abi_calls_per_step": n_calls[0] or None,

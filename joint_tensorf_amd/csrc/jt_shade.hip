@@ -1185,8 +1185,9 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   float* slabs = ws + W::rec_floats(cap);
   const size_t cstride = W::slab_floats_per_chunk();
   const int nb = kWgradBlocks;
-  const char* abl_env = getenv("JT_ABLATE");  // profiling only: 1 = no scatter, 2 = no records, 4 = no wgrad
-  const int ablate = (abl_env ? atoi(abl_env) : 0) | ((flags & JT_SHADE_SKIP_WGRAD) ? 4 : 0) |
+  // profiling knob, read ONCE per process: 1 = no scatter, 2 = no gradient records, 4 = no weight-gradient GEMMs
+  static const int abl_env = [] { const char* e = getenv("JT_ABLATE"); return e ? atoi(e) : 0; }();
+  const int ablate = abl_env | ((flags & JT_SHADE_SKIP_WGRAD) ? 4 : 0) |
                      ((flags & kNoGradRecords) ? 2 : 0);
   constexpr int NT3 = W::NT3, NT1 = W::NT1, NTB = W::NTB;
   constexpr int XF1 = (C::KIND == JT_MLP_FEA) ? 1 : 2;

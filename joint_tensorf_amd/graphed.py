@@ -98,7 +98,7 @@ class GraphedEvalRender:
 
 
 class GraphedTrainStep:
-    def __init__(self, model, min_repeats=2, max_graphs=24):
+    def __init__(self, model, min_repeats=2, max_graphs=64):
         self.model = model
         self.min_repeats = int(min_repeats)
         self.max_graphs = int(max_graphs)
@@ -179,7 +179,7 @@ class GraphedTrainStep:
     def train_iteration(self, opt, var, force_eager=False):
         """Drop-in for Model.train_iteration (same state transitions, same host draws)."""
         m, g = self.model, self.model.graph
-        if force_eager or not self._eligible(opt) or self._blur_scheduled(opt):
+        if force_eager or not self._eligible(opt):
             self.stats["eager"] += 1
             return self._eager(opt, var)
         g.it = m.it
@@ -193,7 +193,9 @@ class GraphedTrainStep:
         # graphs of all lattice shapes of the current signature exist
         base = self._signature(opt, var, 0, 0)
         shapes = self._lattice_shapes(int(opt.H), int(opt.W), step)
-        complete = all((base[:6] + s + base[8:]) in self.cache for s in shapes)
+        complete = False  # (whether the blur is on is only known after the draw: always keep the state)
+        if not self._blur_scheduled(opt):
+            complete = all((base[:6] + s + base[8:] + (None,)) in self.cache for s in shapes)
         np_state = None if complete else np.random.get_state()
         ox, oy = np.random.randint(step), np.random.randint(step)
         if g.lattice_rank is not None:
@@ -201,9 +203,11 @@ class GraphedTrainStep:
             ox = rank_lattice_offset(ox, step, opt.W, *g.lattice_rank)
             oy = rank_lattice_offset(oy, step, opt.H, *g.lattice_rank)
         blur = g.resolve_blur(opt, "train")  # consumes the blur-scale draw exactly like the eager path
-        assert blur[2] is None  # _blur_scheduled() said so
+        # factor blur on: same graph for every (schedule value, random scale) -- the two tap vectors are static device
+        # memory, rewritten below in front of the replay
+        blur_key = None if blur[2] is None else (blur[2], int(blur[3]))
         nx, ny = len(range(ox, opt.W, step)), len(range(oy, opt.H, step))
-        sig = base[:6] + (ny, nx) + base[8:]
+        sig = base[:6] + (ny, nx) + base[8:] + (blur_key,)
         e = self.cache.get(sig)
         if e is None:
             if len(self.seen) > 4096:
@@ -219,7 +223,7 @@ class GraphedTrainStep:
                 print("graphed: capture #%d at it %d, differs from the nearest graph in fields %s"
                       % (self.stats["captured"] + 1, m.it, [i for i, (a, b) in enumerate(zip(near, sig)) if a != b]),
                       flush=True)
-            e = self._capture(opt, var, sig, ny, nx, step)
+            e = self._capture(opt, var, sig, ny, nx, step, blur)
             if (id(m.optim), ops.workspace_generation()) != self.epoch or e is None:
                 # capture is not allowed to move anything; if it did, start over on the eager path
                 self._drop_all()
@@ -233,6 +237,8 @@ class GraphedTrainStep:
         # ---- replay ------------------------------------------------------------------------------------------
         e.last_used = self.stats["replayed"]
         ops.poke_words(e.off, [ox, oy])
+        if blur_key is not None:
+            self._poke_taps(opt, blur)
         m.optim.prepare_step(e.stepped)
         e.graph.replay()
         self.stats["replayed"] += 1
@@ -257,10 +263,32 @@ class GraphedTrainStep:
         return loss
 
     # ------------------------------------------------------------------------------------------------------
-    def _capture(self, opt, var, sig, ny, nx, step):
+    def _taps_buffer(self, opt, ksize):
+        """static [2, K+1] device tensor: row 0 the density taps, row 1 the colour taps of the iteration"""
+        buf = self.__dict__.setdefault("_taps", {})
+        n = int(ksize) + (1 if int(ksize) % 2 == 0 else 0)
+        if n not in buf:
+            buf[n] = torch.zeros(2, n, device=opt.device, dtype=torch.float32)
+        return buf[n]
+
+    def _poke_taps(self, opt, blur):
+        pd, pc, mode, ksize = blur
+        tf = self.model.graph.nerf.tensorf
+        td = tf.get_kernel(opt, mode, pd, ksize, device="cpu")
+        tc = tf.get_kernel(opt, mode, pc, ksize, device="cpu")
+        buf = self._taps_buffer(opt, ksize)
+        assert td.numel() == buf.shape[1] == tc.numel() and 2 * td.numel() <= 256
+        ops.poke_floats(buf.view(-1), td.tolist() + tc.tolist())
+        return buf
+
+    def _capture(self, opt, var, sig, ny, nx, step, blur=(None, None, None, None)):
         m, g = self.model, self.model.graph
         dev = opt.device
         e = _Entry()
+        tf = g.nerf.tensorf
+        if blur[2] is not None:
+            buf = self._poke_taps(opt, blur)
+            tf.taps_static = (buf[0], buf[1])
         e.off = torch.zeros(2, device=dev, dtype=torch.int32)
         # allocated OUTSIDE the capture: the entry must keep them alive for as long as the graph exists
         e.base_x = base_x = torch.arange(nx, device=dev) * step
@@ -306,6 +334,7 @@ class GraphedTrainStep:
         finally:
             ops.USE_AUX_STREAM = aux_was
             g.lattice_override = None
+            tf.taps_static = None
             np.random.set_state(np_state)
         if self.pool is None:
             self.pool = e.graph.pool()

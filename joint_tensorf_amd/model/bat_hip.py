@@ -99,8 +99,7 @@ class NeRF(torch.nn.Module):
                            fea2denseAct=arch.feature_to_density_activation, dtype=torch.float32,
                            volume_init_scale=arch.tensorf.volume_init_scale,
                            rayMarch_weight_thres=arch.tensorf.rayMarch_weight_thres,
-                           volume_init_bias=arch.tensorf.volume_init_bias,
-                           shade_impl=opt.get("shade_impl", "mfma"))
+                           volume_init_bias=arch.tensorf.volume_init_bias)
 
     def _find_resolution(self, opt, n_voxels):
         lo, hi = self.bbox[0], self.bbox[1]
@@ -544,12 +543,18 @@ class Model(torch.nn.Module):
         # (reproduced quirk, SURVEY App. B-15: base.train_iteration zeroes the scene gradients at the top of EVERY
         #  iteration, model/base.py:118, so opt.optim.grad_accum_iter > 1 only thins out the optimizer steps)
         self.optim.zero_grad()
-        var = g.forward(opt, var, mode="train")
-        loss = g.compute_loss(opt, var, mode="train")
-        loss = self.summarize_loss(opt, var, loss)
-        loss.all.backward()
+        ops.PROFILING = bool(_has(opt, "profiling") and opt.profiling)  # roctx ranges named as model/base.py:119-153
+        with ops.prof_range("graph.forward"):
+            var = g.forward(opt, var, mode="train")
+        with ops.prof_range("graph.compute_loss"):
+            loss = g.compute_loss(opt, var, mode="train")
+        with ops.prof_range("summarize_loss"):
+            loss = self.summarize_loss(opt, var, loss)
+        with ops.prof_range("loss.all.backward()"):
+            loss.all.backward()
         if (not _has(opt.optim, "grad_accum_iter")) or (self.it % opt.optim.grad_accum_iter) == 0:
-            self.optim.step()
+            with ops.prof_range("optim.step"):
+                self.optim.step()
             self.optim.zero_grad()
         self.it += 1
         if (not _has(opt.optim, "pose_grad_accum_iter")) or (self.it % opt.optim.pose_grad_accum_iter) == 0:

@@ -79,6 +79,32 @@ def poke_floats(dst, values, offset=0):
 
 
 KEEP_INTERMEDIATES = False
+# roctx ranges with the reference's record_function names (model/base.py:119-153, tensorBase.py:774) when
+# opt.profiling is set (Model.train_iteration switches this on): they show up in rocprofv3 --marker-trace output.
+PROFILING = False
+
+
+class prof_range:
+    """`with prof_range("graph.forward"):` -- a roctx range (torch.cuda.nvtx is roctx on ROCm) while PROFILING, else nothing"""
+
+    def __init__(self, name):
+        self.name, self.on = name, False
+
+    def __enter__(self):
+        if PROFILING:
+            try:
+                torch.cuda.nvtx.range_push(self.name)
+                self.on = True
+            except Exception:
+                self.on = False
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            torch.cuda.nvtx.range_pop()
+        return False
+
+
 # In-step kernel timing (bench.py's roofline): while STEP_TIMERS is a list, every training render appends
 # (kind, start event, end event, shade_offset tensor) for its k_shade_fwd<train> and k_shade_bwd launches -- HIP events on
 # the launch stream, read by the caller after its own synchronisation (no sync is added here).
@@ -226,7 +252,7 @@ class RenderCfg:
     def __init__(self, aabb, plane_hw, line_len, n_comp_density, n_comp_app, step_size, near_far,
                  distance_scale, density_shift, density_act, weight_thres, n_samples, ndc, white_bg,
                  app_dim, mlp_kind, mlp_hidden, view_pe, fea_pe, view_pe_progress=1.0, fea_pe_progress=1.0,
-                 shade_impl="mfma", alpha_mask=None):
+                 alpha_mask=None):
         self.aabb = [float(v) for v in aabb]  # lo xyz, hi xyz
         self.plane_hw = [(int(h), int(w)) for h, w in plane_hw]
         self.line_len = [int(v) for v in line_len]
@@ -248,7 +274,6 @@ class RenderCfg:
         self.fea_pe = int(fea_pe)
         self.view_pe_progress = float(view_pe_progress)
         self.fea_pe_progress = float(fea_pe_progress)
-        self.shade_impl = shade_impl
         # (volume [z,y,x] float32 contiguous on the device, lo [3], inv [3]) or None; see AlphaGridMask
         self.alpha_mask = alpha_mask
 
@@ -304,37 +329,6 @@ def _mlp_struct(basis, w1, b1, w2, b2, w3, b3):
 
 
 # ----------------------------------------------------------------------------------------------
-# MLP in stock torch ops -- only used by shade_impl="torch" (staged cross-check path)
-# ----------------------------------------------------------------------------------------------
-def _pe(x, freqs, progress):
-    levels = torch.arange(freqs, device=x.device)
-    bands = (2 ** levels).to(x.dtype)
-    mask = (progress * freqs - levels).clamp(0.0, 1.0).to(x.dtype)
-    pts = x[..., None] * bands
-    pts = torch.cat([torch.sin(pts) * mask, torch.cos(pts) * mask], -1)
-    return pts.reshape(x.shape[:-1] + (freqs * 2 * x.shape[-1],))
-
-
-def _torch_shade(cfg, prod, vdir, basis, w1, b1, w2, b2, w3, b3):
-    feat = prod @ basis.t()
-    F = torch.nn.functional
-    if cfg.mlp_kind == _lib.JT_MLP_WEAKVIEW:
-        x = torch.cat([feat, _pe(feat, cfg.fea_pe, cfg.fea_pe_progress)], -1) if cfg.fea_pe > 0 else feat
-        h = F.relu(F.linear(x, w1, b1))
-        h = F.relu(F.linear(h, w2, b2))
-        mid = torch.cat([_pe(vdir, cfg.view_pe, cfg.view_pe_progress), h], -1) if cfg.view_pe > 0 else h
-        return torch.sigmoid(F.linear(mid, w3, b3))
-    x = [feat, vdir]
-    if cfg.fea_pe > 0:
-        x.append(_pe(feat, cfg.fea_pe, cfg.fea_pe_progress))
-    if cfg.view_pe > 0:
-        x.append(_pe(vdir, cfg.view_pe, cfg.view_pe_progress))
-    h = F.relu(F.linear(torch.cat(x, -1), w1, b1))
-    h = F.relu(F.linear(h, w2, b2))
-    return torch.sigmoid(F.linear(h, w3, b3))
-
-
-# ----------------------------------------------------------------------------------------------
 # the renderer
 # ----------------------------------------------------------------------------------------------
 class RenderRays(torch.autograd.Function):
@@ -374,11 +368,7 @@ class RenderRays(torch.autograd.Function):
         check(lib.jt_march_forward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals), R,
                                    ptr(sigma_feat), ptr(weight), ptr(tmin), ptr(count), ptr(offset), ptr(sidx),
                                    ptr(opacity), ptr(depth), st), "jt_march_forward")
-        if cfg.shade_impl == "torch":
-            n = int(offset[R].item())  # host sync: staged cross-check path only
-            cap = n
-        else:
-            n = cap = R * S  # worst case; kernels bound themselves by shade_offset[R] on the device
+        n = cap = R * S  # worst case; kernels bound themselves by shade_offset[R] on the device
         cap_alloc = max(cap, 1)
         eray = torch.empty(cap_alloc, device=dev, dtype=torch.int32)
         esmp = torch.empty(cap_alloc, device=dev, dtype=torch.int32)
@@ -386,38 +376,29 @@ class RenderRays(torch.autograd.Function):
         check(lib.jt_shade_list(scene, ptr(rays_d), R, ptr(offset), ptr(sidx), ptr(eray), ptr(esmp), ptr(vdir),
                                 cap, st), "jt_shade_list")
         rgb_s = torch.empty(cap_alloc, 3, **f32)
-        if cfg.shade_impl == "torch":
-            prod = torch.empty(cap_alloc, 3 * cfg.n_comp_app, **f32)
-            check(lib.jt_app_gather_forward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
-                                            ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(prod), cap, st),
-                  "jt_app_gather_forward")
-            if n > 0:
-                with torch.no_grad():
-                    rgb_s[:n] = _torch_shade(cfg, prod[:n], vdir[:n], *mlp_t)
-            ctx.prod = prod
+        mlp = _mlp_struct(*mlp_t)
+        if getattr(cfg, "grad_enabled", True) and any(ctx.needs_input_grad):
+            # training: the forward leaves the layer inputs of every shaded sample in the (persistent)
+            # workspace; the backward consumes them instead of gathering / evaluating the chain again
+            nbytes = lib.jt_shade_workspace_bytes(scene, cap)
+            ws = _workspace(dev, "shade", nbytes)
+            ctx.ws_ticket = _workspace_claim(dev, "shade")
+            # only the rays want a gradient (test-time pose optimisation): the light set of records
+            ctx.pose_only = not any(ctx.needs_input_grad[5:])
+            ws_args = (ptr(ws), nbytes, _lib.JT_SHADE_POSE_ONLY if ctx.pose_only else 0)
         else:
-            mlp = _mlp_struct(*mlp_t)
-            if getattr(cfg, "grad_enabled", True) and any(ctx.needs_input_grad):
-                # training: the forward leaves the layer inputs of every shaded sample in the (persistent)
-                # workspace; the backward consumes them instead of gathering / evaluating the chain again
-                nbytes = lib.jt_shade_workspace_bytes(scene, cap)
-                ws = _workspace(dev, "shade", nbytes)
-                ctx.ws_ticket = _workspace_claim(dev, "shade")
-                # only the rays want a gradient (test-time pose optimisation): the light set of records
-                ctx.pose_only = not any(ctx.needs_input_grad[5:])
-                ws_args = (ptr(ws), nbytes, _lib.JT_SHADE_POSE_ONLY if ctx.pose_only else 0)
-            else:
-                ws_args = (None, 0, 0)
-            timed = STEP_TIMERS is not None and ws_args[0] is not None
-            if timed:
-                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                t0.record()
+            ws_args = (None, 0, 0)
+        timed = STEP_TIMERS is not None and ws_args[0] is not None
+        if timed:
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+        with prof_range("compute appearance feature + Rendering"):  # tensorBase.py:774
             check(lib.jt_shade_forward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
                                        ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(rgb_s),
                                        cap, *ws_args, st), "jt_shade_forward")
-            if timed:
-                t1.record()
-                STEP_TIMERS.append(("fwd", t0, t1, offset))
+        if timed:
+            t1.record()
+            STEP_TIMERS.append(("fwd", t0, t1, offset))
         rgb = torch.empty(R, 3, **f32)
         cmask = torch.empty(R, device=dev, dtype=torch.int32)
         check(lib.jt_composite_forward(scene, R, ptr(offset), ptr(sidx), ptr(weight), ptr(rgb_s), ptr(opacity),
@@ -440,7 +421,7 @@ class RenderRays(torch.autograd.Function):
         reg3 = None
         ctx.reg = None
         flags = getattr(cfg, "reg_flags", None)
-        if flags is not None and cfg.shade_impl != "torch":
+        if flags is not None:
             hw = []
             for i in range(3):
                 H, W, _ = sdp[i].shape
@@ -475,7 +456,7 @@ class RenderRays(torch.autograd.Function):
         nig = ctx.needs_input_grad
         want_fac = any(nig[5:17])
         want_mlp = any(nig[17:24])
-        fused_mlp_zero = want_fac and want_mlp and cfg.shade_impl != "torch"
+        fused_mlp_zero = want_fac and want_mlp
         if want_fac:
             # gradient buffers (channel-last storage, zero-initialised: the kernels accumulate with atomics)
             if fused_mlp_zero:
@@ -494,65 +475,47 @@ class RenderRays(torch.autograd.Function):
             raise RuntimeError("data-parallel render backward needs the fused path with all scene gradients wanted")
 
         reducer = DpReducer(gflat, spans, _DP["group"]) if dp else None
-        if cfg.shade_impl == "torch":
-            g_mlp = [torch.zeros_like(t) for t in mlp_t]
-            if n > 0:
-                prod = ctx.prod[:n].detach().requires_grad_(True)
-                leaves = [t.detach().requires_grad_(True) for t in mlp_t]
-                with torch.enable_grad():
-                    out = _torch_shade(cfg, prod, vdir[:n], *leaves)
-                grads = torch.autograd.grad(out, [prod] + leaves, g_rgb_s[:n])
-                g_prod = grads[0].contiguous()
-                g_mlp = list(grads[1:])
-            else:
-                g_prod = torch.zeros(1, 3 * cfg.n_comp_app, **f32)
-            gfac_app = gfac if gfac is not None else _factors_struct(
-                None, None, [torch.zeros_like(t) for t in sap], [torch.zeros_like(t) for t in sal])
-            check(lib.jt_app_gather_backward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
-                                             ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(g_prod), gfac_app,
-                                             ptr(g_xyz), cap, st), "jt_app_gather_backward")
+        mlp = _mlp_struct(*mlp_t)
+        if want_mlp:
+            g_mlp = g_mlp_z if fused_mlp_zero else [torch.zeros_like(t) for t in mlp_t]
+            gm = _mlp_struct(*g_mlp)
         else:
-            mlp = _mlp_struct(*mlp_t)
-            if want_mlp:
-                g_mlp = g_mlp_z if fused_mlp_zero else [torch.zeros_like(t) for t in mlp_t]
-                gm = _mlp_struct(*g_mlp)
-            else:
-                gm = None
-            nbytes = lib.jt_shade_workspace_bytes(scene, cap)
-            ws = _workspace(dev, "shade", nbytes)
-            if _workspace_owner(dev, "shade") != ctx.ws_ticket:
-                # another render wrote the workspace since this one's forward (several forwards before one
-                # backward): put this call's records back
-                ctx.ws_ticket = _workspace_claim(dev, "shade")
-                check(lib.jt_shade_forward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
-                                           ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir),
-                                           ptr(torch.empty_like(rgb_s)), cap, ptr(ws), nbytes,
-                                           _lib.JT_SHADE_POSE_ONLY if ctx.pose_only else 0, st),
-                      "jt_shade_forward")
-            if USE_AUX_STREAM and want_mlp:
-                aux, ev_fork, ev_join = _aux_stream(dev)
-                # the weight-gradient GEMMs read mlp_t / ws and write g_mlp on the auxiliary stream
-                if not torch.cuda.is_current_stream_capturing():  # graph-pool memory is never recycled elsewhere
-                    for t in list(mlp_t) + g_mlp + [offset]:
-                        t.record_stream(aux)
-                h_aux = (ctypes.c_void_p(aux.cuda_stream), ctypes.c_void_p(ev_fork.cuda_event),
-                         ctypes.c_void_p(ev_join.cuda_event))
-                join = ev_join
-            else:
-                h_aux = (None, None, None)
-            if STEP_TIMERS is not None and not ctx.pose_only:
-                # the fork event doubles as the end mark of k_shade_bwd (jt_render.h); a fresh timing-enabled pair per call
-                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                t0.record()
-                t1.record()  # creates the handle; the library records it again behind k_shade_bwd
-                h_aux = (h_aux[0], ctypes.c_void_p(t1.cuda_event), h_aux[2])
-                STEP_TIMERS.append(("bwd", t0, t1, offset))
-            check(lib.jt_shade_backward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
-                                        ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(rgb_s),
-                                        ptr(g_rgb_s), gfac, gm, ptr(g_xyz), cap, ptr(ws), nbytes, 0, st, *h_aux),
-                  "jt_shade_backward")
-            if dp:
-                reducer.reduce(2, 3)  # appearance planes + lines are final
+            gm = None
+        nbytes = lib.jt_shade_workspace_bytes(scene, cap)
+        ws = _workspace(dev, "shade", nbytes)
+        if _workspace_owner(dev, "shade") != ctx.ws_ticket:
+            # another render wrote the workspace since this one's forward (several forwards before one
+            # backward): put this call's records back
+            ctx.ws_ticket = _workspace_claim(dev, "shade")
+            check(lib.jt_shade_forward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
+                                       ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir),
+                                       ptr(torch.empty_like(rgb_s)), cap, ptr(ws), nbytes,
+                                       _lib.JT_SHADE_POSE_ONLY if ctx.pose_only else 0, st),
+                  "jt_shade_forward")
+        if USE_AUX_STREAM and want_mlp:
+            aux, ev_fork, ev_join = _aux_stream(dev)
+            # the weight-gradient GEMMs read mlp_t / ws and write g_mlp on the auxiliary stream
+            if not torch.cuda.is_current_stream_capturing():  # graph-pool memory is never recycled elsewhere
+                for t in list(mlp_t) + g_mlp + [offset]:
+                    t.record_stream(aux)
+            h_aux = (ctypes.c_void_p(aux.cuda_stream), ctypes.c_void_p(ev_fork.cuda_event),
+                     ctypes.c_void_p(ev_join.cuda_event))
+            join = ev_join
+        else:
+            h_aux = (None, None, None)
+        if STEP_TIMERS is not None and not ctx.pose_only:
+            # the fork event doubles as the end mark of k_shade_bwd (jt_render.h); a fresh timing-enabled pair per call
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+            t1.record()  # creates the handle; the library records it again behind k_shade_bwd
+            h_aux = (h_aux[0], ctypes.c_void_p(t1.cuda_event), h_aux[2])
+            STEP_TIMERS.append(("bwd", t0, t1, offset))
+        check(lib.jt_shade_backward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
+                                    ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(rgb_s),
+                                    ptr(g_rgb_s), gfac, gm, ptr(g_xyz), cap, ptr(ws), nbytes, 0, st, *h_aux),
+              "jt_shade_backward")
+        if dp:
+            reducer.reduce(2, 3)  # appearance planes + lines are final
         g_o = torch.empty(R, 3, **f32)
         g_d = torch.empty(R, 3, **f32)
         mws_bytes = lib.jt_march_backward_workspace_bytes(scene, R)

@@ -90,7 +90,7 @@ class BAT_VMSplit(torch.nn.Module):
                  shadingMode="MLP_Fea", alphaMask=None, near_far=(2.0, 6.0), density_shift=-10,
                  alphaMask_thres=0.001, distance_scale=25, rayMarch_weight_thres=0.0001, pos_pe=6, view_pe=6,
                  fea_pe=6, featureC=128, step_ratio=2.0, fea2denseAct="softplus", dtype=torch.float32,
-                 volume_init_scale=0.1, volume_init_bias=0.1, shade_impl="mfma"):
+                 volume_init_scale=0.1, volume_init_bias=0.1):
         super().__init__()
         if dtype != torch.float32:
             raise NotImplementedError("the HIP path computes in fp32 (the reference yamls never set half_tensor)")
@@ -99,7 +99,6 @@ class BAT_VMSplit(torch.nn.Module):
         self.alphaMask = alphaMask
         self.matMode = [list(m) for m in MAT_MODE]
         self.vecMode = list(VEC_MODE)
-        self.shade_impl = shade_impl
         self.kernel_density = None
         self.kernel_color = None
         self.c2f_mode = None
@@ -366,14 +365,16 @@ class BAT_VMSplit(torch.nn.Module):
             return F.softplus(density_features + self.density_shift)
         return F.relu(density_features + self.density_shift)
 
-    def get_kernel(self, opt, c2f_mode, c2f_parameter, c2f_kernel_size=25):
-        """batBase.py:13-25: sigma in voxels = mean(gridSize/aabbSize) * parameter (fp32)."""
+    def get_kernel(self, opt, c2f_mode, c2f_parameter, c2f_kernel_size=25, device=None):
+        """batBase.py:13-25: sigma in voxels = mean(gridSize/aabbSize) * parameter (fp32).  device="cpu": the taps as
+        a host tensor (a replayed hipGraph reads them from static device memory, written by jt_poke)."""
+        device = self.device if device is None else device
         scale = torch.mean(self.gridSize.to(torch.float32) / (self.aabb[1] - self.aabb[0]))
         sig = (scale * c2f_parameter).to(torch.float32)
         if c2f_mode == "uniform-gaussian":
-            return ops.gaussian_taps(sig, c2f_kernel_size, self.device)
+            return ops.gaussian_taps(sig, c2f_kernel_size, device)
         if c2f_mode == "uniform-average":
-            return _average_kernel(float(sig), c2f_kernel_size).to(self.device)
+            return _average_kernel(float(sig), c2f_kernel_size).to(device)
         raise RuntimeError(f"invalid c2f_mode {c2f_mode}")
 
     def _check_flags(self, opt):
@@ -414,7 +415,11 @@ class BAT_VMSplit(torch.nn.Module):
             jitter = jitter.to(dev)
         # blur kernels (batBase.py:91-101)
         self.c2f_mode = c2f_mode
-        if c2f_mode is not None:
+        if c2f_mode is not None and getattr(self, "taps_static", None) is not None:
+            # hipGraph capture / replay (graphed.GraphedTrainStep): the taps live in static device memory that the
+            # stepper rewrites in front of every replay
+            self.kernel_density, self.kernel_color = self.taps_static
+        elif c2f_mode is not None:
             kd_mode = "uniform-gaussian" if is_test_optim else c2f_mode
             self.kernel_density = self.get_kernel(opt, kd_mode, c2f_parameter_density, c2f_kernel_size)
             self.kernel_color = self.get_kernel(opt, c2f_mode, c2f_parameter_color, c2f_kernel_size)
@@ -445,7 +450,7 @@ class BAT_VMSplit(torch.nn.Module):
             density_act=_lib.JT_ACT_SOFTPLUS if self.fea2denseAct == "softplus" else _lib.JT_ACT_RELU,
             weight_thres=self.rayMarch_weight_thres, n_samples=S, ndc=ndc_ray, white_bg=wb, app_dim=self.app_dim,
             mlp_kind=self.renderModule.kind, mlp_hidden=self.featureC, view_pe=self.view_pe, fea_pe=self.fea_pe,
-            view_pe_progress=view_pe_progress, fea_pe_progress=fea_pe_progress, shade_impl=self.shade_impl,
+            view_pe_progress=view_pe_progress, fea_pe_progress=fea_pe_progress,
             # empty-space samples are dropped only while the blur is off (batBase.py:76-82)
             alpha_mask=self.alphaMask.kernel_args() if (self.alphaMask is not None and c2f_mode is None
                                                          and c2f_parameter_density is None
@@ -453,7 +458,7 @@ class BAT_VMSplit(torch.nn.Module):
         # blur off and a backward to come: the regularisers ride on the render node (ops.RenderRays), so that their
         # gradient is added into the render gradient in place; _reg() then finds the values in its cache
         lw = opt.get("loss_weight", None) if isinstance(opt, dict) else getattr(opt, "loss_weight", None)
-        fuse_reg = (c2f_mode is None and lw is not None and torch.is_grad_enabled() and self.shade_impl != "torch"
+        fuse_reg = (c2f_mode is None and lw is not None and torch.is_grad_enabled()
                     and all(p.requires_grad for p in dP + dL + aP))
         if fuse_reg:
             cfg.reg_flags = (float(lw.get("TV_density", 0) or 0) != 0.0, float(lw.get("TV_color", 0) or 0) != 0.0)

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _build(seed=0):
+def _build(seed=0, blur=False):
     from joint_tensorf_amd.model import bat_hip
     from joint_tensorf_amd.options import make_options
     from joint_tensorf_amd.synthetic import make_views
@@ -26,8 +26,9 @@ def _build(seed=0):
     # Jitter ON, but pinned: without jitter the first sample of every ray lies exactly on the box face and the
     # last bit of the (optimised) pose decides whether it is in -- a coin toss that makes two runs of the same loop
     # differ by 1e-4 in the loss after a few iterations (discreteness note).
-    opt.c2f_schedule_density = [0.0, 0.0]       # sharp stage (the blurred stages stay on the eager path)
-    opt.c2f_schedule_color = [0.0, 0.0]
+    if not blur:
+        opt.c2f_schedule_density = [0.0, 0.0]   # sharp stage; blur=True keeps the yaml's schedule (factor blur with its
+        opt.c2f_schedule_color = [0.0, 0.0]     # random density scale: the taps reach the graph through static memory)
     torch.manual_seed(seed)
     model = bat_hip.Model(opt)
     model.build_networks(opt, n_views=B)
@@ -42,10 +43,10 @@ def _build(seed=0):
     return opt, model, var0
 
 
-def _run(use_graph, K, it0=0):
+def _run(use_graph, K, it0=0, blur=False):
     from joint_tensorf_amd.graphed import GraphedTrainStep
     from joint_tensorf_amd.options import Opt
-    opt, model, var0 = _build()
+    opt, model, var0 = _build(blur=blur)
     model.it = it0
     model.graph.nerf.set_progress(it0 / opt.max_iter)
     np.random.seed(5)
@@ -68,11 +69,16 @@ def _run(use_graph, K, it0=0):
     return np.array(losses), sd, (stepper.stats if use_graph else None), np.random.get_state()[1][:8].copy()
 
 
-@pytest.mark.parametrize("it0", [0, 9000])
-def test_graph_replay_follows_the_eager_trajectory(it0):
+@pytest.mark.parametrize("it0,blur", [(0, False), (9000, False), (0, True), (9000, True)])
+def test_graph_replay_follows_the_eager_trajectory(it0, blur):
     K = 16
-    l_e, sd_e, _, rs_e = _run(False, K, it0)
-    l_g, sd_g, stats, rs_g = _run(True, K, it0)
+    l_e, sd_e, _, rs_e = _run(False, K, it0, blur)
+    l_g, sd_g, stats, rs_g = _run(True, K, it0, blur)
+    if blur:
+        from joint_tensorf_amd.model.bat_hip import interp_schedule
+        from joint_tensorf_amd.options import make_options
+        o = make_options("bat_blender_VM", device="cpu")
+        assert interp_schedule(it0 / o.max_iter, o.c2f_schedule_color) >= 0.001  # the blur really is on at it0
     assert stats["captured"] >= 2 and stats["replayed"] >= K - 4, stats
     assert (rs_e == rs_g).all()  # the host random stream is consumed identically
     np.testing.assert_allclose(l_g, l_e, rtol=2e-5, atol=1e-9)

@@ -22,7 +22,7 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-def build_scene(fx, device, shade_impl):
+def build_scene(fx, device, shade_impl="mfma"):
     import joint_tensorf_amd as jt
     m = fx.meta
     torch.manual_seed(0)
@@ -31,7 +31,7 @@ def build_scene(fx, device, shade_impl):
                         shadingMode=m["shadingMode"], density_shift=m["density_shift"],
                         distance_scale=m["distance_scale"], view_pe=m["view_pe"], fea_pe=m["fea_pe"],
                         featureC=m["featureC"], step_ratio=m["step_ratio"], fea2denseAct=m["fea2denseAct"],
-                        rayMarch_weight_thres=m["rayMarch_weight_thres"], shade_impl=shade_impl)
+                        rayMarch_weight_thres=m["rayMarch_weight_thres"])
     sd = {k[len("param.nerf.tensorf."):]: fx.t(k) for k in fx.arrays if k.startswith("param.nerf.tensorf.")}
     missing, unexpected = tf.load_state_dict(sd, strict=True)
     tf = tf.to(device)
@@ -62,11 +62,15 @@ def replay_hip(fx, shade_impl, pin_rays=True, device="cuda"):
     if m["is_train"] and fx.has("in.jitter"):
         tf.jitter_override = fx.t("in.jitter", device)
     tf.coin_override = m["coin"][0] if m["coin"] else None
-    rgb, depth, acc = tf(None, center.reshape(-1, 3), ray.reshape(-1, 3), white_bg=m["white_bg"],
-                         is_train=m["is_train"], ndc_ray=m["ndc_ray"], N_samples=m["N_samples"],
-                         c2f_parameter_density=m["c2f_parameter_density"], c2f_parameter_color=m["c2f_parameter_color"],
-                         c2f_mode=m["c2f_mode"], c2f_kernel_size=m["c2f_kernel_size"],
-                         view_pe_progress=m["view_pe_progress"], fea_pe_progress=m["fea_pe_progress"])
+    import contextlib
+    from tests.staged_path import use_staged_path
+    # "torch": the staged cross-check path (tests/staged_path.py) instead of the fused MFMA kernels
+    with (use_staged_path() if shade_impl == "torch" else contextlib.nullcontext()):
+        rgb, depth, acc = tf(None, center.reshape(-1, 3), ray.reshape(-1, 3), white_bg=m["white_bg"],
+                             is_train=m["is_train"], ndc_ray=m["ndc_ray"], N_samples=m["N_samples"],
+                             c2f_parameter_density=m["c2f_parameter_density"], c2f_parameter_color=m["c2f_parameter_color"],
+                             c2f_mode=m["c2f_mode"], c2f_kernel_size=m["c2f_kernel_size"],
+                             view_pe_progress=m["view_pe_progress"], fea_pe_progress=m["fea_pe_progress"])
     rgb = rgb.view(B, r, 3)
     from oracle import tensorf_oracle as O  # checker only
     if m["mode"] == "vis":

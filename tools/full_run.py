@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="bat_blender_VM")
     ap.add_argument("--max-iter", type=int, default=0, help="stop early (0 = the yaml's max_iter)")
+    ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--graph", action="store_true", help="replay the sharp-stage iterations from hipGraphs (graphed.py)")
     args = ap.parse_args()
     from joint_tensorf_amd.model import bat_hip
@@ -27,14 +28,14 @@ def main():
     from joint_tensorf_amd.synthetic import make_views
     dev = "cuda:0"
     torch.cuda.set_device(0)
-    torch.manual_seed(0)
-    np.random.seed(0)
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
     opt = make_options(args.config, device=dev)
     n_views = int(opt.data.num_views)
     model = bat_hip.Model(opt)
     model.build_networks(opt, n_views=n_views)
     model.setup_optimizer(opt)
-    views = make_views(opt, n_views, seed=0, device=dev)
+    views = make_views(opt, n_views, seed=args.seed, device=dev)
     from joint_tensorf_amd.graphed import GraphedTrainStep
     stepper = GraphedTrainStep(model) if args.graph else None
     last = args.max_iter or int(opt.max_iter)
@@ -55,6 +56,7 @@ def main():
             torch.cuda.synchronize()
             lv = float(loss.all)
             assert np.isfinite(lv), (it, lv)
+            model.check_finite(opt)  # the device-side status word: pose / render / loss of every iteration since
             worst = max(worst, lv)
         if (it + 1) in marks:
             now = time.perf_counter()
