@@ -224,7 +224,7 @@ def measure_roofline(model, opt, var, reps=20):
     return probe.run(reps)
 
 
-def instep_roofline(timers, n_comp_app):
+def instep_roofline(timers, n_comp_app, n_comp_density=16):
     """roofline block of the dominant kernel from the HIP events recorded around its launches INSIDE the timed steps
     (ops.STEP_TIMERS): algorithmic bytes of SURVEY 8(d) (backward: the gather bytes re-read + the same bytes added to the
     gradients) times the shaded samples of every launch, over the summed launch durations."""
@@ -233,7 +233,12 @@ def instep_roofline(timers, n_comp_app):
     for kind, mult, name in (("bwd", 2, "k_shade_bwd (fused appearance backward: MLP backward on the fp32 matrix cores + "
                                        "run-length scatter of the factor gradients), inside the timed training steps"),
                              ("fwd", 1, "k_shade_fwd<train> (gather + basis + MLP + layer-input records), inside the timed "
-                                        "training steps")):
+                                        "training steps"),
+                             ("march_bwd", 2, "k_march_bwd_scan + k_march_bwd_walk (density backward: transmittance suffix "
+                                              "scan, then the run-length scatter of the density-factor gradients; bytes "
+                                              "counted for the walk's listed samples only), inside the timed training steps")):
+        if kind == "march_bwd":
+            per = 4 * 3 * n_comp_density * 6
         rows = [(a.elapsed_time(b) * 1e-3, int(off[-1])) for k, a, b, off in timers if k == kind]
         if not rows:
             continue
@@ -256,7 +261,10 @@ def pmc_traffic_instep(roof):
     try:
         rec = json.load(open(path))
         k = rec["k_shade_bwd"]
-        return {"traffic": k["hbm_bytes_per_sample"] * roof["samples_per_launch"], "traffic_unit": "bytes/launch",
+        n = roof["samples_per_launch"]
+        if abs(n - rec["process_samples_per_launch"]) > 0.1 * n:
+            return {"traffic": None}  # another workload than the one the counters were collected on
+        return {"traffic": k["hbm_bytes_per_sample"] * n, "traffic_unit": "bytes/launch",
                 "traffic_source": "profiles/round2_pmc_traffic_instep.json", "traffic_detail": rec}
     except Exception:
         return {"traffic": None}
@@ -323,6 +331,8 @@ def run_extras():
     base = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-probe",
             "--no-torch-baseline", "--no-extras"]
     cases = [("stage0_blurred", ["--stage", "0"], {}),
+             ("stage0_blurred_hipgraph", ["--stage", "0"], {"JT_GRAPH": "1"}),
+             ("stage2_blurred_hipgraph", ["--stage", "2"], {"JT_GRAPH": "1"}),
              ("stage4_blurred_it9000", ["--stage", "4", "--it", "9000"], {}),
              ("parent_yaml_299cube_4096rays", ["--n-voxel-final", "27000000", "--n-rays", "4096"], {}),
              ("llff_final_grid", ["--config", "bat_llff_VM_MLP"], {}),
@@ -340,7 +350,11 @@ def run_extras():
                          "launch": j["config"]["launch"]}
             if "roofline" in j and "launch_ms" in j["roofline"]:
                 out[name]["k_shade_bwd_ms"] = j["roofline"]["launch_ms"]
-                out[name]["roofline_frac"] = j["roofline"]["frac"]
+                out[name]["k_shade_bwd_frac"] = j["roofline"]["frac"]
+                db = j["roofline"].get("density_backward")
+                if db:
+                    out[name]["density_backward_ms"], out[name]["density_backward_frac"] = db["launch_ms"], db["frac"]
+                    out[name]["density_backward_listed_samples"] = db["samples_per_launch"]
         except Exception as ex:  # a secondary number must never cost the headline line
             out[name] = {"error": repr(ex)[:200]}
     return out
@@ -491,7 +505,7 @@ def main():
     def counting_check(rc, what):
         n_calls[0] += 1
         return orig_check(rc, what)
-    if rank == 0 and stepper is None:
+    if stepper is None:  # on every rank: the step contains collectives
         jops_t.check = counting_check
         one_step()
         jops_t.check = orig_check
@@ -584,7 +598,7 @@ def main():
             try:
                 from joint_tensorf_amd.options import Opt
                 tf_ = model.graph.nerf.tensorf
-                ins = instep_roofline(timers or [], tf_.app_n_comp[0])
+                ins = instep_roofline(timers or [], tf_.app_n_comp[0], tf_.density_n_comp[0])
                 if "bwd" in ins:
                     out["roofline"] = ins["bwd"]
                     # every k_shade_bwd launch of the process (priming and warm-up included): what a profiler sees
@@ -594,6 +608,8 @@ def main():
                     out["roofline"].update(pmc_traffic_instep(out["roofline"]))
                     if "fwd" in ins:
                         out["roofline"]["forward"] = ins["fwd"]
+                    if "march_bwd" in ins:
+                        out["roofline"]["density_backward"] = ins["march_bwd"]
                 else:
                     out["roofline"] = {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None,
                                        "traffic": None, "note": "no in-step launch timed (hipGraph replay)"}

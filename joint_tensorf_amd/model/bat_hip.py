@@ -669,6 +669,11 @@ class Model(torch.nn.Module):
         f_scalar, f_val, f_ckpt = (int(freq.get(k, 0) or 0) for k in ("scalar", "val", "ckpt"))
         images_all = self.train_data.all.image
         loss, t0 = None, time.time()
+        stepper = None
+        if _has(opt, "train_graph") and opt.train_graph and str(opt.device).startswith("cuda"):
+            # every steady-state iteration replayed from a hipGraph (graphed.GraphedTrainStep): one launch per iteration
+            from ..graphed import GraphedTrainStep
+            stepper = GraphedTrainStep(self)
         for it in range(int(opt.max_iter)):
             self.it = it
             if _has(opt, "early_stop_iter") and opt.early_stop_iter == it:
@@ -697,7 +702,7 @@ class Model(torch.nn.Module):
             if view_idx is not None:
                 for k in ("image", "pose", "intr_inv", "idx", "intr"):
                     var[k] = var[k][view_idx]
-            loss = self.train_iteration(opt, var)
+            loss = stepper.train_iteration(opt, var) if stepper is not None else self.train_iteration(opt, var)
             if _has(opt, "finite_checks_every_iteration") and opt.finite_checks_every_iteration:
                 self.check_finite(opt, loss)
             self.after_iteration(opt)  # self.it is it + 1 here, as in the reference

@@ -520,10 +520,22 @@ class RenderRays(torch.autograd.Function):
         g_d = torch.empty(R, 3, **f32)
         mws_bytes = lib.jt_march_backward_workspace_bytes(scene, R)
         mws = _workspace(dev, "march_bwd", mws_bytes)
+        timed = STEP_TIMERS is not None and not getattr(ctx, "pose_only", False)
+        if timed:
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
         check(lib.jt_march_backward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals), R,
                                     ptr(sigma_feat), ptr(weight), ptr(tmin), ptr(offset), ptr(sidx), ptr(rgb_s),
                                     ptr(cmask), ptr(g_rgb), ptr(g_op), ptr(g_xyz), gfac, ptr(g_o), ptr(g_d),
                                     ptr(mws), mws_bytes, st), "jt_march_backward")
+        if timed:
+            t1.record()
+            # listed samples of this call (in-box samples with a density gradient): the per-ray counts sit behind
+            # gfeat [R,S] f32 and vlist [R,S] u16 in the workspace (jt_march.hip: march_bwd_ws_layout)
+            S_ = cfg.n_samples
+            o = (R * S_ * 4 + 255) // 256 * 256
+            o = (o + R * S_ * 2 + 255) // 256 * 256
+            STEP_TIMERS.append(("march_bwd", t0, t1, mws[o:o + 4 * R].view(torch.int32).sum().view(1)))
         if dp:
             reducer.reduce(0, 1)  # density planes + lines are final
         if join is not None:
