@@ -252,6 +252,13 @@ size_t jt_shade_workspace_bytes(const JtScene* scene, int n_entries_max);
  * out[2] = hidden width, out[3] = samples per tile.  Bit mt * 16 + r of the word of half h stands for hidden unit
  * mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h (tensorBase.py:101-126: the ReLUs of MLPRender_Fea). */
 int jt_shade_record_layout(const JtScene* scene, int32_t* out);
+/* JT_DETERMINISTIC mode (also the environment variable of that name, read once): bit-reproducible gradients.  While
+ * it is on, the g_factors pointers handed to jt_shade_backward / jt_march_backward must be INT64 shadow buffers with
+ * the element count and indexing of the float gradient buffers (zero-initialised; sums arrive as 2^56 fixed point: value
+ * = word / 2^56), the cross-block sums of jt_render_loss_forward / jt_reg_losses_forward / the weight gradients run in
+ * a fixed order, and the ray gradients of jt_march_backward are combined in fixed point inside its workspace.  Returns
+ * the previous setting; any argument other than 0 / 1 only queries.  A debugging aid (race detection), slower. */
+int jt_set_deterministic(int on);
 int jt_shade_chunk_entries(void);
 int jt_shade_set_chunk_log2(int log2_entries);
 int jt_shade_forward(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp, const float* rays_o,

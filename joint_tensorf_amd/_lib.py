@@ -91,6 +91,7 @@ SIGNATURES = {
     "jt_shade_workspace_bytes": (ctypes.c_size_t, [SP, I]),
     "jt_shade_record_layout": (I, [SP, P]),
     "jt_finite_check": (I, [P, I, P, P]),
+    "jt_set_deterministic": (I, [I]),
     "jt_shade_chunk_entries": (I, []),
     "jt_shade_set_chunk_log2": (I, [I]),
     "jt_render_loss_forward": (I, [P, P, P, P, I, I, I, F, F, P, P, P]),

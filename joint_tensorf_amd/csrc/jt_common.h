@@ -68,6 +68,14 @@ inline int make_dev(const JtScene* s, const JtFactors* f, Dev* d) {
   return JT_OK;
 }
 
+// JT_DETERMINISTIC mode (jt_set_deterministic / the environment variable, read once): every order-dependent float
+// accumulation of the path is replaced by an order-independent one -- the factor / ray gradients of the scatters are
+// summed as 64-bit fixed point (integer atomics commute), the small reductions run in one workgroup or one pass -- so
+// that two runs from the same state produce bit-identical gradients.  A debugging aid (race detection: SURVEY section 5);
+// slower, and the callers hand int64 shadow buffers where the header says so.
+int jt_deterministic();                      // defined in jt_march.hip
+constexpr double kFixedScale = 72057594037927936.0;  // 2^56: 1.4e-17 resolution, +-128 range
+
 #define JT_LAUNCH_CHECK()                      \
   do {                                         \
     hipError_t e__ = hipGetLastError();        \
@@ -224,6 +232,11 @@ __device__ inline float density_act_grad(int act, float x) {
 }
 
 __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// order-independent accumulation: v as 2^56 fixed point into a 64-bit word
+__device__ inline void fixed_add(long long* p, float v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn((double)v * kFixedScale));
+}
 
 __device__ inline float wave_sum(float v) {
 #pragma unroll

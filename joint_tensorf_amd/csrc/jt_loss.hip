@@ -129,6 +129,7 @@ extern "C" int jt_render_loss_forward(const float* rgb, const float* image, cons
   JT_LAUNCH_CHECK();
   long n = (long)n_views * rays_per_view * 3;
   int blocks = (int)min((n + 255) / 256, 512L);
+  if (jt_deterministic()) blocks = 1;  // one workgroup: the four sums have a fixed order
   hipLaunchKernelGGL(k_render_loss_fwd, dim3(blocks), dim3(256), 0, st, rgb, image, ray_idx, edge_mask, n_views,
                      rays_per_view, n_pixels, acc4);
   JT_LAUNCH_CHECK();

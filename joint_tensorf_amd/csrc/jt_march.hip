@@ -1,6 +1,8 @@
 // Ray marching kernels (gfx950): sampling, density interpolation, transmittance scan, compositing,
 // and their backward.  One 64-lane wavefront owns one ray; lanes stride over the ray's samples so
 // the transmittance product is a wave prefix scan with a carry between 64-sample chunks.
+#include <cstdlib>
+
 #include "jt_common.h"
 #include "jt_walk.h"
 
@@ -426,7 +428,8 @@ __global__ __launch_bounds__(256, 4) void k_march_bwd_walk(Dev D, JtFactors G, c
                                                         const float* __restrict__ gfeat,
                                                         const uint16_t* __restrict__ vlist,
                                                         const int* __restrict__ nvalid, int runs_per_ray,
-                                                        float* __restrict__ g_rays_o, float* __restrict__ g_rays_d) {
+                                                        float* __restrict__ g_rays_o, float* __restrict__ g_rays_d,
+                                                        long long* __restrict__ rays_fixed) {
   constexpr int NCH = (CD + 15) / 16;
   // + 16 words per group: the four groups of a wave read their own records in the same instruction, and a group
   // stride that is a multiple of the 64 LDS banks would put all four on the same banks (measured: 17 % of the
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(256, 4) void k_march_bwd_walk(Dev D, JtFactors G, c
   float* rec = s_rec[grp];
   RecWalker<NCH, CD> wk[3];
 #pragma unroll
-  for (int pl = 0; pl < 3; ++pl) wk[pl].init(G.density_plane[pl], G.density_line[pl], cl);
+  for (int pl = 0; pl < 3; ++pl) wk[pl].init(G.density_plane[pl], G.density_line[pl], cl, rays_fixed != nullptr);
   float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
 
   for (int kb = k0; kb < k1; kb += kWalkSub) {
@@ -527,8 +530,29 @@ __global__ __launch_bounds__(256, 4) void k_march_bwd_walk(Dev D, JtFactors G, c
     go[a] = row16_sum(go[a]);
     gd[a] = row16_sum(gd[a]);
   }
+  if (rays_fixed) {  // JT_DETERMINISTIC: the runs of a ray meet in 64-bit fixed point, added to g_rays by k_rays_fixed_add
+    if (cl < 6)
+      fixed_add(rays_fixed + (size_t)ray * 6 + cl, cl == 0 ? go[0] : cl == 1 ? go[1] : cl == 2 ? go[2]
+                                                                  : cl == 3 ? gd[0] : cl == 4 ? gd[1] : gd[2]);
+    return;
+  }
   if (cl < 3) atomicAdd(g_rays_o + ray * 3 + cl, cl == 0 ? go[0] : cl == 1 ? go[1] : go[2]);
   else if (cl < 6) atomicAdd(g_rays_d + ray * 3 + (cl - 3), cl == 3 ? gd[0] : cl == 4 ? gd[1] : gd[2]);
+}
+
+__global__ void k_zero64(long long* p, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0;
+}
+
+// g_rays_o/d [R][3] += fixed-point sums [R][6]
+__global__ void k_rays_fixed_add(const long long* __restrict__ f, int R, float* __restrict__ g_rays_o,
+                                 float* __restrict__ g_rays_d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * 6) return;
+  const int ray = i / 6, c = i - ray * 6;
+  const float v = (float)((double)f[i] / kFixedScale);
+  if (c < 3) g_rays_o[ray * 3 + c] += v;
+  else g_rays_d[ray * 3 + (c - 3)] += v;
 }
 
 // opacity of one step of `length` at arbitrary points (BatBase.compute_alpha, batBase.py:27-41): the dense
@@ -557,6 +581,20 @@ static int check_density_shape(const Dev& D) {
 }
 
 extern "C" int jt_version(void) { return JT_VERSION; }
+
+static int g_deterministic = -1;  // -1: not yet read from the environment
+int jt::jt_deterministic() {
+  if (g_deterministic < 0) {
+    const char* e = getenv("JT_DETERMINISTIC");
+    g_deterministic = (e && atoi(e) != 0) ? 1 : 0;
+  }
+  return g_deterministic;
+}
+extern "C" int jt_set_deterministic(int on) {
+  const int prev = jt_deterministic();
+  if (on == 0 || on == 1) g_deterministic = on;
+  return prev;
+}
 
 extern "C" int jt_dense_alpha(const JtScene* scene, const JtFactors* factors, const float* xyz, long n, float length,
                               float* alpha, void* stream) {
@@ -642,7 +680,7 @@ extern "C" int jt_composite_backward(const JtScene* scene, int n_rays, const int
   return JT_OK;
 }
 
-static size_t march_bwd_ws_layout(int S, int R, size_t* o_vlist, size_t* o_nvalid) {
+static size_t march_bwd_ws_layout(int S, int R, size_t* o_vlist, size_t* o_nvalid, size_t* o_fixed = nullptr) {
   size_t off = 0;
   off += (size_t)R * S * sizeof(float);                 // gfeat
   off = (off + 255) & ~(size_t)255;
@@ -651,6 +689,9 @@ static size_t march_bwd_ws_layout(int S, int R, size_t* o_vlist, size_t* o_nvali
   off = (off + 255) & ~(size_t)255;
   *o_nvalid = off;
   off += (size_t)R * sizeof(int);
+  off = (off + 255) & ~(size_t)255;
+  if (o_fixed) *o_fixed = off;
+  off += (size_t)R * 6 * sizeof(long long);             // ray-gradient sums in fixed point (JT_DETERMINISTIC only)
   return (off + 255) & ~(size_t)255;
 }
 
@@ -677,8 +718,11 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
     if (g_factors && (!g_factors->density_plane[a] || !g_factors->density_line[a])) return JT_ERR_ARG;
   if (D.ndc && !zvals) return JT_ERR_ARG;
   if ((rc = check_density_shape(D))) return rc;
-  size_t o_vlist, o_nvalid;
-  if (workspace_bytes < march_bwd_ws_layout(D.S, n_rays, &o_vlist, &o_nvalid)) return JT_ERR_ARG;
+  size_t o_vlist, o_nvalid, o_fixed;
+  if (workspace_bytes < march_bwd_ws_layout(D.S, n_rays, &o_vlist, &o_nvalid, &o_fixed)) return JT_ERR_ARG;
+  // JT_DETERMINISTIC with factor gradients wanted: g_factors points at int64 shadow buffers, ray sums in fixed point
+  long long* rays_fixed = jt_deterministic() ? reinterpret_cast<long long*>(reinterpret_cast<char*>(workspace) + o_fixed)
+                                             : nullptr;
   JtFactors no_grads = {};  // g_factors == NULL: gradients w.r.t. the rays only (the walk writes no factor gradient)
   const JtFactors& GF = g_factors ? *g_factors : no_grads;
   float* gfeat = reinterpret_cast<float*>(workspace);
@@ -694,24 +738,33 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
                      n_rays, sigma_feat, weight, tmin, shade_offset, shade_idx, rgb_s, clamp_mask, g_rgb, g_opacity,
                      g_xyz_app, gfeat, vlist, nvalid, g_rays_o, g_rays_d, Spad);
   JT_LAUNCH_CHECK();
+  if (rays_fixed) {
+    hipLaunchKernelGGL(k_zero64, dim3((n_rays * 6 + 255) / 256), dim3(256), 0, st, rays_fixed, (long)n_rays * 6);
+    JT_LAUNCH_CHECK();
+  }
   const int runs = (D.S + kWalkRun - 1) / kWalkRun;
   const long items = (long)n_rays * runs;
   const int blocks = (int)((items + 15) / 16);
   if (D.Cd <= 16) {
     if (D.Cd == 16)
       hipLaunchKernelGGL(k_march_bwd_walk<16>, dim3(blocks), dim3(256), 0, st, D, GF, rays_o, rays_d, jitter,
-                         zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d);
+                         zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d, rays_fixed);
     else if (D.Cd == 8)
       hipLaunchKernelGGL(k_march_bwd_walk<8>, dim3(blocks), dim3(256), 0, st, D, GF, rays_o, rays_d, jitter,
-                         zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d);
+                         zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d, rays_fixed);
     else
       return JT_ERR_UNSUPPORTED;
   } else if (D.Cd == 32) {
     hipLaunchKernelGGL(k_march_bwd_walk<32>, dim3(blocks), dim3(256), 0, st, D, GF, rays_o, rays_d, jitter,
-                       zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d);
+                       zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d, rays_fixed);
   } else {
     return JT_ERR_UNSUPPORTED;
   }
   JT_LAUNCH_CHECK();
+  if (rays_fixed) {
+    hipLaunchKernelGGL(k_rays_fixed_add, dim3((n_rays * 6 + 255) / 256), dim3(256), 0, st, rays_fixed, n_rays, g_rays_o,
+                       g_rays_d);
+    JT_LAUNCH_CHECK();
+  }
   return JT_OK;
 }

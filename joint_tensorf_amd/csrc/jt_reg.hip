@@ -259,6 +259,7 @@ extern "C" int jt_reg_losses_forward(const JtFactors* factors, const int32_t* pl
     const RegTensor& t = S.t[i];
     long total = (long)t.H * t.W * (t.C / 4);
     int blocks = (int)min((total + 255) / 256, 512L);  // every block ends in three same-address atomics
+    if (jt_deterministic()) blocks = 1;                // one workgroup per tensor: a fixed summation order
     B.t[B.n++] = {t.x, nullptr, t.H, t.W, t.C, tv ? 1 : 0, i, nblk, blocks};
     nblk += blocks;
   }

@@ -529,13 +529,13 @@ __device__ inline void wave_lds_sync() {
 // sample and sit in LDS; the factor values of the next sample are loaded while the current one is accumulated.
 template <class C>
 __device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, const float* tp, const float* recs,
-                                     float* gxyz, int lane) {
+                                     float* gxyz, int lane, bool fixed) {
   constexpr int NCH = (C::CA + 15) / 16;
   const int grp = lane >> 4, cl = lane & 15;
   const float* P = D.aP[pl];
   const float* Ln = D.aL[pl];
   RecWalker<NCH, C::CA> wk;
-  wk.init(G.app_plane[pl], G.app_line[pl], cl);
+  wk.init(G.app_plane[pl], G.app_line[pl], cl, fixed);
   const int m0 = kM0(pl), m1 = kM1(pl), mv = kV(pl);
   // lanes 0..2 of a group add the x / y / line coordinate gradient of the step to gxyz[sample][axis]
   const int my_axis = (cl == 0) ? m0 : (cl == 1) ? m1 : mv;
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
                       recs + j * kRecWords);
       }
       wave_lds_sync();
-      if (!(ablate & 1)) scatter_plane<C>(D, G, pl, tp, recs, gxyz, lane);
+      if (!(ablate & 1)) scatter_plane<C>(D, G, pl, tp, recs, gxyz, lane, (ablate & 16) != 0);
       wave_lds_sync();
     }
     if (on && h == 0) {
@@ -1187,8 +1187,9 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   const int nb = kWgradBlocks;
   // profiling knob, read ONCE per process: 1 = no scatter, 2 = no gradient records, 4 = no weight-gradient GEMMs
   static const int abl_env = [] { const char* e = getenv("JT_ABLATE"); return e ? atoi(e) : 0; }();
+  const int det = jt_deterministic();  // 16: the appearance-factor gradients go to int64 shadow buffers (fixed point)
   const int ablate = abl_env | ((flags & JT_SHADE_SKIP_WGRAD) ? 4 : 0) |
-                     ((flags & kNoGradRecords) ? 2 : 0);
+                     ((flags & kNoGradRecords) ? 2 : 0) | (det ? 16 : 0);
   constexpr int NT3 = W::NT3, NT1 = W::NT1, NTB = W::NTB;
   constexpr int XF1 = (C::KIND == JT_MLP_FEA) ? 1 : 2;
   // ---- per chunk: the per-sample backward on the main stream, its weight-gradient GEMMs on the auxiliary stream ----
@@ -1253,20 +1254,21 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     }
   }
   {
+    const int ry = det ? 1 : 32;  // slab groups that add into dW atomically; ONE group = a fixed summation order
     float* s3 = slabs;
     float* s2 = s3 + W::P3 * nb;
     float* s1 = s2 + W::P2 * nb;
     float* sb = s1 + W::P1 * nb;
-    hipLaunchKernelGGL((k_wgrad_reduce<1, NT3, 0>), dim3((W::P3 + 255) / 256, 32), dim3(256), 0, ws_st, s3, nb, cstride,
+    hipLaunchKernelGGL((k_wgrad_reduce<1, NT3, 0>), dim3((W::P3 + 255) / 256, ry), dim3(256), 0, ws_st, s3, nb, cstride,
                        chunk, offset, R, cap, 3, C::IN3, C::APP, GM.w3, C::IN3, GM.b3);
     JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad_reduce<C::MT, C::MT, 0>), dim3((W::P2 + 255) / 256, 32), dim3(256), 0, ws_st, s2, nb,
+    hipLaunchKernelGGL((k_wgrad_reduce<C::MT, C::MT, 0>), dim3((W::P2 + 255) / 256, ry), dim3(256), 0, ws_st, s2, nb,
                        cstride, chunk, offset, R, cap, C::HID, C::HID, C::APP, GM.w2, C::HID, GM.b2);
     JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad_reduce<C::MT, NT1, XF1>), dim3((W::P1 + 255) / 256, 32), dim3(256), 0, ws_st, s1, nb,
+    hipLaunchKernelGGL((k_wgrad_reduce<C::MT, NT1, XF1>), dim3((W::P1 + 255) / 256, ry), dim3(256), 0, ws_st, s1, nb,
                        cstride, chunk, offset, R, cap, C::HID, C::IN1, C::APP, GM.w1, C::IN1, GM.b1);
     JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad_reduce<1, NTB, 0>), dim3((W::PB + 255) / 256, 32), dim3(256), 0, ws_st, sb, nb, cstride,
+    hipLaunchKernelGGL((k_wgrad_reduce<1, NTB, 0>), dim3((W::PB + 255) / 256, ry), dim3(256), 0, ws_st, sb, nb, cstride,
                        chunk, offset, R, cap, C::APP, C::NC, C::APP, GM.basis, C::NC, (float*)nullptr);
     JT_LAUNCH_CHECK();
   }

@@ -119,10 +119,12 @@ struct RecWalker {
   bool live[NCH];
   float* gP;
   float* gL;
+  bool fixed;  // JT_DETERMINISTIC: gP / gL are int64 shadow buffers (same element indexing), sums in 2^56 fixed point
 
-  __device__ inline void init(float* gP_, float* gL_, int cl) {
+  __device__ inline void init(float* gP_, float* gL_, int cl, bool fixed_ = false) {
     gP = gP_;
     gL = gL_;
+    fixed = fixed_;
 #pragma unroll
     for (int c = 0; c < 4; ++c) o[c] = 0u;
     lo[0] = lo[1] = 0u;
@@ -152,8 +154,12 @@ struct RecWalker {
   __device__ inline void flush(float* base, unsigned off, float* a) {
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-      if (base != nullptr && live[k] && JT_FLUSH_COND(a[k]))
-        atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (off + ck[k])), a[k]);
+      if (base != nullptr && live[k] && JT_FLUSH_COND(a[k])) {
+        if (fixed)  // byte offset of a float element -> the same element of the 64-bit shadow buffer
+          fixed_add(reinterpret_cast<long long*>(reinterpret_cast<char*>(base) + 2 * (size_t)(off + ck[k])), a[k]);
+        else
+          atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (off + ck[k])), a[k]);
+      }
       a[k] = 0.f;
     }
   }

@@ -457,7 +457,19 @@ class RenderRays(torch.autograd.Function):
         want_fac = any(nig[5:17])
         want_mlp = any(nig[17:24])
         fused_mlp_zero = want_fac and want_mlp
-        if want_fac:
+        det = bool(lib.jt_set_deterministic(-1))  # JT_DETERMINISTIC: factor gradients summed in 64-bit fixed point
+        if det and want_fac:
+            if _DP["world"] > 1 or _DP["force"]:
+                raise RuntimeError("JT_DETERMINISTIC is a single-process debugging mode")
+            # int64 shadow buffers with the layout of the float ones; converted after the density backward
+            (gdp, gdl, gap, gal), gflat, spans = _zeros_flat([sdp, sdl, sap, sal], with_flat=True)
+            gflat64 = torch.zeros(gflat.numel(), device=dev, dtype=torch.int64)
+            shadow = [gflat64[(v.data_ptr() - gflat.data_ptr()) // 4:][:v.numel()] for grp in (gdp, gdl, gap, gal) for v in grp]
+            gfac = _factors_struct(shadow[0:3], shadow[3:6], shadow[6:9], shadow[9:12])
+            gfac_float = _factors_struct(gdp, gdl, gap, gal)
+            fused_mlp_zero = False
+            g_mlp_z = None
+        elif want_fac:
             # gradient buffers (channel-last storage, zero-initialised: the kernels accumulate with atomics)
             if fused_mlp_zero:
                 (gdp, gdl, gap, gal, g_mlp_z), gflat, spans = _zeros_flat([sdp, sdl, sap, sal, mlp_t], with_flat=True)
@@ -543,6 +555,10 @@ class RenderRays(torch.autograd.Function):
         if dp:
             reducer.reduce(4, 4)  # basis + MLP
             reducer.wait()  # stream-level: whoever consumes the gradients next runs behind the collectives
+        if det and want_fac:
+            # fixed point -> float (value = word / 2^56), in place of the zero-filled float buffers
+            gflat.copy_((gflat64.double() * (1.0 / 72057594037927936.0)).float())
+            gfac = gfac_float
         if ctx.reg is not None and g_reg is not None and want_fac:
             # the regularisers' gradient joins the render gradient in place (after the collectives: it is the same
             # on every rank and is not part of the exchange)

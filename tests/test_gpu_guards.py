@@ -80,3 +80,63 @@ def test_float_atomic_scatters_reproduce_within_rounding():
                 worst = (k, e)
             assert e <= 5e-6, (k, e)
     print("run-to-run gradient difference: worst %.2e of the tensor's max (%s)" % (worst[1], worst[0]))
+
+
+def test_deterministic_mode_is_bit_reproducible():
+    """JT_DETERMINISTIC (jt_set_deterministic): the scatters' float atomics become 64-bit fixed-point integer atomics
+    (order-independent), the cross-block sums run in a fixed order -- three backward passes from the same state give
+    BIT-IDENTICAL gradients and losses, and they agree with the default mode to rounding."""
+    from joint_tensorf_amd._lib import lib
+    from joint_tensorf_amd.options import Opt
+    opt, model, var = _model()
+    tf = model.graph.nerf.tensorf
+    jit = torch.rand(4096, 1, generator=torch.Generator().manual_seed(9)).to(DEV)
+
+    def backward():
+        np.random.seed(11)
+        tf.jitter_override = jit
+        g = model.graph
+        g.it = model.it
+        model.optim.zero_grad()
+        model.optim_pose.zero_grad()
+        v = g.forward(opt, Opt(dict(var)), mode="train")
+        loss = model.summarize_loss(opt, v, g.compute_loss(opt, v, mode="train"))
+        loss.all.backward()
+        out = {k: p.grad.detach().clone() for k, p in g.named_parameters() if p.grad is not None}
+        out["loss.all"] = loss.all.detach().clone()
+        out["loss.L1"] = loss.L1.detach().clone()
+        return out
+
+    plain = backward()
+    prev = lib.jt_set_deterministic(1)
+    try:
+        runs = [backward() for _ in range(3)]
+    finally:
+        lib.jt_set_deterministic(prev)
+    assert len(runs[0]) >= 22
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]) and torch.equal(runs[0][k], runs[2][k]), k
+    worst = ("", 0.0)
+    for k in plain:
+        a, b = plain[k].double(), runs[0][k].double()
+        e = float((a - b).abs().max() / a.abs().max().clamp_min(1e-30))
+        if e > worst[1]:
+            worst = (k, e)
+        assert e <= 5e-6, (k, e)
+    print("deterministic vs default mode: worst difference %.2e of the tensor's max (%s)" % (worst[1], worst[0]))
+    # a full optimizer step in the mode: parameters identical between two models stepped from the same state
+    states = []
+    lib.jt_set_deterministic(1)
+    try:
+        for _ in range(2):
+            o2, m2, v2 = _model()
+            m2.graph.nerf.tensorf.jitter_override = jit
+            for it in range(3):
+                np.random.seed(20 + it)
+                m2.train_iteration(o2, Opt(dict(v2)))
+                m2.after_iteration(o2)
+            states.append({k: p.detach().clone() for k, p in m2.graph.named_parameters()})
+    finally:
+        lib.jt_set_deterministic(prev)
+    for k in states[0]:
+        assert torch.equal(states[0][k], states[1][k]), k
