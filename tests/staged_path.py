@@ -90,6 +90,14 @@ class StagedRenderRays(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_opacity):
+        prev = lib.jt_set_deterministic(0)  # float gradient buffers: the fixed-point mode of the product path is off here
+        try:
+            return StagedRenderRays._backward(ctx, g_rgb, g_depth, g_opacity)
+        finally:
+            lib.jt_set_deterministic(prev)
+
+    @staticmethod
+    def _backward(ctx, g_rgb, g_depth, g_opacity):
         cfg = ctx.cfg
         (rays_o, rays_d, jitter, zvals, sdp, sdl, sap, sal, mlp_t, sigma_feat, weight, tmin, offset, sidx, eray, esmp,
          vdir, rgb_s, cmask) = ctx.saved
