@@ -341,7 +341,7 @@ def run_extras():
     out = {}
     for name, flags, env in cases:
         try:
-            e = dict(os.environ)
+            e = dict(os.environ, JT_TIME_WALK="1")
             e.update(env)
             r = subprocess.run(base + flags, env=e, capture_output=True, text=True, timeout=300)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
@@ -484,6 +484,8 @@ def main():
         from joint_tensorf_amd import ops as _jops
         # HIP events around every k_shade_fwd<train> / k_shade_bwd launch; the ones of the timed steps make the roofline
         _jops.STEP_TIMERS = []
+        # the density backward is timed as well (one more reduction launch per step) outside the headline workload
+        _jops.STEP_TIMERS_WALK = os.environ.get("JT_TIME_WALK") == "1" or args.config != "bat_blender_VM"
     # priming (untimed, in front of the warm-up): one eager step on the densest lattice (offsets 0, 0) so that every
     # persistent workspace and allocator block reaches its final size, then one step per lattice shape so that the
     # hipGraph of each shape is captured before the clock starts
@@ -492,7 +494,8 @@ def main():
         use_graph[0] = True
         lat = model.graph.lattice_step(opt, n_views)
         for offs in ([0, 0], [0, lat - 1], [lat - 1, 0], [lat - 1, lat - 1]):
-            primed_step(offs)
+            primed_step(offs)   # two consecutive iterations per lattice shape: both parities of the alternating
+            primed_step(offs)   # edge-weighted loss (model/tensorf.py:106), each a graph signature of its own
     for w in range(args.warmup):
         one_step()
     barrier()

@@ -109,6 +109,7 @@ class prof_range:
 # (kind, start event, end event, shade_offset tensor) for its k_shade_fwd<train> and k_shade_bwd launches -- HIP events on
 # the launch stream, read by the caller after its own synchronisation (no sync is added here).
 STEP_TIMERS = None
+STEP_TIMERS_WALK = False  # also time jt_march_backward and count its listed samples (one more launch per step)
 _AUX = {}
 _WS = {}
 _WS_EPOCH = {}
@@ -532,7 +533,7 @@ class RenderRays(torch.autograd.Function):
         g_d = torch.empty(R, 3, **f32)
         mws_bytes = lib.jt_march_backward_workspace_bytes(scene, R)
         mws = _workspace(dev, "march_bwd", mws_bytes)
-        timed = STEP_TIMERS is not None and not getattr(ctx, "pose_only", False)
+        timed = STEP_TIMERS is not None and STEP_TIMERS_WALK and not getattr(ctx, "pose_only", False)
         if timed:
             t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0.record()
