@@ -156,3 +156,55 @@ def test_a_reference_checkpoint_restores_into_this_build(tmp_path):
             np.testing.assert_array_equal(sd[k[len("graph."):]].cpu().numpy(), d[k], err_msg=k)
     assert abs(m.optim.param_groups[0]["lr"] - meta["optim_param_groups"][0]["lr"]) < 1e-12
     assert abs(m.graph.nerf.progress_host - meta["progress"]) < 1e-9
+
+
+def test_train_loop_sequencing_without_a_gpu(tmp_path):
+    """nerf.Model.train's control flow (model/nerf.py:150-278) with the device work stubbed out: schedule glue before
+    every iteration, update_schedule after it with the incremented counter, validation / checkpoint cadence, early stop,
+    and a resumed run that skips the iterations it has already done."""
+    from joint_tensorf_amd.options import Opt
+    opt = _small_opt(output_path=str(tmp_path), max_iter=12, freq=dict(scalar=4, val=5, ckpt=6), blur_2d=False,
+                     train_schedule=dict(n_voxel_init=10 ** 3, n_voxel_final=16 ** 3, upsample_iters=[3, 50], n_rays_init=60,
+                                         n_rays_rest=30, change_n_rays_after_n_iters=7))
+    m = _build(opt)
+    log = []
+    m.validate = lambda o, ep=None: log.append(("val", ep))
+    m.check_finite = lambda o, loss=None: log.append(("finite", m.it))
+
+    def fake_iteration(o, var):
+        log.append(("it", m.it, o.nerf.n_rays, m.graph.nerf.tensorf.gridSize.tolist()[0], tuple(var.image.shape)))
+        m.it += 1
+        m.graph.nerf.set_progress(m.it / o.max_iter)
+        return Opt(all=torch.tensor(0.5))
+    m.train_iteration = fake_iteration
+    m.train(opt)
+    its = [e for e in log if e[0] == "it"]
+    assert [e[1] for e in its] == list(range(12))
+    assert [e[2] for e in its] == [60] * 7 + [30] * 5                      # n_rays switch at iteration 7
+    assert [e[3] for e in its] == [10] * 3 + [12] * 9                      # grid grows after the step that reaches it 3
+    assert its[0][4] == (3, 3, 32, 32)
+    assert [e[1] for e in log if e[0] == "val"] == [0, 5, 10]             # at the start, then every freq.val
+    assert [e[1] for e in log if e[0] == "finite"] == [4, 8, 12, 12]      # every freq.scalar + at the end
+    assert sorted(os.listdir(os.path.join(str(tmp_path), "model"))) == ["12.ckpt", "6.ckpt"]
+    ck = torch.load(os.path.join(str(tmp_path), "model.ckpt"), weights_only=False)
+    assert ck["iter"] == 12
+    # resume from the iteration-6 checkpoint: iterations 0..5 are skipped, the grid is the checkpointed one
+    opt2 = _small_opt(output_path=str(tmp_path), max_iter=12, freq=dict(scalar=4, val=5, ckpt=100), blur_2d=False, resume=6,
+                      train_schedule=dict(n_voxel_init=10 ** 3, n_voxel_final=16 ** 3, upsample_iters=[3, 50], n_rays_init=60,
+                                          n_rays_rest=30, change_n_rays_after_n_iters=7))
+    m2 = _build(opt2)
+    m2.restore_checkpoint(opt2)
+    assert m2.iter_start == 6 and m2.graph.nerf.tensorf.gridSize.tolist() == [12, 12, 12]
+    log2 = []
+    m2.validate = lambda o, ep=None: log2.append(("val", ep))
+    m2.check_finite = lambda o, loss=None: None
+
+    def fake2(o, var):
+        log2.append(("it", m2.it))
+        m2.it += 1
+        return Opt(all=torch.tensor(0.5))
+    m2.train_iteration = fake2
+    opt2.early_stop_iter = 10
+    m2.train(opt2)
+    assert [e[1] for e in log2 if e[0] == "it"] == [6, 7, 8, 9]
+    assert ("val", 0) not in log2  # no start-of-run validation when resuming
