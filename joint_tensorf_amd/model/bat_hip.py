@@ -683,8 +683,7 @@ class Model(torch.nn.Module):
                 # a resumed run passes through the skipped iterations' cache refreshes (model/nerf.py:172-176 sits in
                 # front of the `continue`): the 2-D supervision cache is the one the uninterrupted run would hold
                 if it % 500 == 0 and _has(opt, "blur_2d") and opt.blur_2d:
-                    self.blurred_gt_cached_images = self.process_GT_images(opt, images_all)
-                    self.blurred_edge_masks = self.get_edge_mask(opt, self.blurred_gt_cached_images)
+                    self._refresh_supervision(opt, images_all)
                 continue
             self.before_iteration(opt, it)
             train_images, train_edge_masks, sc = self.select_supervision(opt, images_all)
@@ -917,6 +916,25 @@ class Model(torch.nn.Module):
                 masks[sc] = (GG > GG.mean(dim=1, keepdim=True) * thresh).to(torch.uint8)
         return masks
 
+    def _refresh_supervision(self, opt, images=None):
+        """Rebuild the 2-D blur cache and the edge masks (model/nerf.py:172-176).  The new contents are written INTO the
+        existing buffers when the shapes allow: the supervising tensors keep their addresses over the 80 refreshes of
+        a run, so hipGraphs that read them (graphed.GraphedTrainStep) stay valid."""
+        new_img = self.process_GT_images(opt, images)
+        new_msk = self.get_edge_mask(opt, new_img)
+        src = images if images is not None else self.train_data.all.image
+        for name, new in (("blurred_gt_cached_images", new_img), ("blurred_edge_masks", new_msk)):
+            old = getattr(self, name, None)
+            if isinstance(old, dict) and old.keys() == new.keys() and all(
+                    old[k].shape == new[k].shape and old[k].dtype == new[k].dtype and old[k].data_ptr() != src.data_ptr()
+                    for k in new):
+                for k in new:
+                    old[k].copy_(new[k])
+            else:
+                # (a scale whose blur is below the cut-off comes back as the source images themselves,
+                #  model/nerf.py:92-94: it gets a buffer of its own, so that later refreshes can write into it)
+                setattr(self, name, {k: (v.clone() if v.data_ptr() == src.data_ptr() else v) for k, v in new.items()})
+
     def select_supervision(self, opt, images=None):
         """The per-iteration choice of nerf.Model.train (model/nerf.py:172-176, 209-227): refresh the caches every
         500 iterations, then draw the blur scale of this iteration's supervising images; the edge masks come from
@@ -924,8 +942,7 @@ class Model(torch.nn.Module):
         if not (_has(opt, "blur_2d") and opt.blur_2d):
             return (images if images is not None else self.train_data.all.image), None, None
         if self.it % 500 == 0 or not hasattr(self, "blurred_gt_cached_images"):
-            self.blurred_gt_cached_images = self.process_GT_images(opt, images)
-            self.blurred_edge_masks = self.get_edge_mask(opt, self.blurred_gt_cached_images)
+            self._refresh_supervision(opt, images)
         if _has(opt, "c2f_alternate_2D_blur") and opt.c2f_alternate_2D_blur:
             sc = np.random.choice(opt.c2f_alternate_2D_scale_pool)
             train_images = self.blurred_gt_cached_images[sc]
