@@ -1,3 +1,5 @@
+#!/bin/bash
+# eager vs hipGraph-replayed train step per grid stage of bat_blender_VM (blurred stages included): DESIGN.md section 3
 F="--no-cpu-baseline --no-probe --no-torch-baseline --no-extras --no-roofline --steps 40 --warmup 10"
 for st in 0 1 2 3; do
   for g in 0 1; do
