@@ -189,3 +189,47 @@ def test_backward_chunk_boundaries_small_chunks():
     for k, p in model.graph.nerf.tensorf.named_parameters():
         if p.grad is not None:
             assert U.rel_max(g16[k], p.grad) <= 2e-5, (k, U.rel_max(g16[k], p.grad))
+
+
+def test_configs4_full_800x800_render_graph_vs_slices_vs_oracle():
+    """(v') BASELINE.json configs[4] as a whole: the 800 x 800 novel-view render, S = 1 024, 400^3, captured as ONE hipGraph
+    of 20 slices of 32 768 pixels (graphed.GraphedEvalRender), against the eager sliced render (bit-equal: same kernels,
+    no atomics in the forward) and against the oracle on all 640 000 pixels."""
+    from joint_tensorf_amd.options import Opt
+    opt, model, var_all, it0 = U.build("bat_blender_VM", stage=-1, density_scale=25.0,
+                                      overrides=dict(data=dict(image_size=[800, 800], num_views=2),
+                                                     nerf=dict(sample_intvs=1024)))
+    g = model.graph
+    tf = g.nerf.tensorf
+    g.nerf.n_samples = g.nerf._find_n_samples(opt, g.nerf.resolution)
+    S = g.nerf.n_samples
+    assert S == 1024
+    g.eval()
+    var = Opt({k: (v[1:2] if torch.is_tensor(v) and v.shape[:1] == (2,) else v) for k, v in dict(var_all).items()})
+    var.idx = torch.arange(1, device=DEV)
+    outs = {}
+    with torch.no_grad():
+        for use_graph in (False, True):
+            opt.nerf.eval_graph = use_graph
+            v = g.forward(opt, Opt(dict(var)), mode="vis_eval")
+            outs[use_graph] = {k: v[k].clone() for k in ("rgb", "depth", "opacity")}
+        assert g.eval_graph is not None and g.eval_graph.entry is not None
+        for k in outs[False]:
+            assert outs[False][k].shape[1] == 640000
+            torch.testing.assert_close(outs[True][k], outs[False][k], rtol=0, atol=0)
+        from joint_tensorf_amd import ops
+        cfg = U.oracle_cfg(opt, tf)
+        params = U.oracle_params(tf)
+        worst = dict(rgb=0.0, depth=0.0, opacity=0.0)
+        for a in range(0, 640000, 8192):
+            idx = torch.arange(a, min(a + 8192, 640000), device=DEV)
+            c, r = ops.ray_gen(var.pose, var.intr_inv, var.intr, idx, opt.W)
+            rgb, depth, acc = O.render(cfg, params, c[0], r[0], S, white_bg=True)
+            for k, t in (("rgb", rgb), ("depth", depth), ("opacity", acc)):
+                e = float((outs[True][k][0, a:a + 8192].reshape(t.shape) - t).abs().max())
+                worst[k] = max(worst[k], e)
+    rep = dict(case="configs4_800x800_graph_render", rays=640000, samples_per_ray=S, grid=tf.gridSize.tolist(), blur=False,
+               loss_hip=0.0, loss_oracle=0.0, values=worst, grads={})
+    U.report(rep)
+    U.record(rep)
+    assert worst["rgb"] <= 2e-5 and worst["opacity"] <= 2e-5 and worst["depth"] <= 2e-4, worst
