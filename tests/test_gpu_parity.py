@@ -3,7 +3,7 @@
   (b) the CPU oracle on the same inputs.
 Tolerances = ~4x the errors measured on MI355X (printed per case; round 2: rgb / opacity <= 4.8e-7, gradients
 <= 8.7e-5 of the tensor's max-abs on the Blender fixtures, <= 2.1e-4 on the LLFF ones, 2.1e-3 on the saturated
-`dense` fixtures whose render gradient is a cancellation residue): values 2e-6 abs, gradients 5e-4 / 8e-3.
+`dense` fixtures whose render gradient is a cancellation residue): values 2e-6 abs, gradients 5e-4 / 1e-3 (LLFF) / 8e-3.
 The full-size configurations are in tests/test_gpu_fullsize.py."""
 import numpy as np
 import pytest
@@ -107,7 +107,7 @@ def test_hip_vs_golden_and_oracle(name, shade_impl):
     fx = Fixture(name)
     out = replay_hip(fx, shade_impl)
     ref = replay_oracle(fx)
-    tol_g = 8e-3 if "dense" in name else TOL_GRAD
+    tol_g = 8e-3 if "dense" in name else (1e-3 if name.startswith("llff") else TOL_GRAD)  # ~4x the measured worst
     np.testing.assert_allclose(out["pose"].detach().cpu().numpy(), fx.arrays["mid.current_pose"], atol=2e-6)
     np.testing.assert_allclose(out["center"].detach().cpu().reshape(-1, 3).numpy(), fx.arrays["mid.center"], atol=5e-6)
     np.testing.assert_allclose(out["ray"].detach().cpu().reshape(-1, 3).numpy(), fx.arrays["mid.ray_dir"], atol=5e-6)
