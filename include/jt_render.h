@@ -321,6 +321,11 @@ int jt_loss_sum_forward(const float* render, const float* reg3, float w_render, 
                         float w_tv_color, float* total, void* stream);
 int jt_loss_sum_backward(const float* g_total, float w_render, float w_l1, float w_tv_density, float w_tv_color,
                          float* g_render, float* g_reg3, void* stream);
+/* The same with w4 = {w_render, w_l1, w_tv_density, w_tv_color} in DEVICE memory: a captured hipGraph keeps working while
+ * the host schedule changes the weights every iteration (LLFF: the TV weights decay per iteration, model/tensorf.py:441-447);
+ * the caller rewrites w4 with jt_poke in front of a replay. */
+int jt_loss_sum_forward_dyn(const float* render, const float* reg3, const float* w4, float* total, void* stream);
+int jt_loss_sum_backward_dyn(const float* g_total, const float* w4, float* g_render, float* g_reg3, void* stream);
 
 /* All regularisers of one scene in one call (replaces the loop bodies of model/tensorf.py:127-130):
  *   out3 = { density_L1(), TV_loss_density(TVLoss()), TV_loss_app(TVLoss()) }   (tensoRF.py:212-228).

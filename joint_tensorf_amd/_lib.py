@@ -98,6 +98,8 @@ SIGNATURES = {
     "jt_render_loss_backward": (I, [P, P, P, P, I, I, I, F, F, P, P, P, P]),
     "jt_loss_sum_forward": (I, [P, P, F, F, F, F, P, P]),
     "jt_loss_sum_backward": (I, [P, F, F, F, F, P, P, P]),
+    "jt_loss_sum_forward_dyn": (I, [P, P, P, P, P]),
+    "jt_loss_sum_backward_dyn": (I, [P, P, P, P, P]),
     "jt_reg_losses_forward": (I, [FP, P, I, I, I, I, P, P, P]),
     "jt_reg_losses_backward": (I, [FP, P, I, I, P, I, I, FP, I, P, P]),
     "jt_adam_step": (I, [P, I, F, F, F, P]),

@@ -114,9 +114,49 @@ __global__ void k_loss_sum_bwd(const float* __restrict__ g, float wr, float w0, 
   }
 }
 
+// the same with the four weights in device memory (a replayed hipGraph: the TV weights decay every iteration)
+__global__ void k_loss_sum_fwd_dyn(const float* __restrict__ render, const float* __restrict__ reg3,
+                                   const float* __restrict__ w, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float t = 0.f;
+    if (w[0] != 0.f) t += w[0] * render[0];
+    t += w[1] * reg3[0];
+    if (w[2] != 0.f) t += w[2] * reg3[1];
+    if (w[3] != 0.f) t += w[3] * reg3[2];
+    out[0] = t;
+  }
+}
+
+__global__ void k_loss_sum_bwd_dyn(const float* __restrict__ g, const float* __restrict__ w,
+                                   float* __restrict__ g_render, float* __restrict__ g_reg3) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float gg = g[0];
+    g_render[0] = gg * w[0];
+    g_reg3[0] = gg * w[1];
+    g_reg3[1] = gg * w[2];
+    g_reg3[2] = gg * w[3];
+  }
+}
+
 }  // namespace jt
 
 using namespace jt;
+
+extern "C" int jt_loss_sum_forward_dyn(const float* render, const float* reg3, const float* w4, float* total,
+                                       void* stream) {
+  if (!render || !reg3 || !w4 || !total) return JT_ERR_ARG;
+  hipLaunchKernelGGL(k_loss_sum_fwd_dyn, dim3(1), dim3(64), 0, (hipStream_t)stream, render, reg3, w4, total);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
+extern "C" int jt_loss_sum_backward_dyn(const float* g_total, const float* w4, float* g_render, float* g_reg3,
+                                        void* stream) {
+  if (!g_total || !w4 || !g_render || !g_reg3) return JT_ERR_ARG;
+  hipLaunchKernelGGL(k_loss_sum_bwd_dyn, dim3(1), dim3(64), 0, (hipStream_t)stream, g_total, w4, g_render, g_reg3);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
 
 extern "C" int jt_render_loss_forward(const float* rgb, const float* image, const int64_t* ray_idx,
                                       const uint8_t* edge_mask, int n_views, int rays_per_view, int n_pixels,

@@ -116,12 +116,24 @@ class GraphedTrainStep:
         m = self.model
         has = lambda o, k: (k in o) and o[k] is not None  # noqa: E731
         return (opt.nerf.ray_sampling_strategy == "all_view_rand_grid"
-                and opt.data.dataset == "blender" and bool(opt.nerf.setbg_opaque)
-                and not opt.optim.warmup_pose
+                and opt.data.dataset in ("blender", "llff")
+                and (not opt.optim.warmup_pose or m.it >= int(opt.optim.warmup_pose))   # past the pose-lr warm-up
                 and (not has(opt.optim, "grad_accum_iter") or int(opt.optim.grad_accum_iter) == 1)
                 and (not has(opt.optim, "pose_grad_accum_iter") or int(opt.optim.pose_grad_accum_iter) == 1)
+                and self._near_plane_settled(opt)
                 and isinstance(m.optim, VMAdam)
                 and ops.data_parallel_world() == 1 and not ops._DP["force"])
+
+    def _near_plane_settled(self, opt):
+        """LLFF: the near plane follows tensorf_near_plane_schedule (model/tensorf.py:230-232) and is a launch argument
+        of the march kernels; iterations are captured once the schedule has stopped moving (bat_llff_VM_MLP: from
+        progress 0.5 on, i.e. all of the large-grid stages)."""
+        if opt.data.dataset == "blender":
+            return True
+        from .model.bat_hip import interp_schedule
+        p = self.model.graph.nerf.progress_host
+        sch = opt.tensorf_near_plane_schedule
+        return interp_schedule(p, sch) == interp_schedule(min(1.0, p + 1.0 / opt.max_iter), sch) == interp_schedule(1.0, sch)
 
     def _blur_scheduled(self, opt):
         """True while the factor-blur schedule is above its cut-off (model/tensorf.py:208-220) whatever the random
@@ -142,9 +154,9 @@ class GraphedTrainStep:
         if has(opt, "edge_mask_on_render_loss") and opt.edge_mask_on_render_loss:
             edge_on = (it % 2 == 0) if (has(opt, "alternate_edge_loss") and opt.alternate_edge_loss) else True
         use_edge = bool(edge_on and it < opt.edge_mask_before_iter)
-        first = opt.train_schedule.update_alphamask_iters[0]
-        l1 = float(opt.loss_weight.L1.rest if it > first else opt.loss_weight.L1.init) if "L1" in opt.loss_weight else 0.0
-        weights = tuple((k, None if opt.loss_weight[k] is None else (l1 if k == "L1" else float(opt.loss_weight[k])))
+        # the VALUES of the four fused loss weights reach the graph through device memory (ops.LOSS_WEIGHTS_STATIC, poked
+        # per replay: LLFF's TV weights decay every iteration); which terms exist at all is structure
+        weights = tuple((k, None if opt.loss_weight[k] is None else (True if k == "L1" else float(opt.loss_weight[k]) != 0.0))
                         for k in sorted(opt.loss_weight))
         tf = g.nerf.tensorf
         # (the edge masks are rebuilt every 500 iterations, model/nerf.py:172-176: their address only counts while
@@ -183,6 +195,11 @@ class GraphedTrainStep:
             self.stats["eager"] += 1
             return self._eager(opt, var)
         g.it = m.it
+        tf = g.nerf.tensorf
+        if opt.data.dataset != "blender":  # what render_rays does per call (model/tensorf.py:230-232); settled by now
+            from .model.bat_hip import interp_schedule
+            tf.near_far[0] = interp_schedule(g.nerf.progress_host, opt.tensorf_near_plane_schedule)
+            opt.nerf.depth.range[0] = tf.near_far[0]
         batch_size = len(var.idx)
         step = g.lattice_step(opt, batch_size)
         epoch = (id(m.optim), ops.workspace_generation())
@@ -195,7 +212,8 @@ class GraphedTrainStep:
         shapes = self._lattice_shapes(int(opt.H), int(opt.W), step)
         complete = False  # (whether the blur is on is only known after the draw: always keep the state)
         if not self._blur_scheduled(opt):
-            complete = all((base[:6] + s + base[8:] + (None,)) in self.cache for s in shapes)
+            complete = all((base[:6] + s + base[8:] + (None, w_)) in self.cache for s in shapes
+                           for w_ in ((True,) if bool(opt.nerf.setbg_opaque) else (True, False)))
         np_state = None if complete else np.random.get_state()
         ox, oy = np.random.randint(step), np.random.randint(step)
         if g.lattice_rank is not None:
@@ -206,8 +224,12 @@ class GraphedTrainStep:
         # factor blur on: same graph for every (schedule value, random scale) -- the two tap vectors are static device
         # memory, rewritten below in front of the replay
         blur_key = None if blur[2] is None else (blur[2], int(blur[3]))
+        # white background: static flag, or the reference's CPU coin per training call (batBase.py:154) -- drawn here
+        # from the same generator; the eager fallback is handed the SAME draw
+        coin = None if bool(opt.nerf.setbg_opaque) else float(torch.rand((1,)))
+        wb = True if coin is None else coin < 0.5
         nx, ny = len(range(ox, opt.W, step)), len(range(oy, opt.H, step))
-        sig = base[:6] + (ny, nx) + base[8:] + (blur_key,)
+        sig = base[:6] + (ny, nx) + base[8:] + (blur_key, wb)
         e = self.cache.get(sig)
         if e is None:
             if len(self.seen) > 4096:
@@ -217,19 +239,19 @@ class GraphedTrainStep:
             if n <= self.min_repeats or not fits:
                 np.random.set_state(np_state)
                 self.stats["eager"] += 1
-                return self._eager(opt, var)
+                return self._eager(opt, var, coin)
             if os.environ.get("JT_GRAPH_DEBUG") == "1" and self.cache:
                 near = min(self.cache, key=lambda k: sum(a != b for a, b in zip(k, sig)))
                 print("graphed: capture #%d at it %d, differs from the nearest graph in fields %s"
                       % (self.stats["captured"] + 1, m.it, [i for i, (a, b) in enumerate(zip(near, sig)) if a != b]),
                       flush=True)
-            e = self._capture(opt, var, sig, ny, nx, step, blur)
+            e = self._capture(opt, var, sig, ny, nx, step, blur, coin)
             if (id(m.optim), ops.workspace_generation()) != self.epoch or e is None:
                 # capture is not allowed to move anything; if it did, start over on the eager path
                 self._drop_all()
                 np.random.set_state(np_state)
                 self.stats["eager"] += 1
-                return self._eager(opt, var)
+                return self._eager(opt, var, coin)
             if len(self.cache) >= self.max_graphs:  # least recently replayed graph goes (its memory returns to the pool)
                 del self.cache[min(self.cache, key=lambda k: self.cache[k].last_used)]
             self.cache[sig] = e
@@ -239,24 +261,44 @@ class GraphedTrainStep:
         ops.poke_words(e.off, [ox, oy])
         if blur_key is not None:
             self._poke_taps(opt, blur)
+        ops.poke_floats(self._loss_weights(opt), list(m.fused_loss_weights(opt)))
         m.optim.prepare_step(e.stepped)
         e.graph.replay()
         self.stats["replayed"] += 1
+        pg = m.optim_pose.param_groups[0]
+        if opt.optim.warmup_pose:  # model/bat.py:98-100,108-110 (a factor of one past the warm-up, which eligibility ensures)
+            pg["lr_orig"] = pg["lr"]
+            pg["lr"] *= min(1, m.it / opt.optim.warmup_pose)
         m.it += 1
         w = g.se3_refine.weight
         w.grad = e.pose_grad
         m.optim_pose.step()
         w.grad = None
+        if opt.optim.warmup_pose:
+            pg["lr"] = pg["lr_orig"]
         if m.sched_pose is not None:
             m.sched_pose.step()
         g.nerf.set_progress(m.it / opt.max_iter)
         self.last_var = e.var
         return e.loss
 
-    def _eager(self, opt, var):
+    def _loss_weights(self, opt):
+        """static [4] device tensor of the fused loss weights (ops.LossSumDyn)"""
+        if getattr(self, "_lw", None) is None:
+            self._lw = torch.zeros(4, device=opt.device, dtype=torch.float32)
+        return self._lw
+
+    def _eager(self, opt, var, coin=None):
         nerf = self.model.graph.nerf
         key = (tuple(nerf.resolution), int(nerf.n_samples))  # before the step: it may end with an upsampling
-        loss = self.model.train_iteration(opt, var)
+        tf = nerf.tensorf
+        prev = tf.coin_override
+        if coin is not None:
+            tf.coin_override = coin   # the white-background draw this iteration already consumed
+        try:
+            loss = self.model.train_iteration(opt, var)
+        finally:
+            tf.coin_override = prev
         self.last_var = var
         if "rgb" in var:
             self.eager_rays[key] = max(self.eager_rays.get(key, 0), var.rgb.shape[0] * var.rgb.shape[1])
@@ -281,7 +323,7 @@ class GraphedTrainStep:
         ops.poke_floats(buf.view(-1), td.tolist() + tc.tolist())
         return buf
 
-    def _capture(self, opt, var, sig, ny, nx, step, blur=(None, None, None, None)):
+    def _capture(self, opt, var, sig, ny, nx, step, blur=(None, None, None, None), coin=None):
         m, g = self.model, self.model.graph
         dev = opt.device
         e = _Entry()
@@ -289,6 +331,10 @@ class GraphedTrainStep:
         if blur[2] is not None:
             buf = self._poke_taps(opt, blur)
             tf.taps_static = (buf[0], buf[1])
+        coin_prev = tf.coin_override
+        if coin is not None:
+            tf.coin_override = coin
+        ops.LOSS_WEIGHTS_STATIC = self._loss_weights(opt)
         e.off = torch.zeros(2, device=dev, dtype=torch.int32)
         # allocated OUTSIDE the capture: the entry must keep them alive for as long as the graph exists
         e.base_x = base_x = torch.arange(nx, device=dev) * step
@@ -335,6 +381,8 @@ class GraphedTrainStep:
             ops.USE_AUX_STREAM = aux_was
             g.lattice_override = None
             tf.taps_static = None
+            tf.coin_override = coin_prev
+            ops.LOSS_WEIGHTS_STATIC = None
             np.random.set_state(np_state)
         if self.pool is None:
             self.pool = e.graph.pool()

@@ -526,11 +526,17 @@ class Model(torch.nn.Module):
             if key == "all" or (opt.loss_weight[key] is not None and float(opt.loss_weight[key]) != 0.0):
                 return None
         tf = self.graph.nerf.tensorf
+        return ops.loss_sum(loss.render, tf._reg(), *self.fused_loss_weights(opt, render_scale))
+
+    def fused_loss_weights(self, opt, render_scale=None):
+        """(w_render, w_L1, w_TV_density, w_TV_color) of this iteration's weighted loss sum (model/tensorf.py:31-47)"""
+        if render_scale is None:
+            render_scale = float(getattr(self, "render_loss_scale", 1.0))
         first = opt.train_schedule.update_alphamask_iters[0]
         w_l1 = float(opt.loss_weight.L1.rest if self.it > first else opt.loss_weight.L1.init)
         w_tvd = float(opt.loss_weight.TV_density or 0.0) * float(getattr(self.graph.tvloss, "TVLoss_weight", 1))
         w_tvc = float(opt.loss_weight.TV_color or 0.0) * float(getattr(self.graph.tvloss, "TVLoss_weight", 1))
-        return ops.loss_sum(loss.render, tf._reg(), float(opt.loss_weight.render) * render_scale, w_l1, w_tvd, w_tvc)
+        return float(opt.loss_weight.render) * render_scale, w_l1, w_tvd, w_tvc
 
     def train_iteration(self, opt, var):
         """One optimisation step (model/bat.py:96-116 around model/base.py:154-172)."""

@@ -799,7 +799,37 @@ class LossSum(torch.autograd.Function):
         return g_render.reshape(ctx.render_shape), g_reg, None, None, None, None
 
 
+class LossSumDyn(torch.autograd.Function):
+    """LossSum with the four weights read from device memory (`w4`, rewritten by the caller with poke_floats): the
+    launch arguments of a captured hipGraph stay the same while the host schedule changes the weights."""
+
+    @staticmethod
+    def forward(ctx, render, reg3, w4):
+        r = render.detach().reshape(1).float()
+        q = reg3.detach().contiguous().float()
+        out = torch.empty(1, device=r.device, dtype=torch.float32)
+        check(lib.jt_loss_sum_forward_dyn(ptr(r), ptr(q), ptr(w4), ptr(out), _stream()), "jt_loss_sum_forward_dyn")
+        ctx.w4 = w4
+        ctx.render_shape = render.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        gc = g.contiguous().float().reshape(1)
+        g_render = torch.empty(1, device=gc.device, dtype=torch.float32)
+        g_reg = torch.empty(3, device=gc.device, dtype=torch.float32)
+        check(lib.jt_loss_sum_backward_dyn(ptr(gc), ptr(ctx.w4), ptr(g_render), ptr(g_reg), _stream()),
+              "jt_loss_sum_backward_dyn")
+        return g_render.reshape(ctx.render_shape), g_reg, None
+
+
+# While this is a device tensor [4] (set by graphed.GraphedTrainStep around a capture), loss_sum reads its weights from it
+LOSS_WEIGHTS_STATIC = None
+
+
 def loss_sum(render, reg3, w_render, w_l1, w_tv_density, w_tv_color):
+    if LOSS_WEIGHTS_STATIC is not None:
+        return LossSumDyn.apply(render, reg3, LOSS_WEIGHTS_STATIC)
     return LossSum.apply(render, reg3, float(w_render), float(w_l1), float(w_tv_density), float(w_tv_color))
 
 

@@ -214,3 +214,86 @@ def test_graph_replayed_test_time_pose_optimisation_matches_eager():
         torch.testing.assert_close(se3_g, se3_e, rtol=1e-4, atol=1e-7)
         torch.testing.assert_close(pr_g, pr_e, rtol=1e-5, atol=1e-7)
         torch.testing.assert_close(se3_g, se3_r, rtol=0, atol=0.25 * float(se3_r.abs().max()))
+
+
+def _build_llff(it0):
+    from joint_tensorf_amd.model import bat_hip
+    from joint_tensorf_amd.options import make_options
+    from joint_tensorf_amd.synthetic import make_views
+    B = 3
+    opt = make_options("bat_llff_VM_MLP", device=DEV, data=dict(image_size=[30, 40], num_views=B),
+                       train_schedule=dict(n_voxel_init=2200, n_rays_init=90, n_rays_rest=90,
+                                           upsample_iters=[10 ** 9]), nerf=dict(n_rays=90))
+    torch.manual_seed(0)
+    model = bat_hip.Model(opt)
+    model.build_networks(opt, n_views=B)
+    model.setup_optimizer(opt)
+    with torch.no_grad():
+        model.graph.se3_refine.weight.copy_(0.01 * torch.randn(B, 6, device=DEV))
+    var0 = make_views(opt, B, seed=3, device=DEV)
+    model.it = it0
+    model.graph.nerf.set_progress(it0 / opt.max_iter)
+    S = model.graph.nerf.n_samples    # NDC: one jitter row shared by all rays (tensorBase.py:554-571)
+    model.graph.nerf.tensorf.jitter_override = torch.rand(1, S, generator=torch.Generator().manual_seed(17)).to(DEV)
+    return opt, model, var0
+
+
+def test_graph_replay_of_llff_iterations_is_bit_identical_to_eager():
+    """bat_llff_VM_MLP past the point where its near-plane schedule has settled (progress 0.5): NDC rays, WeakView MLP,
+    the white-background COIN of every training call (two graph variants, the draw handed to whichever path runs), TV
+    weights that decay every iteration (read from device memory inside the graph), pose-lr warm-up bookkeeping.
+    Run in JT_DETERMINISTIC mode, where neither path has order-dependent sums: every loss term of every iteration and
+    every parameter after 20 iterations must be EXACTLY equal between the eager loop and the hipGraph-replayed one
+    (in the default mode the two drift apart like two eager runs do: Adam turns atomics-order noise in a near-zero
+    gradient into a full +-lr step)."""
+    from joint_tensorf_amd._lib import lib
+    from joint_tensorf_amd.graphed import GraphedTrainStep
+    from joint_tensorf_amd.options import Opt
+    K, it0 = 20, 30000
+    res = []
+    prev = lib.jt_set_deterministic(1)
+    try:
+        for use_graph in (False, True):
+            opt, model, var0 = _build_llff(it0)
+            np.random.seed(5)
+            torch.manual_seed(123)   # the coin stream
+            stepper = GraphedTrainStep(model, min_repeats=0) if use_graph else None
+            losses, tvw = [], []
+            for k in range(K):
+                model.before_iteration(opt)
+                var = Opt(dict(var0))
+                loss = stepper.train_iteration(opt, var, force_eager=k < 2) if use_graph else model.train_iteration(opt, var)
+                losses.append([float(loss[t].detach()) for t in ("all", "render", "L1", "TV_density", "TV_color")])
+                model.after_iteration(opt)
+                tvw.append(float(opt.loss_weight.TV_density))
+            sd = {k_: v.detach().clone() for k_, v in model.graph.state_dict().items()}
+            res.append((np.array(losses), sd, stepper.stats if use_graph else None, float(torch.rand((1,))), tvw,
+                        None if stepper is None else (stepper._lw.cpu().tolist(), list(model.fused_loss_weights(opt)))))
+    finally:
+        lib.jt_set_deterministic(prev)
+    (l_e, sd_e, _, r_e, tv_e, _), (l_g, sd_g, stats, r_g, tv_g, lw) = res
+    assert stats["replayed"] >= K - 8 and stats["captured"] >= 2, stats
+    assert r_e == r_g and tv_e == tv_g and tv_e[0] > tv_e[-1] > 0   # same coin stream consumed, TV weights decaying
+    np.testing.assert_array_equal(l_g, l_e)
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_g[k]), k
+    # the device-side loss weights of the last replay are the host schedule's of that iteration (one decay step behind now)
+    dec = model.graph.nerf.lr_decay_factor
+    np.testing.assert_allclose(lw[0][2], lw[1][2] / dec, rtol=1e-6)
+
+
+@pytest.mark.parametrize("it0,blur", [(9000, False), (0, True)])
+def test_graph_replay_is_bit_identical_to_eager_in_deterministic_mode(it0, blur):
+    """The Blender trajectory of test_graph_replay_follows_the_eager_trajectory in JT_DETERMINISTIC mode: exact equality."""
+    from joint_tensorf_amd._lib import lib
+    prev = lib.jt_set_deterministic(1)
+    try:
+        l_e, sd_e, _, rs_e = _run(False, 14, it0, blur)
+        l_g, sd_g, stats, rs_g = _run(True, 14, it0, blur)
+    finally:
+        lib.jt_set_deterministic(prev)
+    assert stats["replayed"] >= 8, stats
+    assert (rs_e == rs_g).all()
+    np.testing.assert_array_equal(l_g, l_e)
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_g[k]), k
