@@ -336,6 +336,7 @@ def run_extras():
              ("stage4_blurred_it9000", ["--stage", "4", "--it", "9000"], {}),
              ("parent_yaml_299cube_4096rays", ["--n-voxel-final", "27000000", "--n-rays", "4096"], {}),
              ("llff_final_grid", ["--config", "bat_llff_VM_MLP"], {}),
+             ("llff_final_grid_it30000_hipgraph", ["--config", "bat_llff_VM_MLP", "--it", "30000"], {"JT_GRAPH": "1"}),
              ("blobs_eager", ["--scene", "blobs"], {}),
              ("blobs_hipgraph", ["--scene", "blobs"], {"JT_GRAPH": "1"})]
     out = {}
