@@ -252,7 +252,10 @@ def instep_roofline(timers, n_comp_app, n_comp_density=16):
     return out
 
 
-def pmc_traffic_instep(roof):
+ATOMIC_SEGMENTS_PER_S = 20.9e9   # measured: tools/atomic_rate.hip on MI355X (profiles/round2_atomic_rate.txt)
+
+
+def pmc_traffic_instep(roof, hidden=None):
     """HBM-side bytes per launch of k_shade_bwd from the committed rocprofv3 --pmc passes over THIS command (separate
     FETCH_SIZE / WRITE_SIZE runs of `bench.py --no-cpu-baseline --no-probe --no-torch-baseline --no-extras`,
     tools/pmc_traffic.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), per shaded sample, scaled
@@ -264,8 +267,19 @@ def pmc_traffic_instep(roof):
         n = roof["samples_per_launch"]
         if abs(n - rec["process_samples_per_launch"]) > 0.1 * n:
             return {"traffic": None}  # another workload than the one the counters were collected on
-        return {"traffic": k["hbm_bytes_per_sample"] * n, "traffic_unit": "bytes/launch",
-                "traffic_source": "profiles/round2_pmc_traffic_instep.json", "traffic_detail": rec}
+        out = {"traffic": k["hbm_bytes_per_sample"] * n, "traffic_unit": "bytes/launch",
+               "traffic_source": "profiles/round2_pmc_traffic_instep.json", "traffic_detail": rec}
+        if hidden:
+            # the second bound of a scatter kernel: the chip retires ~20.9 G float-atomic 64-byte segments per second
+            # whatever the access pattern (tools/atomic_rate.hip, profiles/round2_atomic_rate.txt).  Segments of a launch =
+            # (WRITE_SIZE bytes - the gradient records and coordinate gradients the kernel stores) / 64.
+            stored = 4 * (3 + 2 * hidden + 32) + 12   # record rows GO, G2, G1, GF + g_xyz, bytes per sample
+            seg = (k["write_bytes_per_launch"] / rec["process_samples_per_launch"] - stored) / 64.0 * n
+            out["atomic_unit"] = {"segments_per_launch": seg, "rate_segments_per_s": ATOMIC_SEGMENTS_PER_S,
+                                  "floor_ms": seg / ATOMIC_SEGMENTS_PER_S * 1e3,
+                                  "frac": seg / ATOMIC_SEGMENTS_PER_S * 1e3 / roof["launch_ms"],
+                                  "source": "profiles/round2_atomic_rate.txt (rate), WRITE_SIZE pass (segments)"}
+        return out
     except Exception:
         return {"traffic": None}
 
@@ -609,7 +623,7 @@ def main():
                     alls = [int(off[-1]) for k, a, b, off in all_timers if k == "bwd"]
                     out["roofline"]["process_launches"] = len(alls)
                     out["roofline"]["process_samples_per_launch"] = sum(alls) / max(len(alls), 1)
-                    out["roofline"].update(pmc_traffic_instep(out["roofline"]))
+                    out["roofline"].update(pmc_traffic_instep(out["roofline"], int(tf_.renderModule.weights()[2].shape[0])))
                     if "fwd" in ins:
                         out["roofline"]["forward"] = ins["fwd"]
                     if "march_bwd" in ins:
