@@ -419,7 +419,7 @@ constexpr int kWalkRecW = 3 * kRecWords + 4;  // per sample: three plane records
 
 __device__ inline int sel3(int i, int a, int b, int c) { return i == 0 ? a : (i == 1 ? b : c); }
 
-template <int CD>
+template <int CD, bool DET>
 __global__ __launch_bounds__(256, 4) void k_march_bwd_walk(Dev D, JtFactors G, const float* __restrict__ rays_o,
                                                         const float* __restrict__ rays_d,
                                                         const float* __restrict__ jitter,
@@ -448,9 +448,9 @@ __global__ __launch_bounds__(256, 4) void k_march_bwd_walk(Dev D, JtFactors G, c
   load_ray(D, rays_o, rays_d, jitter, tmin_in, ray, r);
   const size_t row = (size_t)ray * D.S;
   float* rec = s_rec[grp];
-  RecWalker<NCH, CD> wk[3];
+  RecWalker<NCH, CD, DET ? 1 : 0> wk[3];
 #pragma unroll
-  for (int pl = 0; pl < 3; ++pl) wk[pl].init(G.density_plane[pl], G.density_line[pl], cl, rays_fixed != nullptr);
+  for (int pl = 0; pl < 3; ++pl) wk[pl].init(G.density_plane[pl], G.density_line[pl], cl, DET);
   float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
 
   for (int kb = k0; kb < k1; kb += kWalkSub) {
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256, 4) void k_march_bwd_walk(Dev D, JtFactors G, c
     go[a] = row16_sum(go[a]);
     gd[a] = row16_sum(gd[a]);
   }
-  if (rays_fixed) {  // JT_DETERMINISTIC: the runs of a ray meet in 64-bit fixed point, added to g_rays by k_rays_fixed_add
+  if (DET) {  // JT_DETERMINISTIC: the runs of a ray meet in 64-bit fixed point, added to g_rays by k_rays_fixed_add
     if (cl < 6)
       fixed_add(rays_fixed + (size_t)ray * 6 + cl, cl == 0 ? go[0] : cl == 1 ? go[1] : cl == 2 ? go[2]
                                                                   : cl == 3 ? gd[0] : cl == 4 ? gd[1] : gd[2]);
@@ -745,21 +745,20 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
   const int runs = (D.S + kWalkRun - 1) / kWalkRun;
   const long items = (long)n_rays * runs;
   const int blocks = (int)((items + 15) / 16);
-  if (D.Cd <= 16) {
-    if (D.Cd == 16)
-      hipLaunchKernelGGL(k_march_bwd_walk<16>, dim3(blocks), dim3(256), 0, st, D, GF, rays_o, rays_d, jitter,
-                         zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d, rays_fixed);
-    else if (D.Cd == 8)
-      hipLaunchKernelGGL(k_march_bwd_walk<8>, dim3(blocks), dim3(256), 0, st, D, GF, rays_o, rays_d, jitter,
-                         zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d, rays_fixed);
-    else
-      return JT_ERR_UNSUPPORTED;
-  } else if (D.Cd == 32) {
-    hipLaunchKernelGGL(k_march_bwd_walk<32>, dim3(blocks), dim3(256), 0, st, D, GF, rays_o, rays_d, jitter,
-                       zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d, rays_fixed);
-  } else {
-    return JT_ERR_UNSUPPORTED;
-  }
+#define JT_WALK(CD_)                                                                                              \
+  do {                                                                                                           \
+    if (rays_fixed)                                                                                              \
+      hipLaunchKernelGGL((k_march_bwd_walk<CD_, true>), dim3(blocks), dim3(256), 0, st, D, GF, rays_o, rays_d,   \
+                         jitter, zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d, rays_fixed); \
+    else                                                                                                         \
+      hipLaunchKernelGGL((k_march_bwd_walk<CD_, false>), dim3(blocks), dim3(256), 0, st, D, GF, rays_o, rays_d,  \
+                         jitter, zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d, rays_fixed); \
+  } while (0)
+  if (D.Cd == 16) JT_WALK(16);
+  else if (D.Cd == 8) JT_WALK(8);
+  else if (D.Cd == 32) JT_WALK(32);
+  else return JT_ERR_UNSUPPORTED;
+#undef JT_WALK
   JT_LAUNCH_CHECK();
   if (rays_fixed) {
     hipLaunchKernelGGL(k_rays_fixed_add, dim3((n_rays * 6 + 255) / 256), dim3(256), 0, st, rays_fixed, n_rays, g_rays_o,

@@ -110,7 +110,9 @@ __device__ inline float row16_sum(float v) {
 }
 
 // Run-length accumulator of one plane + its line, driven by step records.
-template <int NCH, int CA>
+// FX: 0 = float atomics, 1 = JT_DETERMINISTIC fixed point, 2 = chosen at run time by init()'s flag (a kernel that is
+// instantiated once; the density walk, short of registers, is instantiated per mode)
+template <int NCH, int CA, int FX = 2>
 struct RecWalker {
   float acc[4][NCH];   // plane accumulators, parity slots
   float accl[2][NCH];  // line accumulators, parity slots
@@ -155,7 +157,7 @@ struct RecWalker {
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       if (base != nullptr && live[k] && JT_FLUSH_COND(a[k])) {
-        if (fixed)  // byte offset of a float element -> the same element of the 64-bit shadow buffer
+        if (FX == 1 || (FX == 2 && fixed))  // byte offset of a float element -> the same element of the 64-bit shadow buffer
           fixed_add(reinterpret_cast<long long*>(reinterpret_cast<char*>(base) + 2 * (size_t)(off + ck[k])), a[k]);
         else
           atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (off + ck[k])), a[k]);
