@@ -619,6 +619,10 @@ def main():
                 ins = instep_roofline(timers or [], tf_.app_n_comp[0], tf_.density_n_comp[0])
                 if "bwd" in ins:
                     out["roofline"] = ins["bwd"]
+                    # the composited-sample rate counts nominal samples (rays x S); the samples that are
+                    # really shaded (in the box and above the weight threshold), read from the launches' device-side counts
+                    out["config"]["Msamples_per_s_shaded"] = (ins["bwd"]["samples_per_launch"] * ins["bwd"]["launches"]
+                                                              * world / dt / 1e6)
                     # every k_shade_bwd launch of the process (priming and warm-up included): what a profiler sees
                     alls = [int(off[-1]) for k, a, b, off in all_timers if k == "bwd"]
                     out["roofline"]["process_launches"] = len(alls)
