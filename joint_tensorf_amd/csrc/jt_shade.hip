@@ -542,11 +542,15 @@ __device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, c
   const float my_scale = ((cl == 0) ? 0.5f * (float)(D.pw[pl] - 1) : (cl == 1) ? 0.5f * (float)(D.ph[pl] - 1)
                                                                                 : 0.5f * (float)(D.ll[pl] - 1)) *
                          D.inv[my_axis];
-  const float* rec0 = recs + (grp * 8) * kRecWords;
+  // odd groups walk their eight samples in DESCENDING order: groups 0 | 1 and 2 | 3 then end on neighbouring samples
+  // (7 | 8, 23 | 24) and merge their last texels before the flush (RecWalker::finish_pair)
+  const bool down = grp & 1;
+  const float* rec0 = recs + (grp * 8 + (down ? 7 : 0)) * kRecWords;
+  const int rstep = down ? -kRecWords : kRecWords;
   TapBuf<NCH> bufA, bufB;
   auto step = [&](TapBuf<NCH>& tv, int q) {
-    const int sidx = grp * 8 + q;
-    const float* rec = rec0 + q * kRecWords;
+    const int sidx = grp * 8 + (down ? 7 - q : q);
+    const float* rec = rec0 + q * rstep;
     wk.advance(rec);
     float g[NCH];
 #pragma unroll
@@ -561,22 +565,22 @@ __device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, c
   // the factor values are fetched two steps ahead of their use (three rotating buffers, steps fully unrolled)
   TapBuf<NCH> bufC;
   wk.load(bufA, P, Ln, rec0);
-  wk.load(bufB, P, Ln, rec0 + kRecWords);
-  wk.load(bufC, P, Ln, rec0 + 2 * kRecWords);
+  wk.load(bufB, P, Ln, rec0 + rstep);
+  wk.load(bufC, P, Ln, rec0 + 2 * rstep);
   step(bufA, 0);
-  wk.load(bufA, P, Ln, rec0 + 3 * kRecWords);
+  wk.load(bufA, P, Ln, rec0 + 3 * rstep);
   step(bufB, 1);
-  wk.load(bufB, P, Ln, rec0 + 4 * kRecWords);
+  wk.load(bufB, P, Ln, rec0 + 4 * rstep);
   step(bufC, 2);
-  wk.load(bufC, P, Ln, rec0 + 5 * kRecWords);
+  wk.load(bufC, P, Ln, rec0 + 5 * rstep);
   step(bufA, 3);
-  wk.load(bufA, P, Ln, rec0 + 6 * kRecWords);
+  wk.load(bufA, P, Ln, rec0 + 6 * rstep);
   step(bufB, 4);
-  wk.load(bufB, P, Ln, rec0 + 7 * kRecWords);
+  wk.load(bufB, P, Ln, rec0 + 7 * rstep);
   step(bufC, 5);
   step(bufA, 6);
   step(bufB, 7);
-  wk.finish();
+  wk.finish_pair(grp);
 }
 
 template <class C>
@@ -757,9 +761,12 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
       // the product gradients
       float* recs = tp + 48 * 33;
       if (h == 0) {
-        const int jp = (j & 7) ? j - 1 : j;  // previous sample of the same 8-sample run
+        // previous sample of the same 8-sample run in WALK order: runs 1 and 3 of a tile are walked downwards
+        const bool down = (j >> 3) & 1;
+        const bool has_prev = down ? (j & 7) != 7 : (j & 7) != 0;
+        const int jp = has_prev ? (down ? j + 1 : j - 1) : j;
         make_step_rec(geo[j * 4 + kM0(pl)], geo[j * 4 + kM1(pl)], geo[j * 4 + kV(pl)], geo[jp * 4 + kM0(pl)],
-                      geo[jp * 4 + kM1(pl)], geo[jp * 4 + kV(pl)], (j & 7) != 0, D.ph[pl], D.pw[pl], D.ll[pl], C::CA,
+                      geo[jp * 4 + kM1(pl)], geo[jp * 4 + kV(pl)], has_prev, D.ph[pl], D.pw[pl], D.ll[pl], C::CA,
                       recs + j * kRecWords);
       }
       wave_lds_sync();

@@ -225,6 +225,32 @@ struct RecWalker {
       ail += glv * (sgz * (tv.v[k] - tv.u[k]));
     }
   }
+  // Two 16-lane groups whose runs END on neighbouring samples (lanes l and l ^ 16) meet before they flush: a parity
+  // slot that stands for the same texel in both -- all four when they end in the same cell, two for edge-adjacent
+  // cells -- is handed from the even group to the odd one, which writes the sum with one atomic instead of two.
+  __device__ inline void finish_pair(int grp) {
+    if (gP == nullptr) return;
+    const bool taker = grp & 1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool same = (unsigned)__shfl_xor((int)o[c], 16) == o[c];
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const float pa = __shfl_xor(acc[c][k], 16);
+        acc[c][k] = same ? (taker ? acc[c][k] + pa : 0.f) : acc[c][k];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const bool same = (unsigned)__shfl_xor((int)lo[c], 16) == lo[c];
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const float pa = __shfl_xor(accl[c][k], 16);
+        accl[c][k] = same ? (taker ? accl[c][k] + pa : 0.f) : accl[c][k];
+      }
+    }
+    finish();
+  }
   __device__ inline void finish() {
     if (gP == nullptr) return;
     flush(gP, o[0], acc[0]);
