@@ -299,6 +299,16 @@ int jt_render_loss_forward(const float* rgb, const float* image, const int64_t* 
 int jt_render_loss_backward(const float* rgb, const float* image, const int64_t* ray_idx, const uint8_t* edge_mask,
                             int n_views, int rays_per_view, int n_pixels, float edge_factor, float non_edge_factor,
                             const float* acc4, const float* g_loss, float* g_rgb, void* stream);
+/* The same with the supervising buffers named by DEVICE memory: slots[0] = address of the image buffer, slots[1] = address
+ * of the edge-mask buffer (read only when with_edge_mask != 0).  The reference picks one of five blur scales of the
+ * ground-truth images per iteration (model/nerf.py:209-227); a captured hipGraph stays the same for all of them when the
+ * caller rewrites `slots` with jt_poke in front of a replay. */
+int jt_render_loss_forward_ind(const float* rgb, const uint64_t* slots, const int64_t* ray_idx, int with_edge_mask,
+                               int n_views, int rays_per_view, int n_pixels, float edge_factor, float non_edge_factor,
+                               float* acc4, float* loss, void* stream);
+int jt_render_loss_backward_ind(const float* rgb, const uint64_t* slots, const int64_t* ray_idx, int with_edge_mask,
+                                int n_views, int rays_per_view, int n_pixels, float edge_factor, float non_edge_factor,
+                                const float* acc4, const float* g_loss, float* g_rgb, void* stream);
 
 /* Non-finite guard without a host sync: ORs items[k].bit into *status_word (device memory, caller-owned, cleared by
  * the caller) for every item whose `data[0..n)` holds a NaN or an infinity; one launch for up to JT_FINITE_MAX

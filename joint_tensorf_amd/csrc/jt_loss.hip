@@ -20,8 +20,13 @@ __global__ void k_loss_zero(float* __restrict__ p, int n) {
 __global__ __launch_bounds__(256) void k_render_loss_fwd(const float* __restrict__ rgb, const float* __restrict__ image,
                                                          const int64_t* __restrict__ ray_idx,
                                                          const uint8_t* __restrict__ mask, int B, int r, int HW,
-                                                         float* __restrict__ acc) {
+                                                         float* __restrict__ acc,
+                                                         const unsigned long long* __restrict__ slots) {
   __shared__ float red[4][4];
+  if (slots) {  // the supervising buffers are named by device memory (a replayed hipGraph, jt_render_loss_forward_ind)
+    image = reinterpret_cast<const float*>(slots[0]);
+    if (mask) mask = reinterpret_cast<const uint8_t*>(slots[1]);
+  }
   const long n = (long)B * r * 3;
   float s0 = 0.f, c0 = 0.f, s1 = 0.f, c1 = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -69,7 +74,12 @@ __global__ __launch_bounds__(256) void k_render_loss_bwd(const float* __restrict
                                                          const int64_t* __restrict__ ray_idx,
                                                          const uint8_t* __restrict__ mask, int B, int r, int HW,
                                                          const float* __restrict__ acc, float fe, float fne,
-                                                         const float* __restrict__ g, float* __restrict__ g_rgb) {
+                                                         const float* __restrict__ g, float* __restrict__ g_rgb,
+                                                         const unsigned long long* __restrict__ slots) {
+  if (slots) {
+    image = reinterpret_cast<const float*>(slots[0]);
+    if (mask) mask = reinterpret_cast<const uint8_t*>(slots[1]);
+  }
   const long n = (long)B * r * 3;
   const float gg = g[0];
   const float ke = (mask ? fe : 1.f) * 2.f / acc[1], kne = mask ? fne * 2.f / acc[3] : 0.f;
@@ -158,10 +168,9 @@ extern "C" int jt_loss_sum_backward_dyn(const float* g_total, const float* w4, f
   return JT_OK;
 }
 
-extern "C" int jt_render_loss_forward(const float* rgb, const float* image, const int64_t* ray_idx,
-                                      const uint8_t* edge_mask, int n_views, int rays_per_view, int n_pixels,
-                                      float edge_factor, float non_edge_factor, float* acc4, float* loss,
-                                      void* stream) {
+static int render_loss_forward(const float* rgb, const float* image, const int64_t* ray_idx, const uint8_t* edge_mask,
+                               int n_views, int rays_per_view, int n_pixels, float edge_factor, float non_edge_factor,
+                               float* acc4, float* loss, const uint64_t* slots, void* stream) {
   if (!rgb || !image || !ray_idx || !acc4 || !loss || n_views < 1 || rays_per_view < 1 || n_pixels < 1)
     return JT_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -171,7 +180,7 @@ extern "C" int jt_render_loss_forward(const float* rgb, const float* image, cons
   int blocks = (int)min((n + 255) / 256, 512L);
   if (jt_deterministic()) blocks = 1;  // one workgroup: the four sums have a fixed order
   hipLaunchKernelGGL(k_render_loss_fwd, dim3(blocks), dim3(256), 0, st, rgb, image, ray_idx, edge_mask, n_views,
-                     rays_per_view, n_pixels, acc4);
+                     rays_per_view, n_pixels, acc4, (const unsigned long long*)slots);
   JT_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_render_loss_final, dim3(1), dim3(64), 0, st, (const float*)acc4, edge_factor,
                      non_edge_factor, edge_mask ? 1 : 0, loss);
@@ -179,18 +188,56 @@ extern "C" int jt_render_loss_forward(const float* rgb, const float* image, cons
   return JT_OK;
 }
 
-extern "C" int jt_render_loss_backward(const float* rgb, const float* image, const int64_t* ray_idx,
-                                       const uint8_t* edge_mask, int n_views, int rays_per_view, int n_pixels,
-                                       float edge_factor, float non_edge_factor, const float* acc4,
-                                       const float* g_loss, float* g_rgb, void* stream) {
+static int render_loss_backward(const float* rgb, const float* image, const int64_t* ray_idx, const uint8_t* edge_mask,
+                                int n_views, int rays_per_view, int n_pixels, float edge_factor, float non_edge_factor,
+                                const float* acc4, const float* g_loss, float* g_rgb, const uint64_t* slots,
+                                void* stream) {
   if (!rgb || !image || !ray_idx || !acc4 || !g_loss || !g_rgb || n_views < 1 || rays_per_view < 1 || n_pixels < 1)
     return JT_ERR_ARG;
   long n = (long)n_views * rays_per_view * 3;
   int blocks = (int)min((n + 255) / 256, 512L);
   hipLaunchKernelGGL(k_render_loss_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rgb, image, ray_idx,
-                     edge_mask, n_views, rays_per_view, n_pixels, acc4, edge_factor, non_edge_factor, g_loss, g_rgb);
+                     edge_mask, n_views, rays_per_view, n_pixels, acc4, edge_factor, non_edge_factor, g_loss, g_rgb,
+                     (const unsigned long long*)slots);
   JT_LAUNCH_CHECK();
   return JT_OK;
+}
+
+extern "C" int jt_render_loss_forward(const float* rgb, const float* image, const int64_t* ray_idx,
+                                      const uint8_t* edge_mask, int n_views, int rays_per_view, int n_pixels,
+                                      float edge_factor, float non_edge_factor, float* acc4, float* loss,
+                                      void* stream) {
+  return render_loss_forward(rgb, image, ray_idx, edge_mask, n_views, rays_per_view, n_pixels, edge_factor,
+                             non_edge_factor, acc4, loss, nullptr, stream);
+}
+
+extern "C" int jt_render_loss_backward(const float* rgb, const float* image, const int64_t* ray_idx,
+                                       const uint8_t* edge_mask, int n_views, int rays_per_view, int n_pixels,
+                                       float edge_factor, float non_edge_factor, const float* acc4,
+                                       const float* g_loss, float* g_rgb, void* stream) {
+  return render_loss_backward(rgb, image, ray_idx, edge_mask, n_views, rays_per_view, n_pixels, edge_factor,
+                              non_edge_factor, acc4, g_loss, g_rgb, nullptr, stream);
+}
+
+extern "C" int jt_render_loss_forward_ind(const float* rgb, const uint64_t* slots, const int64_t* ray_idx,
+                                          int with_edge_mask, int n_views, int rays_per_view, int n_pixels,
+                                          float edge_factor, float non_edge_factor, float* acc4, float* loss,
+                                          void* stream) {
+  if (!slots) return JT_ERR_ARG;
+  // (the pointer arguments of the kernel only say "present"; the addresses are read from `slots` on the device)
+  return render_loss_forward(rgb, reinterpret_cast<const float*>(slots), ray_idx,
+                             with_edge_mask ? reinterpret_cast<const uint8_t*>(slots) : nullptr, n_views, rays_per_view,
+                             n_pixels, edge_factor, non_edge_factor, acc4, loss, slots, stream);
+}
+
+extern "C" int jt_render_loss_backward_ind(const float* rgb, const uint64_t* slots, const int64_t* ray_idx,
+                                           int with_edge_mask, int n_views, int rays_per_view, int n_pixels,
+                                           float edge_factor, float non_edge_factor, const float* acc4,
+                                           const float* g_loss, float* g_rgb, void* stream) {
+  if (!slots) return JT_ERR_ARG;
+  return render_loss_backward(rgb, reinterpret_cast<const float*>(slots), ray_idx,
+                              with_edge_mask ? reinterpret_cast<const uint8_t*>(slots) : nullptr, n_views,
+                              rays_per_view, n_pixels, edge_factor, non_edge_factor, acc4, g_loss, g_rgb, slots, stream);
 }
 
 // ---- device-side non-finite guard ------------------------------------------------------------------------------

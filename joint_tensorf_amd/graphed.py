@@ -162,7 +162,12 @@ class GraphedTrainStep:
         # (the edge masks are rebuilt every 500 iterations, model/nerf.py:172-176: their address only counts while
         # the edge-weighted loss reads them)
         ptrs = tuple(int(var[k].data_ptr()) if (k in var and torch.is_tensor(var[k])) else 0
-                     for k in ("idx", "image", "pose", "intr", "intr_inv") + (("train_edge_masks",) if use_edge else ()))
+                     for k in ("idx", "pose", "intr", "intr_inv"))
+        # the supervising image set (one of five blur scales per iteration, model/nerf.py:209-227) and the edge masks
+        # reach the graph through device memory (ops.SUPERVISION_SLOTS_STATIC, poked per replay): layout, not address
+        ptrs += tuple((tuple(var[k].shape), str(var[k].dtype), var[k].is_contiguous())
+                      if (k in var and torch.is_tensor(var[k])) else None
+                      for k in ("image",) + (("train_edge_masks",) if use_edge else ()))
         view_pe = fea_pe = 1.0
         from .model.bat_hip import interp_schedule
         if has(opt, "c2f_view_pe_schedule"):
@@ -258,7 +263,7 @@ class GraphedTrainStep:
             self.stats["captured"] += 1
         # ---- replay ------------------------------------------------------------------------------------------
         e.last_used = self.stats["replayed"]
-        ops.poke_words(e.off, [ox, oy])
+        ops.poke_words(e.off, [ox, oy] + self._supervision_words(var, sig[8]))
         if blur_key is not None:
             self._poke_taps(opt, blur)
         ops.poke_floats(self._loss_weights(opt), list(m.fused_loss_weights(opt)))
@@ -281,6 +286,13 @@ class GraphedTrainStep:
         g.nerf.set_progress(m.it / opt.max_iter)
         self.last_var = e.var
         return e.loss
+
+    @staticmethod
+    def _supervision_words(var, use_edge):
+        """addresses of the iteration's supervising image buffer and edge-mask buffer as four 32-bit words"""
+        img = int(var.image.data_ptr())
+        msk = int(var.train_edge_masks.data_ptr()) if (use_edge and torch.is_tensor(var.get("train_edge_masks"))) else 0
+        return [img & 0xffffffff, img >> 32, msk & 0xffffffff, msk >> 32]
 
     def _loss_weights(self, opt):
         """static [4] device tensor of the fused loss weights (ops.LossSumDyn)"""
@@ -335,7 +347,10 @@ class GraphedTrainStep:
         if coin is not None:
             tf.coin_override = coin
         ops.LOSS_WEIGHTS_STATIC = self._loss_weights(opt)
-        e.off = torch.zeros(2, device=dev, dtype=torch.int32)
+        # [lattice offset x, y | address of the supervising images (2 words) | address of the edge masks (2 words)]
+        e.off = torch.zeros(6, device=dev, dtype=torch.int32)
+        ops.poke_words(e.off, [0, 0] + self._supervision_words(var, sig[8]))
+        ops.SUPERVISION_SLOTS_STATIC = e.off[2:6].view(torch.int64)
         # allocated OUTSIDE the capture: the entry must keep them alive for as long as the graph exists
         e.base_x = base_x = torch.arange(nx, device=dev) * step
         e.base_y = base_y = torch.arange(ny, device=dev) * step
@@ -383,6 +398,7 @@ class GraphedTrainStep:
             tf.taps_static = None
             tf.coin_override = coin_prev
             ops.LOSS_WEIGHTS_STATIC = None
+            ops.SUPERVISION_SLOTS_STATIC = None
             np.random.set_state(np_state)
         if self.pool is None:
             self.pool = e.graph.pool()

@@ -833,6 +833,11 @@ def loss_sum(render, reg3, w_render, w_l1, w_tv_density, w_tv_color):
     return LossSum.apply(render, reg3, float(w_render), float(w_l1), float(w_tv_density), float(w_tv_color))
 
 
+# While this is a device tensor int64[2] (set by graphed.GraphedTrainStep around a capture), render_loss reads the
+# addresses of the supervising image buffer / edge-mask buffer from it instead of baking them into the launch arguments
+SUPERVISION_SLOTS_STATIC = None
+
+
 class RenderLoss(torch.autograd.Function):
     """nanmean squared error between rgb [B,r,3] and the GT pixels image[:, :, ray_idx], optionally with the
     hard edge-mask split (model/tensorf.py:112-124, base.py:259-261) -- one kernel each way."""
@@ -847,20 +852,33 @@ class RenderLoss(torch.autograd.Function):
         dev = rgb_c.device
         acc = torch.empty(4, device=dev, dtype=torch.float32)
         loss = torch.empty(1, device=dev, dtype=torch.float32)
-        check(lib.jt_render_loss_forward(ptr(rgb_c), ptr(img), ptr(idx), ptr(m), B, r, img.shape[2],
-                                         float(edge_factor), float(non_edge_factor), ptr(acc), ptr(loss), _stream()),
-              "jt_render_loss_forward")
-        ctx.saved = (rgb_c, img, idx, m, acc, float(edge_factor), float(non_edge_factor))
+        slots = SUPERVISION_SLOTS_STATIC
+        if slots is not None:
+            # the caller's slots name buffers of exactly this layout (it pokes img / m -like tensors' addresses)
+            assert img.data_ptr() == image.data_ptr() and (m is None or m.data_ptr() == edge_mask.data_ptr())
+            check(lib.jt_render_loss_forward_ind(ptr(rgb_c), ptr(slots), ptr(idx), int(m is not None), B, r, img.shape[2],
+                                                 float(edge_factor), float(non_edge_factor), ptr(acc), ptr(loss),
+                                                 _stream()), "jt_render_loss_forward_ind")
+        else:
+            check(lib.jt_render_loss_forward(ptr(rgb_c), ptr(img), ptr(idx), ptr(m), B, r, img.shape[2],
+                                             float(edge_factor), float(non_edge_factor), ptr(acc), ptr(loss), _stream()),
+                  "jt_render_loss_forward")
+        ctx.saved = (rgb_c, img, idx, m, acc, float(edge_factor), float(non_edge_factor), slots)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
-        rgb_c, img, idx, m, acc, fe, fne = ctx.saved
+        rgb_c, img, idx, m, acc, fe, fne, slots = ctx.saved
         B, r = rgb_c.shape[0], rgb_c.shape[1]
         gc = g.contiguous().float().view(1)
         g_rgb = torch.empty_like(rgb_c)
-        check(lib.jt_render_loss_backward(ptr(rgb_c), ptr(img), ptr(idx), ptr(m), B, r, img.shape[2], fe, fne,
-                                          ptr(acc), ptr(gc), ptr(g_rgb), _stream()), "jt_render_loss_backward")
+        if slots is not None:
+            check(lib.jt_render_loss_backward_ind(ptr(rgb_c), ptr(slots), ptr(idx), int(m is not None), B, r,
+                                                  img.shape[2], fe, fne, ptr(acc), ptr(gc), ptr(g_rgb), _stream()),
+                  "jt_render_loss_backward_ind")
+        else:
+            check(lib.jt_render_loss_backward(ptr(rgb_c), ptr(img), ptr(idx), ptr(m), B, r, img.shape[2], fe, fne,
+                                              ptr(acc), ptr(gc), ptr(g_rgb), _stream()), "jt_render_loss_backward")
         return g_rgb, None, None, None, None, None
 
 

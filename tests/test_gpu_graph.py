@@ -43,7 +43,7 @@ def _build(seed=0, blur=False):
     return opt, model, var0
 
 
-def _run(use_graph, K, it0=0, blur=False):
+def _run(use_graph, K, it0=0, blur=False, swap_images=False):
     from joint_tensorf_amd.graphed import GraphedTrainStep
     from joint_tensorf_amd.options import Opt
     opt, model, var0 = _build(blur=blur)
@@ -53,8 +53,11 @@ def _run(use_graph, K, it0=0, blur=False):
     stepper = GraphedTrainStep(model, min_repeats=0) if use_graph else None
     losses = []
     orig_randint = np.random.randint
+    alt_image = (0.25 + 0.5 * var0.image).contiguous()  # a second supervising image set (another 2-D blur scale)
     for k in range(K):
         var = Opt(dict(var0))
+        if swap_images and k % 3 == 1:
+            var.image = alt_image
         # the first two iterations are eager on both sides, the very first on the densest lattice (offsets 0, 0):
         # the persistent workspaces reach their final size there, as a training run's first iterations make them
         if k == 0:
@@ -280,6 +283,26 @@ def test_graph_replay_of_llff_iterations_is_bit_identical_to_eager():
     # the device-side loss weights of the last replay are the host schedule's of that iteration (one decay step behind now)
     dec = model.graph.nerf.lr_decay_factor
     np.testing.assert_allclose(lw[0][2], lw[1][2] / dec, rtol=1e-6)
+
+
+def test_supervising_image_set_changes_without_a_new_capture():
+    """The reference supervises with one of five blur scales of the images per iteration (model/nerf.py:209-227): the
+    buffer's address reaches the replayed graph through device memory, so alternating image sets neither re-capture nor
+    change the trajectory (deterministic mode: exact equality with the eager loop)."""
+    from joint_tensorf_amd._lib import lib
+    prev = lib.jt_set_deterministic(1)
+    try:
+        l_e, sd_e, _, _ = _run(False, 14, 9000, False, swap_images=True)
+        l_g, sd_g, stats, _ = _run(True, 14, 9000, False, swap_images=True)
+        l_s, _, stats_same, _ = _run(True, 14, 9000, False, swap_images=False)
+    finally:
+        lib.jt_set_deterministic(prev)
+    assert stats["captured"] == stats_same["captured"], (stats, stats_same)   # no graph per image set
+    assert stats["replayed"] >= 8, stats
+    assert not np.array_equal(l_g, l_s)                                      # the other image set did supervise
+    np.testing.assert_array_equal(l_g, l_e)
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_g[k]), k
 
 
 @pytest.mark.parametrize("it0,blur", [(9000, False), (0, True)])
