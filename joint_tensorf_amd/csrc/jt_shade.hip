@@ -527,15 +527,15 @@ __device__ inline void wave_lds_sync() {
 // lanes: group = lane >> 4 (4 groups), cl = lane & 15.  Group g walks samples g*8 .. g*8+7 of the tile in
 // order (jt_walk.h); the step records of the 32 samples (tap addresses, weights, cells) were computed once per
 // sample and sit in LDS; the factor values of the next sample are loaded while the current one is accumulated.
-template <class C>
+template <class C, bool DET>
 __device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, const float* tp, const float* recs,
-                                     float* gxyz, int lane, bool fixed) {
+                                     float* gxyz, int lane) {
   constexpr int NCH = (C::CA + 15) / 16;
   const int grp = lane >> 4, cl = lane & 15;
   const float* P = D.aP[pl];
   const float* Ln = D.aL[pl];
-  RecWalker<NCH, C::CA> wk;
-  wk.init(G.app_plane[pl], G.app_line[pl], cl, fixed);
+  RecWalker<NCH, C::CA, DET ? 1 : 0> wk;  // (instantiated per accumulation mode: float atomics / 2^56 fixed point)
+  wk.init(G.app_plane[pl], G.app_line[pl], cl, DET);
   const int m0 = kM0(pl), m1 = kM1(pl), mv = kV(pl);
   // lanes 0..2 of a group add the x / y / line coordinate gradient of the step to gxyz[sample][axis]
   const int my_axis = (cl == 0) ? m0 : (cl == 1) ? m1 : mv;
@@ -583,7 +583,7 @@ __device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, c
   wk.finish_pair(grp);
 }
 
-template <class C>
+template <class C, bool DET>
 __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm, JtFactors G,
                                                       const int* __restrict__ offset, int R,
                                                       const float* __restrict__ rgb_s,
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
                       recs + j * kRecWords);
       }
       wave_lds_sync();
-      if (!(ablate & 1)) scatter_plane<C>(D, G, pl, tp, recs, gxyz, lane, (ablate & 16) != 0);
+      if (!(ablate & 1)) scatter_plane<C, DET>(D, G, pl, tp, recs, gxyz, lane);
       wave_lds_sync();
     }
     if (on && h == 0) {
@@ -1186,8 +1186,10 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   if (ws_bytes < W::bytes(cap)) return JT_ERR_ARG;
   const int chunk = kChunkEntries;
   const int nchunks = (cap + chunk - 1) / chunk;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_bwd<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_bwd<C, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_bwd<C, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   float* recs = ws;
   float* slabs = ws + W::rec_floats(cap);
   const size_t cstride = W::slab_floats_per_chunk();
@@ -1210,8 +1212,12 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     const int start = ci * chunk, ccap = std::min(chunk, cap - start);
     long tiles = ((long)ccap + 31) / 32;
     int blocks = (int)std::min<long>((tiles + B::NWAVE - 1) / B::NWAVE, 256);
-    hipLaunchKernelGGL(k_shade_bwd<C>, dim3(blocks), dim3(512), lds, st, D, M, pm, G, offset, R, rgb_s, g_rgb_s,
-                       g_xyz, recs + W::rec_floats_per_chunk() * ci, start, ccap, cap, ablate);
+    if (det)
+      hipLaunchKernelGGL((k_shade_bwd<C, true>), dim3(blocks), dim3(512), lds, st, D, M, pm, G, offset, R, rgb_s,
+                         g_rgb_s, g_xyz, recs + W::rec_floats_per_chunk() * ci, start, ccap, cap, ablate);
+    else
+      hipLaunchKernelGGL((k_shade_bwd<C, false>), dim3(blocks), dim3(512), lds, st, D, M, pm, G, offset, R, rgb_s,
+                         g_rgb_s, g_xyz, recs + W::rec_floats_per_chunk() * ci, start, ccap, cap, ablate);
     JT_LAUNCH_CHECK();
     return JT_OK;
   };
