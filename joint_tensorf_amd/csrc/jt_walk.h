@@ -141,6 +141,26 @@ struct RecWalker {
   __device__ inline void load(TapBuf<NCH>& tv, const float* P, const float* L, const float* rec) const {
     const uint4 ro = *reinterpret_cast<const uint4*>(rec);
     const uint2 rl = *reinterpret_cast<const uint2*>(rec + 4);
+    if (CA % 16 == 0) {
+      // every lane's channels cl, cl + 16, ... exist: ONE offset add per tap, the channel step of 64 bytes rides in
+      // the load's immediate offset
+      const float* pa = reinterpret_cast<const float*>(reinterpret_cast<const char*>(P) + (ro.x + ck[0]));
+      const float* pb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(P) + (ro.y + ck[0]));
+      const float* pc = reinterpret_cast<const float*>(reinterpret_cast<const char*>(P) + (ro.z + ck[0]));
+      const float* pd = reinterpret_cast<const float*>(reinterpret_cast<const char*>(P) + (ro.w + ck[0]));
+      const float* pu = reinterpret_cast<const float*>(reinterpret_cast<const char*>(L) + (rl.x + ck[0]));
+      const float* pv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(L) + (rl.y + ck[0]));
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        tv.a[k] = pa[16 * k];
+        tv.b[k] = pb[16 * k];
+        tv.c[k] = pc[16 * k];
+        tv.d[k] = pd[16 * k];
+        tv.u[k] = pu[16 * k];
+        tv.v[k] = pv[16 * k];
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       tv.a[k] = ldb(P, ro.x + ck[k]);
@@ -154,11 +174,16 @@ struct RecWalker {
   // out-of-range texels never receive anything (their weights are zero), so a clamped address is fine.
   // base == nullptr: the caller does not want factor gradients (pose-only backward), nothing is written.
   __device__ inline void flush(float* base, unsigned off, float* a) {
+    // (CA % 16 == 0: the texel's byte offset plus the lane's first channel once, the 64-byte channel step as an
+    //  immediate offset of the atomic)
+    float* t0 = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (off + ck[0]));
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       if (base != nullptr && live[k] && JT_FLUSH_COND(a[k])) {
         if (FX == 1 || (FX == 2 && fixed))  // byte offset of a float element -> the same element of the 64-bit shadow buffer
           fixed_add(reinterpret_cast<long long*>(reinterpret_cast<char*>(base) + 2 * (size_t)(off + ck[k])), a[k]);
+        else if (CA % 16 == 0)
+          atomicAdd(t0 + 16 * k, a[k]);
         else
           atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (off + ck[k])), a[k]);
       }
