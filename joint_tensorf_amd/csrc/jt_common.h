@@ -232,6 +232,11 @@ __device__ inline float density_act_grad(int act, float x) {
 }
 
 __device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// 16-byte load at (uniform base) + (32-bit byte offset) + 16 * q: the form the hardware addresses directly (scalar base
+// register pair, 32-bit lane offset, immediate) -- no 64-bit address arithmetic per load
+__device__ inline float4 ld4q(const float* base, unsigned byte_off, int q) {
+  return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off)[q];
+}
 
 // order-independent accumulation: v as 2^56 fixed point into a 64-bit word
 __device__ inline void fixed_add(long long* p, float v) {

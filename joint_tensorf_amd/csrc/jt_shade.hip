@@ -185,13 +185,24 @@ __device__ inline f32x16 gather_basis(const Dev& D, const float* s, const float 
     Axis l = axis_taps(n[kV(i)], D.ll[i]);
     const float* P = D.aP[i];
     const float* L = D.aL[i];
+    // byte offsets of the six taps for this lane half's first channel quad; quad slot m is 32 bytes further
+    const unsigned hb = 16u * (unsigned)h;
+    const unsigned b00 = 4u * (unsigned)t.o00 + hb, b10 = 4u * (unsigned)t.o10 + hb, b01 = 4u * (unsigned)t.o01 + hb,
+                   b11 = 4u * (unsigned)t.o11 + hb, bl0 = 4u * (unsigned)(l.c0 * C::CA) + hb,
+                   bl1 = 4u * (unsigned)(l.c1 * C::CA) + hb;
 #pragma unroll
     for (int m = 0; m < C::NSLOT; ++m) {
       const int q = 2 * m + h;
       const bool live = q * 4 < C::CA;
       const int c0 = live ? q * 4 : 0;
-      float4 a = ld4(P + t.o00 + c0), b = ld4(P + t.o10 + c0), c = ld4(P + t.o01 + c0), d = ld4(P + t.o11 + c0);
-      float4 u = ld4(L + l.c0 * C::CA + c0), v = ld4(L + l.c1 * C::CA + c0);
+      float4 a, b, c, d, u, v;
+      if (C::CA % 8 == 0) {  // every (slot, half) exists
+        a = ld4q(P, b00, 2 * m), b = ld4q(P, b10, 2 * m), c = ld4q(P, b01, 2 * m), d = ld4q(P, b11, 2 * m);
+        u = ld4q(L, bl0, 2 * m), v = ld4q(L, bl1, 2 * m);
+      } else {
+        a = ld4(P + t.o00 + c0), b = ld4(P + t.o10 + c0), c = ld4(P + t.o01 + c0), d = ld4(P + t.o11 + c0);
+        u = ld4(L + l.c0 * C::CA + c0), v = ld4(L + l.c1 * C::CA + c0);
+      }
       float pr[4];
       pr[0] = (t.w00 * a.x + t.w10 * b.x + t.w01 * c.x + t.w11 * d.x) * (l.w0 * u.x + l.w1 * v.x);
       pr[1] = (t.w00 * a.y + t.w10 * b.y + t.w01 * c.y + t.w11 * d.y) * (l.w0 * u.y + l.w1 * v.y);
