@@ -39,6 +39,15 @@ __device__ inline float rec_ld(const float* p) {
   return *p;
 #endif
 }
+// record slot of tile block `rt` (uniform: it depends on the wave, not on the lane), row `row` (a constant at every use),
+// lane part `lane_bytes` (4 * sample [+ 512 * lane half for rows rowmap(r, 0) + 4 h]): scalar base + 32-bit lane offset,
+// the form global loads / stores address without 64-bit vector arithmetic
+__device__ inline float* rec_at(float* rt, int row, unsigned lane_bytes) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(rt) + (size_t)row * 128 + lane_bytes);
+}
+__device__ inline const float* rec_at(const float* rt, int row, unsigned lane_bytes) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(rt) + (size_t)row * 128 + lane_bytes);
+}
 __device__ inline float4 rec_ld4(const float* p) {
 #if JT_REC_NT
   typedef float v4f __attribute__((ext_vector_type(4)));
@@ -211,7 +220,12 @@ __device__ inline f32x16 gather_basis(const Dev& D, const float* s, const float 
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float bv = live ? pr[k] : 0.f;
-        if (REC && live && onrec) rec_st(rt + (size_t)(BwdCfg<C>::R_PROD + i * C::CA + c0 + k) * 32 + j, pr[k]);
+        if (REC && live && onrec) {
+          if (C::CA % 8 == 0)  // row = R_PROD + i CA + 8 m + 4 h + k: the lane half rides in the lane part
+            rec_st(rec_at(rt, BwdCfg<C>::R_PROD + i * C::CA + 8 * m + k, 4u * (unsigned)j + 512u * (unsigned)h), pr[k]);
+          else
+            rec_st(rt + (size_t)(BwdCfg<C>::R_PROD + i * C::CA + c0 + k) * 32 + j, pr[k]);
+        }
         float av = sb[i * C::CA + c0 + k];
         facc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, facc, 0, 0, 0);
       }
@@ -428,7 +442,8 @@ __device__ inline void rec_store(float* rt, int row0, const f32x16* v, int j, in
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rec_st(rt + (size_t)(row0 + t * 32 + rowmap(r, 0) + 4 * h) * 32 + j, v[t][r]);
+    for (int r = 0; r < 16; ++r)
+      rec_st(rec_at(rt, row0 + t * 32 + rowmap(r, 0), 4u * (unsigned)j + 512u * (unsigned)h), v[t][r]);
 }
 
 // REC = 1 (training): besides rgb the kernel leaves the tile-blocked records of the layer inputs (see BwdCfg) so
@@ -451,7 +466,8 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
   if ((int)blockIdx.x * 4 >= ntiles) return;
   load_weights_lds<C>(smem, M);
   __syncthreads();
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // (the wave index as a scalar: everything derived from it -- tile, record block -- stays in scalar registers)
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j_ = lane & 31, h_ = lane >> 5;
   constexpr int HOFF = (C::KIND == JT_MLP_FEA) ? 0 : 12;
   for (int tile = blockIdx.x * 4 + wv; tile < ntiles; tile += gridDim.x * 4) {
@@ -466,8 +482,8 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
     if (REC && on && h == 0) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        if (REC == 1) rec_st(rt + (size_t)(B::R_VD + c) * 32 + j, vd[c]);
-        rec_st(rt + (size_t)(B::R_GEO + c) * 32 + j, g.n[c]);
+        if (REC == 1) rec_st(rec_at(rt, B::R_VD + c, 4u * (unsigned)j), vd[c]);
+        rec_st(rec_at(rt, B::R_GEO + c, 4u * (unsigned)j), g.n[c]);
       }
     }
     f32x16 facc = gather_basis<C, REC == 1>(D, smem, g.n, j, h, rt, on);
@@ -480,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
       for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mask1 |= (h1.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
-      if (on) rec_st(rt + (size_t)(B::R_MASK + h) * 32 + j, __uint_as_float(mask1));
+      if (on) rec_st(rec_at(rt, B::R_MASK, 4u * (unsigned)j + 128u * (unsigned)h), __uint_as_float(mask1));
       if (REC == 1) rec_store<C::MT>(rt, B::R_H1, h1.v, j, h, on);
     }
     Hidden<C> h2 = layer2<C>(smem, h1, j, h);
@@ -491,14 +507,14 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
       for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mask2 |= (h2.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
-      if (on) rec_st(rt + (size_t)(B::R_MASK + 2 + h) * 32 + j, __uint_as_float(mask2));
+      if (on) rec_st(rec_at(rt, B::R_MASK + 2, 4u * (unsigned)j + 128u * (unsigned)h), __uint_as_float(mask2));
       if (REC == 1) rec_store<C::MT>(rt, B::R_MID + HOFF, h2.v, j, h, on);
       if (REC == 1 && C::KIND != JT_MLP_FEA) {
         float pe[12];
         view_pe(vd, pm, pe);
         if (on && h == 0) {
 #pragma unroll
-          for (int k = 0; k < 12; ++k) rec_st(rt + (size_t)(B::R_MID + k) * 32 + j, pe[k]);
+          for (int k = 0; k < 12; ++k) rec_st(rec_at(rt, B::R_MID + k, 4u * (unsigned)j), pe[k]);
         }
       }
     }
@@ -609,7 +625,8 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
   if ((int)blockIdx.x * B::NWAVE >= ntiles) return;  // chunk beyond the shaded samples: nothing to do
   load_weights_lds<C>(smem, M);
   __syncthreads();
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // (the wave index as a scalar: everything derived from it -- tile, record block -- stays in scalar registers)
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j_ = lane & 31, h_ = lane >> 5;
   float* tp = smem + C::LDS_FLOATS + wv * B::WAVE_FLOATS;
   float* geo = tp + B::TP_ROWS * B::TP_LD;
@@ -629,17 +646,18 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
     float* rt = rec + (size_t)tile * RC * 32;  // this tile's record block (layer inputs left by the forward)
     const int jj = on ? j : nlive - 1;         // padding lanes mirror the last live sample
     if (h == 0) {
-      geo[j * 4 + 0] = rec_ld(rt + (size_t)(B::R_GEO + 0) * 32 + jj);
-      geo[j * 4 + 1] = rec_ld(rt + (size_t)(B::R_GEO + 1) * 32 + jj);
-      geo[j * 4 + 2] = rec_ld(rt + (size_t)(B::R_GEO + 2) * 32 + jj);
+      geo[j * 4 + 0] = rec_ld(rec_at(rt, B::R_GEO + 0, 4u * (unsigned)jj));
+      geo[j * 4 + 1] = rec_ld(rec_at(rt, B::R_GEO + 1, 4u * (unsigned)jj));
+      geo[j * 4 + 2] = rec_ld(rec_at(rt, B::R_GEO + 2, 4u * (unsigned)jj));
       gxyz[j * 4 + 0] = gxyz[j * 4 + 1] = gxyz[j * 4 + 2] = 0.f;
     }
     // basis_mat output of the forward (accumulator layout) and the ReLU sign bits of both hidden layers
     f32x16 facc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) facc[r] = rec_ld(rt + (size_t)(B::R_F + rowmap(r, 0) + 4 * h) * 32 + jj);
-    const unsigned mask1 = __float_as_uint(rec_ld(rt + (size_t)(B::R_MASK + h) * 32 + jj));
-    const unsigned mask2 = __float_as_uint(rec_ld(rt + (size_t)(B::R_MASK + 2 + h) * 32 + jj));
+    for (int r = 0; r < 16; ++r)
+      facc[r] = rec_ld(rec_at(rt, B::R_F + rowmap(r, 0), 4u * (unsigned)jj + 512u * (unsigned)h));
+    const unsigned mask1 = __float_as_uint(rec_ld(rec_at(rt, B::R_MASK, 4u * (unsigned)jj + 128u * (unsigned)h)));
+    const unsigned mask2 = __float_as_uint(rec_ld(rec_at(rt, B::R_MASK + 2, 4u * (unsigned)jj + 128u * (unsigned)h)));
     // sin / cos of the features, parked in the wave's LDS scratch for the layer-1 backward
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -658,7 +676,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
     }
     if (onrec && h == 0) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) rec_st(rt + (size_t)(B::R_GO + c) * 32 + j, go[c]);
+      for (int c = 0; c < 3; ++c) rec_st(rec_at(rt, B::R_GO + c, 4u * (unsigned)j), go[c]);
     }
     Hidden<C> G2;
 #pragma unroll
