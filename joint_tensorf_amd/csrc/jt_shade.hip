@@ -554,6 +554,9 @@ __device__ inline void wave_lds_sync() {
 // lanes: group = lane >> 4 (4 groups), cl = lane & 15.  Group g walks samples g*8 .. g*8+7 of the tile in
 // order (jt_walk.h); the step records of the 32 samples (tap addresses, weights, cells) were computed once per
 // sample and sit in LDS; the factor values of the next sample are loaded while the current one is accumulated.
+// slot of sample j of a tile in the scatter's LDS arrays: the odd 8-sample runs are stored back to front
+__device__ inline int walk_slot(int j) { return j ^ (((j >> 3) & 1) * 7); }
+
 template <class C, bool DET>
 __device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, const float* tp, const float* recs,
                                      float* gxyz, int lane) {
@@ -570,13 +573,14 @@ __device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, c
                                                                                 : 0.5f * (float)(D.ll[pl] - 1)) *
                          D.inv[my_axis];
   // odd groups walk their eight samples in DESCENDING order: groups 0 | 1 and 2 | 3 then end on neighbouring samples
-  // (7 | 8, 23 | 24) and merge their last texels before the flush (RecWalker::finish_pair)
-  const bool down = grp & 1;
-  const float* rec0 = recs + (grp * 8 + (down ? 7 : 0)) * kRecWords;
-  const int rstep = down ? -kRecWords : kRecWords;
+  // (7 | 8, 23 | 24) and merge their last texels before the flush (RecWalker::finish_pair).  The caller stores the
+  // tile's samples in WALK order -- slot grp * 8 + q holds sample grp * 8 + (7 - q) for the odd groups (walk_slot) --
+  // so every group reads slots q = 0 .. 7 upwards and the offsets below stay instruction immediates
+  const float* rec0 = recs + (grp * 8) * kRecWords;
+  constexpr int rstep = kRecWords;
   TapBuf<NCH> bufA, bufB;
   auto step = [&](TapBuf<NCH>& tv, int q) {
-    const int sidx = grp * 8 + (down ? 7 - q : q);
+    const int sidx = grp * 8 + q;
     const float* rec = rec0 + q * rstep;
     wk.advance(rec);
     float g[NCH];
@@ -638,6 +642,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
     // on them is hoisted out of the tile loop as a loop invariant and the kernel spills hundreds of VGPRs
     int j = j_, h = h_;
     asm volatile("" : "+v"(j), "+v"(h));
+    const int pj = walk_slot(j);             // where this lane's sample sits in the scatter's LDS arrays
     const int l0 = tile * 32;                // first record row of the tile (chunk-local)
     const int e = chunk_start + l0 + j;      // global entry of this lane's sample
     const int nlive = min(32, n_chunk - l0);
@@ -784,7 +789,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ch = T * 32 + rowmap(r, 0) + 4 * h;
-          if (ch < C::CA) tp[ch * 33 + j] = gp[T][r];
+          if (ch < C::CA) tp[ch * 33 + pj] = gp[T][r];
         }
       // step records of the tile's samples for this plane (one lane per sample), in the rows of tp past
       // the product gradients
@@ -796,7 +801,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
         const int jp = has_prev ? (down ? j + 1 : j - 1) : j;
         make_step_rec(geo[j * 4 + kM0(pl)], geo[j * 4 + kM1(pl)], geo[j * 4 + kV(pl)], geo[jp * 4 + kM0(pl)],
                       geo[jp * 4 + kM1(pl)], geo[jp * 4 + kV(pl)], has_prev, D.ph[pl], D.pw[pl], D.ll[pl], C::CA,
-                      recs + j * kRecWords);
+                      recs + pj * kRecWords);
       }
       wave_lds_sync();
       if (!(ablate & 1)) scatter_plane<C, DET>(D, G, pl, tp, recs, gxyz, lane);
@@ -804,7 +809,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
     }
     if (on && h == 0) {
 #pragma unroll
-      for (int a = 0; a < 3; ++a) g_xyz[(size_t)e * 3 + a] = gxyz[j * 4 + a];
+      for (int a = 0; a < 3; ++a) g_xyz[(size_t)e * 3 + a] = gxyz[pj * 4 + a];
     }
     wave_lds_sync();
   }

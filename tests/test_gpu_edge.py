@@ -124,6 +124,9 @@ def test_pose_only_backward_matches_full():
     _, _, ref, out_full, cpu, gpu_full = _run_both(fx, o, d)
     tf, _, _, out_pose, _, gpu_pose = _run_both(fx, o, d, want="pose")
     assert all(p.grad is None for p in tf.parameters())
+    # the two backwards follow two instantiations of the forward (full records / pose-only records) whose fused
+    # multiply-adds the compiler is free to contract differently: equal to 1e-6 of the gradient's scale, not bit for bit
     for a, b in zip(gpu_pose, gpu_full):
-        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
+        ga, gb = a.grad.cpu().numpy(), b.grad.cpu().numpy()
+        np.testing.assert_allclose(ga, gb, rtol=1e-5, atol=1e-6 * float(np.abs(gb).max()))
     _check_ray_grads(cpu, gpu_pose)
