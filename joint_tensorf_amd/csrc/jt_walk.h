@@ -177,9 +177,16 @@ struct RecWalker {
     // (CA % 16 == 0: the texel's byte offset plus the lane's first channel once, the 64-byte channel step as an
     //  immediate offset of the atomic)
     float* t0 = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (off + ck[0]));
+    // ONE test per slot: a slot that received anything has (with measure-zero exceptions) all of the lane's channels
+    // non-zero, and adding an exact zero changes nothing -- a test per channel was a compare, an exec-mask save and a
+    // branch around every atomic
+    bool any = false;
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-      if (base != nullptr && live[k] && JT_FLUSH_COND(a[k])) {
+    for (int k = 0; k < NCH; ++k) any = any || JT_FLUSH_COND(a[k]);
+    if (base != nullptr && any) {
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        if (!live[k]) continue;
         if (FX == 1 || (FX == 2 && fixed))  // byte offset of a float element -> the same element of the 64-bit shadow buffer
           fixed_add(reinterpret_cast<long long*>(reinterpret_cast<char*>(base) + 2 * (size_t)(off + ck[k])), a[k]);
         else if (CA % 16 == 0)
@@ -187,8 +194,9 @@ struct RecWalker {
         else
           atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (off + ck[k])), a[k]);
       }
-      a[k] = 0.f;
     }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) a[k] = 0.f;
   }
   // flush the slots whose texel the walk leaves with this sample, then adopt the sample's texels
   __device__ inline void advance(const float* rec) {
