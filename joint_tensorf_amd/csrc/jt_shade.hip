@@ -253,6 +253,15 @@ __device__ inline void sincos_f(float x, float* sn, float* cs) {
   *cs = ((q + 1) & 2) ? -cc : cc;
 }
 
+// Hardware sine / cosine (v_sin_f32 / v_cos_f32: two quarter-rate instructions and a multiply instead of ~35): absolute
+// error 1.4e-7 for |x| <= 1, 4e-7 for |x| <= 4, 1.4e-6 for |x| <= 16 (measured on MI355X against double precision).
+// Used where the encoding enters a GRADIENT only -- the derivative factors of the backward chain and the layer-1 input
+// of the weight-gradient GEMM -- never for the forward's values (sincos_f).
+__device__ inline void sincos_grad(float x, float* sn, float* cs) {
+  *sn = __sinf(x);
+  *cs = __cosf(x);
+}
+
 // the five values (x, PE(x)) lane-half h feeds into layer 1 for accumulator row r:
 //   [x, sin x * m0, sin 2x * m1, cos x * m0, cos 2x * m1]     (tensorBase.py:43-55)
 template <class C>
@@ -668,7 +677,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
     for (int r = 0; r < 16; ++r) {
       if (rowmap(r, 0) >= C::APP && rowmap(r, 1) >= C::APP) continue;
       float sn, cs;
-      sincos_f(facc[r], &sn, &cs);
+      sincos_grad(facc[r], &sn, &cs);
       tp[(2 * r) * 64 + lane] = sn;
       tp[(2 * r + 1) * 64 + lane] = cs;
     }
@@ -970,7 +979,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ rec, in
         for (int q = 0; q < 16; ++q) asum[a] += av[a][q];
       float sn[16], cs[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) sincos_f(x[q], &sn[q], &cs[q]);
+      for (int q = 0; q < 16; ++q) sincos_grad(x[q], &sn[q], &cs[q]);
 #pragma unroll
       for (int b = 0; b < NT; ++b) {
 #pragma unroll
