@@ -36,6 +36,7 @@ __device__ inline unsigned hash32(unsigned x) {
 // MODE 6: like 0 but a returning atomic (the wave waits for the old value)
 // MODE 7: like 0 with only 4 of the 16 lanes of every group active                              (4 x 16 B / instr)
 // MODE 8: like 0, every group adds to the SAME 16 floats iteration after iteration (one hot line per group)
+// MODE 9 / 10 / 11: like 0 with workgroup / system / wavefront memory scope instead of the default agent scope
 template <int MODE>
 __global__ __launch_bounds__(256) void k_atomic(float* __restrict__ buf, unsigned n_texels, int C, int iters,
                                                 unsigned seed) {
@@ -67,6 +68,9 @@ __global__ __launch_bounds__(256) void k_atomic(float* __restrict__ buf, unsigne
     }
     if (MODE == 8) atomicAdd(buf + (size_t)(walk % n_texels) * C + cl, v);
     if (MODE == 6) acc += atomicAdd(p + cl, v);
+    if (MODE == 9) __hip_atomic_fetch_add(p + cl, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (MODE == 10) __hip_atomic_fetch_add(p + cl, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (MODE == 11) __hip_atomic_fetch_add(p + cl, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   }
   if (MODE == 6 && acc == 123.456f) buf[0] = acc;
 }
@@ -109,6 +113,9 @@ int main() {
     run<6>("4 groups, returning atomics", buf, n, C, 4, 256);
     run<7>("4 groups, 4 lanes each", buf, n, C, 4, 64);
     run<8>("4 groups, one hot line per group", buf, n, C, 4, 256);
+    run<9>("4 groups, workgroup scope", buf, n, C, 4, 256);
+    run<10>("4 groups, system scope", buf, n, C, 4, 256);
+    run<11>("4 groups, wavefront scope", buf, n, C, 4, 256);
   }
   // where is the limit: fewer workgroups (1 / 2 / 4 / 8 per XCD ... all CUs once) at the full texel range
   for (int blocks : {8, 16, 32, 64, 128, 256, 512, 1024})
