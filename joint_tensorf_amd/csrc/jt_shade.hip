@@ -205,12 +205,14 @@ __device__ inline f32x16 gather_basis(const Dev& D, const float* s, const float 
       const bool live = q * 4 < C::CA;
       const int c0 = live ? q * 4 : 0;
       float4 a, b, c, d, u, v;
-      if (C::CA % 8 == 0) {  // every (slot, half) exists
+      if (C::CA % 8 == 0 || m + 1 < C::NSLOT) {  // both halves of the slot exist
         a = ld4q(P, b00, 2 * m), b = ld4q(P, b10, 2 * m), c = ld4q(P, b01, 2 * m), d = ld4q(P, b11, 2 * m);
         u = ld4q(L, bl0, 2 * m), v = ld4q(L, bl1, 2 * m);
       } else {
-        a = ld4(P + t.o00 + c0), b = ld4(P + t.o10 + c0), c = ld4(P + t.o01 + c0), d = ld4(P + t.o11 + c0);
-        u = ld4(L + l.c0 * C::CA + c0), v = ld4(L + l.c1 * C::CA + c0);
+        // last slot of an odd quad count (VM-20: five quads): half 1 has no quad there and re-reads half 0's (its
+        // products are zeroed below) instead of reading past the texel
+        a = ld4q(P, b00 - hb, 2 * m), b = ld4q(P, b10 - hb, 2 * m), c = ld4q(P, b01 - hb, 2 * m);
+        d = ld4q(P, b11 - hb, 2 * m), u = ld4q(L, bl0 - hb, 2 * m), v = ld4q(L, bl1 - hb, 2 * m);
       }
       float pr[4];
       pr[0] = (t.w00 * a.x + t.w10 * b.x + t.w01 * c.x + t.w11 * d.x) * (l.w0 * u.x + l.w1 * v.x);
@@ -220,12 +222,9 @@ __device__ inline f32x16 gather_basis(const Dev& D, const float* s, const float 
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float bv = live ? pr[k] : 0.f;
-        if (REC && live && onrec) {
-          if (C::CA % 8 == 0)  // row = R_PROD + i CA + 8 m + 4 h + k: the lane half rides in the lane part
-            rec_st(rec_at(rt, BwdCfg<C>::R_PROD + i * C::CA + 8 * m + k, 4u * (unsigned)j + 512u * (unsigned)h), pr[k]);
-          else
-            rec_st(rt + (size_t)(BwdCfg<C>::R_PROD + i * C::CA + c0 + k) * 32 + j, pr[k]);
-        }
+        // row = R_PROD + i CA + 8 m + 4 h + k: the lane half rides in the lane part
+        if (REC && live && onrec)
+          rec_st(rec_at(rt, BwdCfg<C>::R_PROD + i * C::CA + 8 * m + k, 4u * (unsigned)j + 512u * (unsigned)h), pr[k]);
         float av = sb[i * C::CA + c0 + k];
         facc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, facc, 0, 0, 0);
       }

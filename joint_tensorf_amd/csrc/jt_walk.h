@@ -141,34 +141,32 @@ struct RecWalker {
   __device__ inline void load(TapBuf<NCH>& tv, const float* P, const float* L, const float* rec) const {
     const uint4 ro = *reinterpret_cast<const uint4*>(rec);
     const uint2 rl = *reinterpret_cast<const uint2*>(rec + 4);
-    if (CA % 16 == 0) {
-      // every lane's channels cl, cl + 16, ... exist: ONE offset add per tap, the channel step of 64 bytes rides in
-      // the load's immediate offset
-      const float* pa = reinterpret_cast<const float*>(reinterpret_cast<const char*>(P) + (ro.x + ck[0]));
-      const float* pb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(P) + (ro.y + ck[0]));
-      const float* pc = reinterpret_cast<const float*>(reinterpret_cast<const char*>(P) + (ro.z + ck[0]));
-      const float* pd = reinterpret_cast<const float*>(reinterpret_cast<const char*>(P) + (ro.w + ck[0]));
-      const float* pu = reinterpret_cast<const float*>(reinterpret_cast<const char*>(L) + (rl.x + ck[0]));
-      const float* pv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(L) + (rl.y + ck[0]));
+    // channel groups k < CA / 16 exist in every lane: ONE offset add per tap, the 64-byte step between groups rides in
+    // the load's immediate offset; a partial last group (VM-20: channels 16..19) keeps its own clamped offset
+    constexpr int NFULL = CA / 16;
+    const float* pa = reinterpret_cast<const float*>(reinterpret_cast<const char*>(P) + (ro.x + ck[0]));
+    const float* pb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(P) + (ro.y + ck[0]));
+    const float* pc = reinterpret_cast<const float*>(reinterpret_cast<const char*>(P) + (ro.z + ck[0]));
+    const float* pd = reinterpret_cast<const float*>(reinterpret_cast<const char*>(P) + (ro.w + ck[0]));
+    const float* pu = reinterpret_cast<const float*>(reinterpret_cast<const char*>(L) + (rl.x + ck[0]));
+    const float* pv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(L) + (rl.y + ck[0]));
 #pragma unroll
-      for (int k = 0; k < NCH; ++k) {
+    for (int k = 0; k < NCH; ++k) {
+      if (k < NFULL) {
         tv.a[k] = pa[16 * k];
         tv.b[k] = pb[16 * k];
         tv.c[k] = pc[16 * k];
         tv.d[k] = pd[16 * k];
         tv.u[k] = pu[16 * k];
         tv.v[k] = pv[16 * k];
+      } else {
+        tv.a[k] = ldb(P, ro.x + ck[k]);
+        tv.b[k] = ldb(P, ro.y + ck[k]);
+        tv.c[k] = ldb(P, ro.z + ck[k]);
+        tv.d[k] = ldb(P, ro.w + ck[k]);
+        tv.u[k] = ldb(L, rl.x + ck[k]);
+        tv.v[k] = ldb(L, rl.y + ck[k]);
       }
-      return;
-    }
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-      tv.a[k] = ldb(P, ro.x + ck[k]);
-      tv.b[k] = ldb(P, ro.y + ck[k]);
-      tv.c[k] = ldb(P, ro.z + ck[k]);
-      tv.d[k] = ldb(P, ro.w + ck[k]);
-      tv.u[k] = ldb(L, rl.x + ck[k]);
-      tv.v[k] = ldb(L, rl.y + ck[k]);
     }
   }
   // out-of-range texels never receive anything (their weights are zero), so a clamped address is fine.
@@ -189,7 +187,7 @@ struct RecWalker {
         if (!live[k]) continue;
         if (FX == 1 || (FX == 2 && fixed))  // byte offset of a float element -> the same element of the 64-bit shadow buffer
           fixed_add(reinterpret_cast<long long*>(reinterpret_cast<char*>(base) + 2 * (size_t)(off + ck[k])), a[k]);
-        else if (CA % 16 == 0)
+        else if (k < CA / 16)
           atomicAdd(t0 + 16 * k, a[k]);
         else
           atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (off + ck[k])), a[k]);
