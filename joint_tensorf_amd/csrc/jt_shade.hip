@@ -257,8 +257,10 @@ __device__ inline void sincos_f(float x, float* sn, float* cs) {
 // Used where the encoding enters a GRADIENT only -- the derivative factors of the backward chain and the layer-1 input
 // of the weight-gradient GEMM -- never for the forward's values (sincos_f).
 __device__ inline void sincos_grad(float x, float* sn, float* cs) {
-  *sn = __sinf(x);
-  *cs = __cosf(x);
+  // the instructions take revolutions and are defined on [-256, 256] only: the fraction keeps any finite x in range
+  const float rev = __builtin_amdgcn_fractf(x * 0.15915494309189535f);
+  *sn = __builtin_amdgcn_sinf(rev);
+  *cs = __builtin_amdgcn_cosf(rev);
 }
 
 // the five values (x, PE(x)) lane-half h feeds into layer 1 for accumulator row r:
