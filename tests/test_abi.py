@@ -61,3 +61,8 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert _lib.lib.jt_blur_forward(None, None, None, 4, 4, 16, None, 65, None) == 1
     s = _lib.JtScene()
     assert _lib.lib.jt_shade_workspace_bytes(ctypes.byref(s), 1000) == 0  # unsupported shape -> 0
+    # the device-memory variants used under hipGraph replay insist on their device arrays
+    assert _lib.lib.jt_render_loss_forward_ind(None, None, None, 0, 1, 1, 1, 1.0, 1.0, None, None, None) == 1
+    assert _lib.lib.jt_render_loss_backward_ind(None, None, None, 0, 1, 1, 1, 1.0, 1.0, None, None, None, None) == 1
+    assert _lib.lib.jt_loss_sum_forward_dyn(None, None, None, None, None) == 1
+    assert _lib.lib.jt_finite_check(None, 0, None, None) == 1
