@@ -172,8 +172,8 @@ struct RecWalker {
   // out-of-range texels never receive anything (their weights are zero), so a clamped address is fine.
   // base == nullptr: the caller does not want factor gradients (pose-only backward), nothing is written.
   __device__ inline void flush(float* base, unsigned off, float* a) {
-    // (CA % 16 == 0: the texel's byte offset plus the lane's first channel once, the 64-byte channel step as an
-    //  immediate offset of the atomic)
+    // (full channel groups, k < CA / 16: the texel's byte offset plus the lane's first channel once, the 64-byte group
+    //  step as an immediate offset of the atomic)
     float* t0 = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (off + ck[0]));
     // ONE test per slot: a slot that received anything has (with measure-zero exceptions) all of the lane's channels
     // non-zero, and adding an exact zero changes nothing -- a test per channel was a compare, an exec-mask save and a
