@@ -9,9 +9,16 @@ Inputs (images, cameras, parameters) are resident in HBM before the timed region
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config bat_blender_VM] [--stage 4]
 
-N > 1: launched by torch.distributed.run, one rank per GPU; every rank renders its own ray batch
-(weak scaling) and the VM-factor / basis / MLP / pose gradients are summed with one RCCL
-all-reduce per iteration.
+N = 1 (default): BASELINE.json configs[1], the bat_blender_VM final-stage training step (about 2 000 rays per iteration).
+N > 1: one rank per GPU over RCCL.  Under a launcher (torch.distributed.run: RANK / WORLD_SIZE / MASTER_* in the
+environment) this process is one rank; without one, `python bench.py --gpus N` starts its own N rank processes before it
+touches a GPU and relays rank 0's line.  The workload is BASELINE.json configs[3]: ONE 65 536-nominal-ray iteration
+(step-16 lattice over 100 views = 62 500 rays, model/nerf.py:655-673) split over the ranks -- STRONG scaling; the ranks
+together render exactly the rays one process would (`--shard pixel`: every rank takes the lattice points rank::N of all
+views; `--shard view`: the views rank::N on the whole lattice), the VM-factor / basis / MLP gradients are summed by three
+all-reduces inside the backward and the pose gradients by one after it.  The N = 1 point of that curve is
+`--gpus 1 --total-rays 65536` (also reported as extra.configs3_single_gpu of the default line).  `--weak` instead keeps
+the yaml's ray count on every rank, each on a lattice of its own.
 """
 import argparse
 import json
@@ -58,8 +65,66 @@ def parse():
     ap.add_argument("--weak", action="store_true",
                     help="N > 1: every rank renders the yaml's own ray count (weak scaling) instead of the default, "
                          "BASELINE.json configs[3]: 65 536 nominal rays per iteration sharded N ways (strong scaling)")
-    ap.add_argument("--total-rays", type=int, default=65536, help="nominal rays per iteration of the strong-scaling mode")
+    ap.add_argument("--total-rays", type=int, default=0,
+                    help="nominal rays per iteration of the strong-scaling mode (default 65536 when N > 1); given at N = 1 "
+                         "it runs that whole iteration on one GPU: the N = 1 point of the strong-scaling curve")
+    ap.add_argument("--shard", default=None, choices=["pixel", "view", "offset"],
+                    help="how the iteration's rays are split over the ranks (Graph.ray_shard): pixel (default, strong), "
+                         "view (SURVEY 8(e)), offset (every rank a lattice of its own: the --weak mode)")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start N FRESH rank processes -- this parent has not
+    touched a GPU (torch.cuda.device_count() does not initialise one on this image) and never does -- wire them up the
+    way torch.distributed.run would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), relay rank 0's
+    stdout and leave with the worst exit code.  A rank that dies takes the others with it (by PID)."""
+    import socket
+    import subprocess
+    n = args.gpus
+    single = os.environ.get("JT_BENCH_SINGLE_DEVICE") == "1"
+    ndev = torch.cuda.device_count()
+    if ndev < n and not single:
+        print("bench.py: --gpus %d but %d GPU(s) visible (JT_BENCH_SINGLE_DEVICE=1 JT_DIST_BACKEND=gloo runs all ranks "
+              "on GPU 0 as a functional test)" % (n, ndev), file=sys.stderr)
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   JT_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0 = None
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                try:
+                    if r == 0:
+                        out0 = procs[0].communicate(timeout=0.5)[0]
+                    else:
+                        procs[r].wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    continue
+                pending.discard(r)
+                if procs[r].returncode != 0:
+                    rc = rc or procs[r].returncode or 1
+                    for q in pending:   # the rendezvous of the others would hang: stop exactly the PIDs started here
+                        procs[q].terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    return rc
 
 
 # JT_FORCE_DIST=1 under `torch.distributed.run --nproc-per-node 1`: a process group of ONE rank on RCCL, all
@@ -68,6 +133,7 @@ FORCE_DIST = os.environ.get("JT_FORCE_DIST") == "1"
 
 
 def setup_dist(args):
+    """(world, rank, local device, backend name) of this rank process"""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -81,9 +147,10 @@ def setup_dist(args):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    else:
-        torch.cuda.set_device(0)
-    return world, rank, local
+        world, rank = dist.get_world_size(), dist.get_rank()  # what the process group says, not what the env said
+        return world, rank, local, dist.get_backend()
+    torch.cuda.set_device(0)
+    return world, rank, local, None
 
 
 def stage_setup(opt, stage):
@@ -113,21 +180,6 @@ def build_model(opt, it0, n_views):
     model.it = it0
     model.graph.nerf.set_progress(it0 / opt.max_iter)
     return model
-
-
-OVERLAP = os.environ.get("JT_DIST_OVERLAP", "1") != "0"
-
-
-def allreduce_grads(model, world):
-    if world == 1 and not FORCE_DIST:
-        return
-    from joint_tensorf_amd import dist as jdist
-    if OVERLAP:
-        # the renderer's backward has already reduced the scene gradients (ops.set_data_parallel); what left
-        # through the rays -- the pose refinements -- is reduced here
-        jdist.allreduce_gradients([model.graph.se3_refine.weight], world, force=FORCE_DIST)
-    else:
-        jdist.allreduce_gradients(list(model.graph.parameters()), world, force=FORCE_DIST)
 
 
 def _cpu_oracle_rate(grid, S, rays_per_view, seconds_budget, blur_off=True):
@@ -351,6 +403,8 @@ def run_extras():
              ("parent_yaml_299cube_4096rays", ["--n-voxel-final", "27000000", "--n-rays", "4096"], {}),
              ("llff_final_grid", ["--config", "bat_llff_VM_MLP"], {}),
              ("llff_final_grid_it30000_hipgraph", ["--config", "bat_llff_VM_MLP", "--it", "30000"], {"JT_GRAPH": "1"}),
+             # the N = 1 point of the strong-scaling curve: the WHOLE 62 500-ray iteration of BASELINE.json configs[3]
+             ("configs3_single_gpu", ["--total-rays", "65536", "--steps", "8", "--warmup", "2"], {}),
              ("blobs_eager", ["--scene", "blobs"], {}),
              ("blobs_hipgraph", ["--scene", "blobs"], {"JT_GRAPH": "1"})]
     out = {}
@@ -377,7 +431,12 @@ def run_extras():
 
 def main():
     args = parse()
-    world, rank, local = setup_dist(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not FORCE_DIST:
+        sys.exit(launch_ranks(args))   # nothing in this process has touched the GPU
+    world, rank, local, backend = setup_dist(args)
+    if world != args.gpus and not FORCE_DIST:
+        print("bench.py: --gpus %d but the process group has %d rank(s)" % (args.gpus, world), file=sys.stderr)
+        sys.exit(3)
     dev = "cuda:%d" % local
     import joint_tensorf_amd  # noqa: F401  (fails loudly without the HIP library)
     from joint_tensorf_amd.options import make_options
@@ -397,26 +456,27 @@ def main():
         opt.nerf.n_rays = opt.train_schedule.n_rays_rest
     if args.n_rays:
         opt.nerf.n_rays = args.n_rays
-    strong = world > 1 and not args.weak and not args.n_rays
-    if strong:  # BASELINE.json configs[3]: one 65 536-nominal-ray iteration, ray-sharded over the ranks
-        opt.nerf.n_rays = args.total_rays // world
+    # BASELINE.json configs[3]: ONE 65 536-nominal-ray iteration (the GLOBAL count: the lattice stride follows from it,
+    # model/nerf.py:660-662), split over the ranks by Graph.ray_shard -- or rendered whole at N = 1 (--total-rays)
+    strong = not args.weak and not args.n_rays and (world > 1 or args.total_rays > 0)
+    total_rays = (args.total_rays or 65536) if strong else 0
+    shard = (args.shard or "pixel") if strong else "offset"
+    if strong:
+        opt.nerf.n_rays = total_rays
     n_views = int(opt.data.num_views)
     model = build_model(opt, it0, n_views)
     if args.scene == "blobs":
         from joint_tensorf_amd.synthetic import bake_blobs
         bake_blobs(model.graph.nerf.tensorf, n_blobs=12, seed=0)
-    if (world > 1 or FORCE_DIST) and OVERLAP:
-        from joint_tensorf_amd import ops as jops
-        jops.set_data_parallel(world, force=FORCE_DIST)
-        model.render_loss_scale = 1.0 / world
     var_all = make_views(opt, n_views, seed=0, device=dev)
+    if world > 1 or FORCE_DIST:
+        # the scene gradients are all-reduced inside the renderer's backward, the pose gradients behind it; the host
+        # draws (lattice offsets, blur scale) come from NumPy's global generator, seeded identically on every rank
+        model.enable_data_parallel(opt, rank, world, shard=shard, force=FORCE_DIST)
+        var_all = model.local_views(var_all)       # "view" sharding: this rank's views only
+        torch.manual_seed(1000 + rank)              # per-ray jitter: a stream per rank (parameters were built above)
     nerf = model.graph.nerf
     res, S = nerf.resolution, nerf.n_samples
-    # the host draws (lattice offsets, blur scale) come from NumPy's global generator, seeded identically on every
-    # rank; each rank shifts the lattice draw inside the draw's class (dist.rank_lattice_offset): different pixels per
-    # GPU, the same ray count on every GPU in every iteration (no straggler at the all-reduce)
-    if world > 1:
-        model.graph.lattice_rank = (rank, world)
     if args.probe_only:
         from joint_tensorf_amd.options import Opt
         print(json.dumps(measure_roofline(model, opt, Opt(dict(var_all)), reps=10)))
@@ -450,11 +510,8 @@ def main():
         var = g.forward(opt, var, mode="train")
         loss = g.compute_loss(opt, var, mode="train")
         loss = model.summarize_loss(opt, var, loss)
-        if OVERLAP:
-            loss.all.backward()  # render term already scaled by 1 / world (model.render_loss_scale)
-        else:
-            (loss.all / world).backward()
-        allreduce_grads(model, world)
+        loss.all.backward()  # render term scaled to its share of the global mean (var.dp_render_scale)
+        model.reduce_pose_gradients()
         if os.environ.get("JT_BENCH_CHECKSUM") == "1":
             with torch.no_grad():
                 tf = model.graph.nerf.tensorf
@@ -540,7 +597,7 @@ def main():
     # the gradient exchange alone: the three collectives of a backward (appearance factors, density factors, basis +
     # MLP; ops.RenderRays.backward) on buffers of the same sizes, not overlapped with anything, median of 5
     allreduce_ms = None
-    if (world > 1 or FORCE_DIST) and OVERLAP and jops_t._DP.get("span_elems"):
+    if (world > 1 or FORCE_DIST) and jops_t._DP.get("span_elems"):
         import torch.distributed as dist
         allreduce_ms = {}
         for (lo, hi), n in sorted(jops_t._DP["span_elems"].items()):
@@ -563,8 +620,12 @@ def main():
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt, rays_all = float(tmax[0]), float(tsum[1])
+        per_rank = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(per_rank, t[1:2].contiguous())
+        rays_per_rank = [float(v) / args.steps for v in per_rank]
     else:
         rays_all = float(rays_total)
+        rays_per_rank = [rays_all / args.steps]
 
     if rank == 0:
         out = {
@@ -595,12 +656,25 @@ def main():
                 "launch": ("hipGraph replay (%(replayed)d replayed / %(captured)d captured / %(eager)d eager steps)"
                            % stepper.stats) if stepper is not None else "eager",
                 "abi_calls_per_step": n_calls[0] or None,
-                "parallelism": ("ray-sharded data parallel x%d, %d nominal rays per iteration in total, RCCL all-reduce "
-                                "of the VM-factor / basis / MLP gradients inside the backward + pose gradients"
-                                % (world, args.total_rays)) if strong else
-                               ("ray-sharded data parallel x%d, yaml ray count on every rank" % world if world > 1 else "1 GPU"),
+                "parallelism": ("ray-sharded data parallel x%d (%s shards of ONE %d-nominal-ray iteration = %d rays: the "
+                                "ranks together render exactly the single-process iteration), all-reduce of the VM-factor / "
+                                "basis / MLP gradients inside the backward + pose gradients behind it"
+                                % (world, shard, total_rays, int(round(sum(rays_per_rank))))) if (strong and world > 1) else
+                               ("1 GPU, the whole %d-nominal-ray iteration of configs[3] (N = 1 point of the strong-scaling "
+                                "curve)" % total_rays if strong else
+                                ("ray-sharded data parallel x%d, yaml ray count on every rank, a lattice per rank" % world
+                                 if world > 1 else "1 GPU")),
             },
         }
+        if world > 1 or FORCE_DIST:
+            import torch.distributed as dist
+            out["ranks"] = {"world_size": dist.get_world_size(), "backend": backend,
+                            "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
+                            "devices": "one GPU per rank" if os.environ.get("JT_BENCH_SINGLE_DEVICE") != "1"
+                                       else "ALL RANKS ON GPU 0 (functional test, not a scaling measurement)",
+                            "shard": shard, "rays_per_iter_per_rank": rays_per_rank,
+                            "launcher": "bench.py --gpus N (self-launched ranks)"
+                                        if os.environ.get("JT_BENCH_SELF_LAUNCHED") == "1" else "external (torch.distributed.run)"}
         if allreduce_ms is not None:
             out["allreduce_ms"] = allreduce_ms
         if os.environ.get("JT_BENCH_CHECKSUM") == "1":  # validation of the N > 1 paths against each other
@@ -635,12 +709,12 @@ def main():
                 else:
                     out["roofline"] = {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None,
                                        "traffic": None, "note": "no in-step launch timed (hipGraph replay)"}
-                if not args.no_probe:  # the same kernels as isolated back-to-back launches on one fixed lattice batch
+                if not args.no_probe and not strong:  # the same kernels as isolated back-to-back launches on one fixed lattice batch
                     out["roofline"]["probe"] = measure_roofline(model, opt, Opt(dict(var_all)))
             except Exception as e:  # keep the bench line even if the timing is unavailable
                 out["roofline"] = {"error": repr(e)}
-        if world == 1 and not args.no_torch_baseline and args.config == "bat_blender_VM" and args.scene == "random" \
-                and not model.graph.resolve_blur(opt, "vis")[2]:
+        if world == 1 and not strong and not args.no_torch_baseline and args.config == "bat_blender_VM" \
+                and args.scene == "random" and not model.graph.resolve_blur(opt, "vis")[2]:
             try:
                 from joint_tensorf_amd.options import Opt
                 out["torch_gpu_baseline"] = torch_gpu_baseline(opt, model, Opt(dict(var_all)))
@@ -650,9 +724,9 @@ def main():
                                            "(torch_gpu_baseline)")
             except Exception as e:
                 out["torch_gpu_baseline"] = {"error": repr(e)[:300]}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not strong and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(res, S)
-        if world == 1 and not args.no_extras:
+        if world == 1 and not strong and not args.no_extras:
             # free this process' device memory first: the children build their own models
             del model
             jops_t._WS.clear()

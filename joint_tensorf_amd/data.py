@@ -50,14 +50,44 @@ class SyntheticDataset(DictDataset):
         super().__init__(opt, var, split)
 
 
+class RenderedDataset(DictDataset):
+    """The self-consistent synthetic scene (`opt.data.synthetic: rendered`): cameras as SyntheticDataset's, images RENDERED
+    from one known ground-truth field (synthetic.make_gt_scene) at those cameras by the HIP evaluation renderer -- pictures
+    of a scene taken from the poses the run is scored against, which is what the reference's image sets are.  Train and
+    test splits look at the same field from different cameras.  Needs the GPU."""
+
+    def __init__(self, opt, split="train", subset=None):
+        from .synthetic import make_rendered_views
+        n = int(opt.data.num_views) if split == "train" else int(opt.data.get("num_test_views", 4))
+        if subset:
+            n = min(n, int(subset))
+        seed = int(opt.get("seed", 0)) + (0 if split == "train" else 1000)
+        var = make_rendered_views(opt, n, seed=seed, device=opt.device)
+        super().__init__(opt, var, split)
+
+
 def load(opt, split, subset=None):
-    """The reference's `data.<dataset>.Dataset` when its package is importable (this build dropped into the reference
-    tree) and the image set exists; the synthetic scene otherwise or when opt.data.synthetic is set."""
-    if not opt.data.get("synthetic", False):
+    """Which dataset object a run gets, recorded in `opt.data.dataset_class` and printed:
+    * `opt.data.synthetic` = "rendered": RenderedDataset; any other true value ("noise"): SyntheticDataset;
+    * otherwise the reference's `data.<dataset>.Dataset` (this build dropped into the reference tree).  Only a MISSING
+      loader module falls back to the synthetic noise scene, loudly; a loader that is there and fails (wrong path, missing
+      dependency of its own, bad file) raises -- a run must not finish on noise images by accident."""
+    syn = opt.data.get("synthetic", False)
+    if syn:
+        ds = RenderedDataset(opt, split=split, subset=subset) if str(syn) == "rendered" \
+            else SyntheticDataset(opt, split=split, subset=subset)
+    else:
+        import importlib
+        name = "data.{}".format(opt.data.dataset)
         try:
-            import importlib
-            mod = importlib.import_module("data.{}".format(opt.data.dataset))
-            return mod.Dataset(opt, split=split, subset=subset)
-        except Exception:
-            pass
-    return SyntheticDataset(opt, split=split, subset=subset)
+            mod = importlib.import_module(name)
+        except ImportError as e:
+            if getattr(e, "name", None) not in (name, "data"):
+                raise          # the loader exists; one of ITS imports is missing
+            print("joint_tensorf_amd: WARNING -- no dataset loader `%s` on the path (%s); %s split is the SYNTHETIC NOISE "
+                  "scene (set opt.data.synthetic to choose it deliberately)" % (name, e, split))
+            mod = None
+        ds = mod.Dataset(opt, split=split, subset=subset) if mod is not None \
+            else SyntheticDataset(opt, split=split, subset=subset)
+    opt.data.dataset_class = type(ds).__module__ + "." + type(ds).__name__
+    return ds

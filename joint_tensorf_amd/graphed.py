@@ -122,7 +122,7 @@ class GraphedTrainStep:
                 and (not has(opt.optim, "pose_grad_accum_iter") or int(opt.optim.pose_grad_accum_iter) == 1)
                 and self._near_plane_settled(opt)
                 and isinstance(m.optim, VMAdam)
-                and ops.data_parallel_world() == 1 and not ops._DP["force"])
+                and ops.data_parallel_world() == 1 and not ops._DP["force"] and self.model.graph.ray_shard is None)
 
     def _near_plane_settled(self, opt):
         """LLFF: the near plane follows tensorf_near_plane_schedule (model/tensorf.py:230-232) and is a launch argument
@@ -221,10 +221,6 @@ class GraphedTrainStep:
                            for w_ in ((True,) if bool(opt.nerf.setbg_opaque) else (True, False)))
         np_state = None if complete else np.random.get_state()
         ox, oy = np.random.randint(step), np.random.randint(step)
-        if g.lattice_rank is not None:
-            from .dist import rank_lattice_offset
-            ox = rank_lattice_offset(ox, step, opt.W, *g.lattice_rank)
-            oy = rank_lattice_offset(oy, step, opt.H, *g.lattice_rank)
         blur = g.resolve_blur(opt, "train")  # consumes the blur-scale draw exactly like the eager path
         # factor blur on: same graph for every (schedule value, random scale) -- the two tap vectors are static device
         # memory, rewritten below in front of the replay

@@ -203,7 +203,15 @@ class Graph(torch.nn.Module):
         self.pose_eye = torch.eye(3, 4, device=opt.device)
         self.tvloss = tensorf_repr.TVLoss()
         self.sim3 = None
-        self.lattice_rank = None  # (rank, world) under ray-sharded data parallelism (dist.rank_lattice_offset)
+        # ray-sharded data parallelism (Model.enable_data_parallel).  ray_shard = (mode, rank, world):
+        #   "pixel"  every rank renders ALL views on the points rank::world of the iteration's pixel lattice,
+        #   "view"   every rank renders the FULL lattice on the views rank::world (the caller hands it those views only;
+        #            global_views = the view count the lattice stride is derived from, model/nerf.py:660-662)
+        #            -- either way the ranks together render exactly the iteration one process would;
+        #   "offset" every rank renders a whole lattice of its own, shifted inside the shared draw's class
+        #            (dist.rank_lattice_offsets: weak scaling).
+        self.ray_shard = None
+        self.global_views = None
         self.eval_graph = None
         self.lattice_override = None  # callable(step) -> (ray_idx, grid_H, grid_W); see graphed.GraphedTrainStep
 
@@ -286,15 +294,24 @@ class Graph(torch.nn.Module):
                 var.ray_idx, var.grid_H, var.grid_W = self.lattice_override(step)
                 var.ray_grid_step = step
             elif strat == "all_view_rand_grid":
-                step = self.lattice_step(opt, batch_size)
-                ox, oy = np.random.randint(step), np.random.randint(step)
-                if self.lattice_rank is not None:  # ray-sharded data parallelism: same draw, same count, other pixels
-                    from ..dist import rank_lattice_offset
-                    ox = rank_lattice_offset(ox, step, opt.W, *self.lattice_rank)
-                    oy = rank_lattice_offset(oy, step, opt.H, *self.lattice_rank)
+                shard = self.ray_shard
+                step = self.lattice_step(opt, self.global_views or batch_size)
+                ox, oy = np.random.randint(step), np.random.randint(step)  # shared by all ranks (same seeded generator)
+                if shard is not None and shard[0] == "offset":  # same draw, same count, other pixels
+                    from ..dist import rank_lattice_offsets
+                    ox, oy = rank_lattice_offsets(ox, oy, step, opt.W, opt.H, shard[1], shard[2])
                 nx, ny = len(range(ox, opt.W, step)), len(range(oy, opt.H, step))
                 var.ray_idx = self._lattice_base(opt, step, ny, nx) + (ox + oy * opt.W)
                 var.ray_grid_step, var.grid_H, var.grid_W = step, ny, nx
+                if shard is not None and shard[0] == "pixel":
+                    var.ray_idx = var.ray_idx[shard[1]::shard[2]]
+                    var.grid_H = var.grid_W = None  # a shard is not a 2-D grid (compute_loss: TV_depth)
+                    # the photometric term is the mean over the GLOBAL ray batch: local mean x local / global count
+                    var.dp_render_scale = len(range(shard[1], nx * ny, shard[2])) / float(nx * ny)
+                elif shard is not None and shard[0] == "view":
+                    var.dp_render_scale = batch_size / float(self.global_views or batch_size)
+                elif shard is not None:
+                    var.dp_render_scale = 1.0 / shard[2]
             else:
                 assert strat == "single_view_rand_rays"
                 var.ray_idx = torch.randperm(opt.H * opt.W, device=opt.device)[:opt.nerf.n_rays]
@@ -413,7 +430,12 @@ class Graph(torch.nn.Module):
         loss.L1 = tf.density_L1()
         loss.TV_density = tf.TV_loss_density(self.tvloss)
         loss.TV_color = tf.TV_loss_app(self.tvloss)
-        if mode == "train" and opt.nerf.ray_sampling_strategy == "all_view_rand_grid" and "TV_depth" in opt.loss_weight:
+        if mode == "train" and opt.nerf.ray_sampling_strategy == "all_view_rand_grid" and "TV_depth" in opt.loss_weight \
+                and var.get("grid_H") is None:
+            # a pixel shard of the lattice has no neighbours to difference; the BAT yamls weight the term 0.0
+            if float(opt.loss_weight.TV_depth or 0.0) != 0.0:
+                raise NotImplementedError("TV_depth with a non-zero weight under pixel-sharded data parallelism")
+        elif mode == "train" and opt.nerf.ray_sampling_strategy == "all_view_rand_grid" and "TV_depth" in opt.loss_weight:
             d = var.depth.reshape(batch_size, var.grid_H, var.grid_W)
             loss.TV_depth = torch.pow(d[:, 1:, :] - d[:, :-1, :], 2).sum() / var.grid_H + \
                 torch.pow(d[:, :, 1:] - d[:, :, :-1], 2).sum() / var.grid_W
@@ -484,12 +506,49 @@ class Model(torch.nn.Module):
             gamma = (opt.optim.lr_pose_end / opt.optim.lr_pose) ** (1.0 / opt.max_iter)
             self.sched_pose = torch.optim.lr_scheduler.ExponentialLR(self.optim_pose, gamma=gamma)
 
+    # ---- ray-sharded data parallelism (the reference is single-GPU, options.py:126) -------------------
+    def enable_data_parallel(self, opt, rank, world, shard="pixel", group=None, force=False):
+        """One process per GPU, torch.distributed already initialised ("nccl" = RCCL over xGMI).  The iteration's rays
+        are split over the ranks (Graph.ray_shard: "pixel" | "view" | "offset"), the scene gradients are SUM-all-reduced
+        inside the renderer's backward (ops.set_data_parallel), the pose gradients after it (train_iteration), the
+        optimizer steps are replicated.  Host draws must come from identically seeded generators on every rank."""
+        assert shard in ("pixel", "view", "offset"), shard
+        ops.set_data_parallel(world, group=group, force=force)
+        self.dp = Opt(rank=int(rank), world=int(world), shard=shard, group=group, force=bool(force))
+        g = self.graph
+        g.ray_shard = (shard, int(rank), int(world))
+        g.global_views = int(g.se3_refine.weight.shape[0]) if shard == "view" else None
+        self.render_loss_scale = 1.0 / world  # the per-iteration value (unequal shards) travels in var.dp_render_scale
+        self._dp_local_views = None
+
+    def local_views(self, var_all):
+        """The views this rank renders, as a `var`-layout dict: all of them except under "view" sharding, where it is
+        the views rank::world (sliced once per source dict and remembered: the per-view tensors are static)."""
+        dp = getattr(self, "dp", None)
+        if dp is None or dp.shard != "view":
+            return var_all
+        memo = self._dp_local_views
+        if memo is None or memo[0] is not var_all:
+            n = len(var_all.idx)
+            from ..dist import shard_indices
+            sel = torch.tensor(shard_indices(n, dp.rank, dp.world), device=var_all.idx.device)
+            local = Opt({k: (v[sel] if torch.is_tensor(v) and v.shape[:1] == (n,) else v) for k, v in dict(var_all).items()})
+            self._dp_local_views = memo = (var_all, local)
+        return memo[1]
+
+    def reduce_pose_gradients(self):
+        """what left the renderer through the rays: the se(3) refinements' gradient, summed over the ranks (2.4 KB)"""
+        dp = getattr(self, "dp", None)
+        if dp is not None and (dp.world > 1 or dp.force):
+            from ..dist import allreduce_gradients
+            allreduce_gradients([self.graph.se3_refine.weight], dp.world, group=dp.group, force=dp.force)
+
     def summarize_loss(self, opt, var, loss):
         """model/tensorf.py:31-47 (linear weights; the finiteness asserts would force a host sync per
         iteration and are left to the caller)."""
         total = 0.0
         # ray-sharded data parallelism: only the photometric term is a mean over the (global) ray batch
-        render_scale = float(getattr(self, "render_loss_scale", 1.0))
+        render_scale = float(var.get("dp_render_scale", None) or getattr(self, "render_loss_scale", 1.0))
         fused = self._summarize_fused(opt, loss, render_scale)
         if fused is not None:
             loss.update(all=fused)
@@ -558,6 +617,7 @@ class Model(torch.nn.Module):
             loss = self.summarize_loss(opt, var, loss)
         with ops.prof_range("loss.all.backward()"):
             loss.all.backward()
+        self.reduce_pose_gradients()
         if (not _has(opt.optim, "grad_accum_iter")) or (self.it % opt.optim.grad_accum_iter) == 0:
             with ops.prof_range("optim.step"):
                 self.optim.step()
@@ -673,7 +733,8 @@ class Model(torch.nn.Module):
             self.group_idx = [all_views[i::ng] for i in range(ng)]
         freq = opt.get("freq", Opt())
         f_scalar, f_val, f_ckpt = (int(freq.get(k, 0) or 0) for k in ("scalar", "val", "ckpt"))
-        images_all = self.train_data.all.image
+        data_all = self.local_views(self.train_data.all)  # this rank's views (all of them unless view-sharded)
+        images_all = data_all.image
         loss, t0 = None, time.time()
         stepper = None
         if _has(opt, "train_graph") and opt.train_graph and str(opt.device).startswith("cuda"):
@@ -693,7 +754,7 @@ class Model(torch.nn.Module):
                 continue
             self.before_iteration(opt, it)
             train_images, train_edge_masks, sc = self.select_supervision(opt, images_all)
-            var = Opt(dict(self.train_data.all))
+            var = Opt(dict(data_all))
             var.image, var.train_edge_masks = train_images, train_edge_masks
             if _has(opt, "sync_2d_3d_scales") and opt.sync_2d_3d_scales:
                 var.scale = sc

@@ -84,3 +84,129 @@ def bake_blobs(tensorf, n_blobs=12, seed=0, amplitude=60.0, radius=(0.12, 0.3), 
     plane[0, C - 1] = background
     line[0, C - 1] = 1.0
     return n_blobs
+
+
+# ---- a self-consistent scene: supervising images RENDERED from a known field at the known poses ---------------------
+# (what the reference gets from its image sets: model/nerf.py:35-40 loads pictures of ONE scene taken from the poses the
+#  run is scored against, model/bat.py:229-263.  Uniform-noise images, make_views' default, have no such scene behind them:
+#  the joint optimisation then has nothing to recover and the field turns into fog.)
+@torch.no_grad()
+def bake_appearance(tensorf, seed=0, amplitude=0.7, contrast=9.0):
+    """Overwrite the APPEARANCE factors with smooth low-frequency patterns (every component one plane wave over its plane
+    times one cosine along its line, 0.4 - 1.6 periods across the box) and raise the contrast of the random-init MLP's
+    last layer, so that the colour decoded at a point varies smoothly with position (and weakly with view direction)
+    over most of [0, 1]^3 -- textured, registrable content for the blobs of bake_blobs."""
+    rng = np.random.RandomState(seed + 77)
+    dev = tensorf.app_plane[0].device
+    for i in range(3):
+        plane, line = tensorf.app_plane[i], tensorf.app_line[i]
+        C, H, W, L = plane.shape[1], plane.shape[2], plane.shape[3], line.shape[2]
+        u = torch.linspace(0, 1, W, device=dev)[None, :]
+        v = torch.linspace(0, 1, H, device=dev)[:, None]
+        w = torch.linspace(0, 1, L, device=dev)
+        for c in range(C):
+            fu, fv, fw = (2 * math.pi * (0.4 + 1.2 * rng.rand()) * (1 if rng.rand() < 0.5 else -1) for _ in range(3))
+            pu, pw = 2 * math.pi * rng.rand(), 2 * math.pi * rng.rand()
+            plane[0, c] = amplitude * torch.cos(fu * u + fv * v + pu)
+            line[0, c, :, 0] = torch.cos(fw * w + pw)
+    last = tensorf.renderModule.weights()[4]
+    last.mul_(contrast)
+
+
+@torch.no_grad()
+def bake_wall(tensorf, axis_frac=0.88, thickness=0.05, amplitude=40.0, component=None):
+    """An opaque slab across the box at `axis_frac` of its z extent (rank-1: constant plane 0 times a bump on line 0): closes
+    a forward-facing (LLFF-like) scene, so that every ray ends on content as in a real photograph."""
+    plane, line = tensorf.density_plane[0], tensorf.density_line[0]
+    C, L = plane.shape[1], line.shape[2]
+    c = C - 2 if component is None else component
+    z = torch.linspace(0, 1, L, device=line.device)
+    plane[0, c] = amplitude
+    line[0, c, :, 0] = torch.exp(-((z - axis_frac) ** 2) / (2 * thickness * thickness))
+
+
+def make_gt_scene(opt, seed=0, res=None, n_blobs=12):
+    """A ground-truth field for `opt`'s configuration: the same scene class, box, ranks and MLP as the run trains, at a
+    grid of `res`^3-equivalent voxels (default opt.data.gt_res or 128), with opaque blobs (bake_blobs; an extra back wall
+    for forward-facing NDC scenes), smooth textured appearance (bake_appearance) and the blur switched off (progress 1).
+    Returns (gt_opt, gt_graph); render supervising views from it with render_views."""
+    import copy
+    from .model import bat_hip
+    g_opt = copy.deepcopy(opt)
+    res = int(res or (opt.data.get("gt_res", None) or 128))
+    g_opt.train_schedule.n_voxel_init = res ** 3
+    g_opt.train_schedule.resolution_scale_init = [1.0, 1.0, 1.0]
+    g_opt.train_schedule.upsample_iters = []
+    g_opt.train_schedule.n_voxel_final = res ** 3
+    # building the field must not move the caller's random streams (same initial parameters with or without a GT scene)
+    cpu_state = torch.get_rng_state()
+    dev_state = torch.cuda.get_rng_state(torch.device(opt.device)) if str(opt.device).startswith("cuda") else None
+    torch.manual_seed(90000 + seed)
+    try:
+        graph = bat_hip.Graph(g_opt).to(opt.device)
+    finally:
+        torch.set_rng_state(cpu_state)
+        if dev_state is not None:
+            torch.cuda.set_rng_state(dev_state, torch.device(opt.device))
+    tf = graph.nerf.tensorf
+    ndc = bool(opt.camera.ndc)
+    n = bake_blobs(tf, n_blobs=min(n_blobs, tf.density_plane[0].shape[1] - (2 if ndc else 1)), seed=seed)
+    if ndc:
+        bake_wall(tf)
+    bake_appearance(tf, seed=seed)
+    graph.nerf.set_progress(1.0)
+    graph.eval()
+    for p in graph.parameters():
+        p.requires_grad_(False)
+    graph.n_blobs = n
+    return g_opt, graph
+
+
+@torch.no_grad()
+def render_views(g_opt, graph, views, chunk=8):
+    """images [N,3,H,W] of the ground-truth field at views.pose / views.intr (the HIP evaluation renderer, mode "vis":
+    no jitter, no blur, the yaml's background)."""
+    out = []
+    n = len(views.idx)
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        ret = graph.render_by_slices(g_opt, views.pose[a:b], intr_inv=views.intr_inv[a:b], mode="vis", intr=views.intr[a:b])
+        out.append(ret.rgb.view(b - a, g_opt.H, g_opt.W, 3).permute(0, 3, 1, 2).contiguous())
+    return torch.cat(out, 0)
+
+
+_SCENES = {}
+
+
+def gt_scene_for(opt, seed=0):
+    """the ground-truth field of (configuration, image size, seed), built once per process"""
+    key = (str(opt.get("yaml", "")), str(opt.device), int(opt.H), int(opt.W), int(seed), int(opt.data.get("gt_res", None) or 128))
+    if key not in _SCENES:
+        _SCENES[key] = make_gt_scene(opt, seed=seed)
+    return _SCENES[key]
+
+
+def make_rendered_views(opt, n_views, seed=0, device="cuda", scene_seed=None):
+    """make_views with the images rendered from the ground-truth field at the views' own (ground-truth) poses."""
+    var = make_views(opt, n_views, seed=seed, device=device, with_images=False)
+    g_opt, graph = gt_scene_for(opt, seed=int(opt.get("seed", 0)) if scene_seed is None else scene_seed)
+    var.image = render_views(g_opt, graph, var)
+    var.train_edge_masks = torch.zeros(n_views, opt.H * opt.W, dtype=torch.uint8, device=device)  # rebuilt by the 2-D cache
+    return var
+
+
+@torch.no_grad()
+def load_scene_into(tensorf, gt_tensorf):
+    """Resample the ground-truth field's factors onto `tensorf`'s grid (bilinear, align_corners, like the reference's own
+    up_sampling_VM, tensoRF.py:274-295) and copy basis + MLP: a model that HAS converged to the scene -- the workload of
+    the sharp last stage of a real run (few per cent of the in-box samples shaded), without training for it."""
+    F = torch.nn.functional
+    for name in ("density_plane", "app_plane"):
+        for p, q in zip(getattr(tensorf, name), getattr(gt_tensorf, name)):
+            p.copy_(F.interpolate(q, size=p.shape[2:], mode="bilinear", align_corners=True))
+    for name in ("density_line", "app_line"):
+        for p, q in zip(getattr(tensorf, name), getattr(gt_tensorf, name)):
+            p.copy_(F.interpolate(q, size=p.shape[2:], mode="bilinear", align_corners=True))
+    tensorf.basis_mat.weight.copy_(gt_tensorf.basis_mat.weight)
+    for a, b in zip(tensorf.renderModule.weights(), gt_tensorf.renderModule.weights()):
+        a.copy_(b)

@@ -35,24 +35,43 @@ def jitter_for(rank, n=8192):
     return torch.rand(n, 1, generator=torch.Generator().manual_seed(50 + rank)).cuda()
 
 
+def global_ray_ids(opt, graph, n_views, seed, shard):
+    """The rays of the iteration whose host draws start at np.random.seed(seed) that `shard` = (mode, rank, world)
+    renders, as indices into the single-process iteration's [view, lattice point] ray list (view-major), plus that
+    list's length; the generator is left where the iteration expects it (re-seeded)."""
+    from joint_tensorf_amd.dist import shard_indices
+    np.random.seed(seed)
+    step = graph.lattice_step(opt, n_views)
+    ox, oy = np.random.randint(step), np.random.randint(step)
+    n_pts = len(range(ox, opt.W, step)) * len(range(oy, opt.H, step))
+    mode, rank, world = shard
+    views = shard_indices(n_views, rank, world) if mode == "view" else list(range(n_views))
+    pts = shard_indices(n_pts, rank, world) if mode == "pixel" else list(range(n_pts))
+    np.random.seed(seed)
+    return torch.tensor([v * n_pts + p for v in views for p in pts]), n_views * n_pts
+
+
 def main():
     out, steps = sys.argv[1], int(sys.argv[2])
+    mode = sys.argv[3] if len(sys.argv) > 3 else "offset"
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from joint_tensorf_amd import dist as jdist, ops
     from joint_tensorf_amd.options import Opt
     opt, model, var = build()
-    ops.set_data_parallel(world)
-    model.render_loss_scale = 1.0 / world
-    model.graph.lattice_rank = (rank, world)
+    model.enable_data_parallel(opt, rank, world, shard=mode)
+    var = model.local_views(var)
     tf = model.graph.nerf.tensorf
     first = None
     for it in range(steps):
         np.random.seed(100 + it)          # the host draws are shared by all ranks
-        tf.jitter_override = jitter_for(rank)
         g = model.graph
+        if mode == "offset":              # a lattice of its own per rank: a jitter stream per rank
+            tf.jitter_override = jitter_for(rank)
+        else:                             # a shard of THE iteration: the jitter of the rays it renders
+            ids, n_all = global_ray_ids(opt, g, 4, 100 + it, (mode, rank, world))
+            tf.jitter_override = jitter_for(0, n_all)[ids.cuda()]
         g.it = model.it
         model.optim.zero_grad()
         model.optim_pose.zero_grad()
@@ -60,7 +79,7 @@ def main():
         loss = g.compute_loss(opt, v, mode="train")
         loss = model.summarize_loss(opt, v, loss)
         loss.all.backward()
-        jdist.allreduce_gradients([g.se3_refine.weight], world)  # what left through the rays
+        model.reduce_pose_gradients()     # what left through the rays
         if first is None:
             first = {k: p.grad.detach().cpu().clone() for k, p in g.named_parameters() if p.grad is not None}
             first["rays"] = v.rgb.shape[0] * v.rgb.shape[1]

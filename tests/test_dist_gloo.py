@@ -132,3 +132,29 @@ def test_rank_lattice_offsets_keep_the_ray_count_and_differ():
             assert all(len(range(x, extent, step)) == n for x in offs) and offs[0] == o
             cls = [x for x in range(step) if len(range(x, extent, step)) == n]
             assert len(set(offs)) == min(8, len(cls))
+
+
+def test_two_axis_offsets_give_every_rank_its_own_pixels():
+    """dist.rank_lattice_offsets (what Graph.forward uses under "offset" sharding): the shared draw's lattice SHAPE on
+    every rank, and -- unlike the per-axis shift, which repeats as soon as one class has fewer members than ranks (the
+    5-member class of stride 45 on 400 pixels) -- pairwise different (ox, oy) while |class_x| * |class_y| >= world."""
+    from joint_tensorf_amd.dist import _offset_class, rank_lattice_offsets
+    for step, W, H in ((90, 400, 400), (45, 400, 400), (16, 400, 400), (17, 640, 480), (37, 640, 480)):
+        for ox in range(0, step, 3):
+            for oy in range(0, step, 5):
+                shape = (len(range(ox, W, step)), len(range(oy, H, step)))
+                offs = [rank_lattice_offsets(ox, oy, step, W, H, r, 8) for r in range(8)]
+                assert offs[0] == (ox, oy)
+                assert all((len(range(x, W, step)), len(range(y, H, step))) == shape for x, y in offs)
+                if len(_offset_class(ox, step, W)) * len(_offset_class(oy, step, H)) >= 8:
+                    assert len(set(offs)) == 8, (step, ox, oy, offs)
+
+
+def test_shards_partition_the_iteration():
+    """dist.shard_indices: the interleaved split behind the "pixel" and "view" shardings -- over all ranks the shards are
+    a partition, sizes differ by at most one (62 500 rays of configs[3]: 625 lattice points or 100 views over 8 ranks)."""
+    from joint_tensorf_amd.dist import shard_indices
+    for n, world in ((625, 8), (100, 8), (100, 2), (100, 4), (7, 8), (0, 2)):
+        parts = [shard_indices(n, r, world) for r in range(world)]
+        assert sorted(i for p in parts for i in p) == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1

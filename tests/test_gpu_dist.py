@@ -1,8 +1,11 @@
 """Ray-sharded data parallelism through the path a multi-GPU run takes: two FRESH processes (gloo
-rendezvous, both on GPU 0), ops.set_data_parallel -> the renderer's backward all-reduces its flat gradient buffer in
-three collectives, pose gradients through dist.allreduce_gradients.  Checked: (1) the reduced gradient of the first step
-equals the single-process gradient of the UNION of the two ranks' lattices; (2) after three optimizer steps both ranks
-hold identical parameters."""
+rendezvous, both on GPU 0), Model.enable_data_parallel -> the renderer's backward all-reduces its flat gradient buffer in
+three collectives, pose gradients through Model.reduce_pose_gradients.  Checked per sharding mode: (1) the reduced
+gradient of the first step equals the single-process gradient -- "pixel" / "view": of THE iteration one process renders
+(same draws, all views, whole lattice: the ranks' shards partition it); "offset": of the union of the two ranks' own
+lattices; (2) after three optimizer steps both ranks hold identical parameters.  Last: `bench.py --gpus 2` with no
+launcher around it starts its own two ranks."""
+import json
 import os
 import socket
 import subprocess
@@ -24,13 +27,14 @@ def _free_port():
     return p
 
 
-def test_two_ranks_equal_one_process_on_the_union_of_their_rays(tmp_path):
+@pytest.mark.parametrize("mode", ["pixel", "view", "offset"])
+def test_two_ranks_equal_one_process(tmp_path, mode):
     port = _free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), "3"],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), "3", mode],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
@@ -44,29 +48,41 @@ def test_two_ranks_equal_one_process_on_the_union_of_their_rays(tmp_path):
             assert torch.equal(r0["first"][k], r1["first"][k]), k
     assert r0["first"]["rays"] == r1["first"]["rays"]
 
-    # (1) one process, the two lattices one after the other (gradients accumulate), same draws and jitter
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dist_worker as W
     from joint_tensorf_amd.options import Opt
     opt, model, var = W.build()
     g = model.graph
     tf = g.nerf.tensorf
-    model.render_loss_scale = 0.5
     model.optim.zero_grad()
     model.optim_pose.zero_grad()
-    l1 = opt.loss_weight.L1
-    for rank in range(2):
-        np.random.seed(100)
-        tf.jitter_override = W.jitter_for(rank)
-        g.lattice_rank = (rank, 2)
+    if mode == "offset":
+        # (1) one process, the two lattices one after the other (gradients accumulate), same draws and jitter
+        l1 = opt.loss_weight.L1
+        for rank in range(2):
+            np.random.seed(100)
+            tf.jitter_override = W.jitter_for(rank)
+            g.ray_shard = ("offset", rank, 2)
+            g.it = model.it
+            if rank == 1:  # the regularisers are not part of the exchange: every rank adds them once
+                opt.loss_weight.L1 = Opt(init=0.0, rest=0.0)
+            v = g.forward(opt, Opt(dict(var)), mode="train")
+            loss = g.compute_loss(opt, v, mode="train")
+            loss = model.summarize_loss(opt, v, loss)
+            loss.all.backward()
+        opt.loss_weight.L1 = l1
+    else:
+        # (1) THE iteration: one process, all four views, the whole lattice, the same draws and per-ray jitter
+        assert r0["first"]["rays"] + r1["first"]["rays"] > 0
+        ids, n_all = W.global_ray_ids(opt, g, 4, 100, ("none", 0, 1))
+        assert n_all == r0["first"]["rays"] + r1["first"]["rays"], "the two shards partition the iteration's rays"
+        tf.jitter_override = W.jitter_for(0, n_all)
         g.it = model.it
-        if rank == 1:  # the regularisers are not part of the exchange: every rank adds them once
-            opt.loss_weight.L1 = Opt(init=0.0, rest=0.0)
         v = g.forward(opt, Opt(dict(var)), mode="train")
+        assert v.rgb.shape[0] * v.rgb.shape[1] == n_all
         loss = g.compute_loss(opt, v, mode="train")
         loss = model.summarize_loss(opt, v, loss)
         loss.all.backward()
-    opt.loss_weight.L1 = l1
     worst = ("", 0.0)
     for k, p in g.named_parameters():
         if p.grad is None:
@@ -76,5 +92,33 @@ def test_two_ranks_equal_one_process_on_the_union_of_their_rays(tmp_path):
         if e > worst[1]:
             worst = (k, e)
         assert e <= 1e-5, (k, e)
-    print("two ranks vs the union in one process: worst relative gradient difference %.2e (%s); %d rays per rank"
-          % (worst[1], worst[0], r0["first"]["rays"]))
+    print("%s shards, two ranks vs one process: worst relative gradient difference %.2e (%s); %d + %d rays"
+          % (mode, worst[1], worst[0], r0["first"]["rays"], r1["first"]["rays"]))
+
+
+def test_bench_gpus2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher: the script spawns two fresh ranks before touching the GPU (here both
+    on GPU 0 over gloo -- the one-GPU functional form), shards ONE iteration over them and prints n_gpus = 2."""
+    env = dict(os.environ, JT_BENCH_SINGLE_DEVICE="1", JT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stage", "0", "--total-rays", "8192",
+                        "--steps", "3", "--warmup", "1", "--no-probe"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    rk = line["ranks"]
+    assert rk["world_size"] == 2 and rk["backend"] == "gloo" and rk["rccl_ranks"] == 0 and rk["shard"] == "pixel"
+    assert rk["launcher"].startswith("bench.py --gpus N")
+    per = rk["rays_per_iter_per_rank"]
+    # 8192 nominal rays over 100 views: 81 per view -> stride ceil(sqrt(160000 // 81)) = 45 -> 8 or 9 points per axis
+    assert len(per) == 2 and abs(per[0] - per[1]) <= 100 and 6400 <= per[0] + per[1] <= 8100
+    assert "allreduce_ms" in line and len(line["allreduce_ms"]) == 3
+
+
+def test_bench_gpus_mismatch_is_an_error():
+    """--gpus 4 inside a process group of one rank: refuse instead of printing a line for another N"""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3 and "--gpus 4" in r.stderr

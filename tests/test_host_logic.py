@@ -157,3 +157,19 @@ def test_baked_blob_scene_is_an_exact_vm_field():
     # the grid is coarse (0.1 per texel): bilinear interpolation of a Gaussian of width >= 0.3 is good to a few %
     np.testing.assert_allclose(feat.numpy(), np.array(expect), rtol=0.08, atol=0.3)
     assert float(feat[-1]) < -11.0 and float(feat[:n].min()) > 20.0
+
+
+def test_bench_gpus_n_without_n_gpus_refuses():
+    """`python bench.py --gpus 8` on a machine with fewer GPUs: no line for another N, a non-zero exit (round 2's script
+    ignored --gpus and benchmarked one GPU)."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.device_count() >= 8:
+        import pytest
+        pytest.skip("8 GPUs visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "JT_BENCH_SINGLE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "--gpus 8" in r.stderr and not r.stdout.strip()

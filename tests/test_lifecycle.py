@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -55,6 +56,38 @@ def test_dataset_objects_have_the_reference_interface():
     assert len(batches) == 3 and batches[1]["pose"].shape == (1, 3, 4) and int(batches[1]["idx"][0]) == 1
     wrapped = jdata.DictDataset(opt, dict(ds.all))
     assert len(wrapped) == 3
+
+
+def test_data_load_falls_back_only_when_the_loader_module_is_missing(tmp_path, monkeypatch, capsys):
+    """data.load: no `data.<dataset>` module on the path -> the synthetic noise scene, with a warning
+    and the class recorded in opt.data.dataset_class; a loader that EXISTS and fails (bad path, missing dependency of
+    its own) raises instead of letting the run finish on noise images."""
+    import sys
+    from joint_tensorf_amd import data as jdata
+    for k in [k for k in sys.modules if k == "data" or k.startswith("data.")]:
+        monkeypatch.delitem(sys.modules, k)
+    opt = _small_opt()
+    opt.data.synthetic = False
+    ds = jdata.load(opt, "train")
+    assert type(ds).__name__ == "SyntheticDataset" and opt.data.dataset_class.endswith("SyntheticDataset")
+    assert "SYNTHETIC NOISE" in capsys.readouterr().out
+    pkg = tmp_path / "data"
+    pkg.mkdir()
+    (pkg / "__init__.py").write_text("")
+    (pkg / "blender.py").write_text("class Dataset:\n    def __init__(self, opt, split, subset=None):\n"
+                                    "        raise FileNotFoundError('no such image set: ' + str(split))\n")
+    monkeypatch.syspath_prepend(str(tmp_path))
+    for k in [k for k in sys.modules if k == "data" or k.startswith("data.")]:
+        monkeypatch.delitem(sys.modules, k)
+    with pytest.raises(FileNotFoundError):
+        jdata.load(opt, "train")
+    (pkg / "blender.py").write_text("import a_package_that_is_not_installed\n")
+    for k in [k for k in sys.modules if k == "data" or k.startswith("data.")]:
+        monkeypatch.delitem(sys.modules, k)
+    with pytest.raises(ImportError):
+        jdata.load(opt, "train")
+    opt.data.synthetic = True      # chosen deliberately: no loader is consulted
+    assert type(jdata.load(opt, "train")).__name__ == "SyntheticDataset"
 
 
 def _build(opt):

@@ -13,7 +13,8 @@ import json
 import sys
 from collections import defaultdict
 
-KERNELS = {"k_shade_bwd": "jt::k_shade_bwd<", "k_shade_fwd_train": "jt::k_shade_fwd<"}
+KERNELS = {"k_shade_bwd": "jt::k_shade_bwd<", "k_shade_fwd_train": "jt::k_shade_fwd<",
+           "k_march_bwd_walk": "jt::k_march_bwd_walk<", "k_march_bwd_scan": "jt::k_march_bwd_scan", "k_march_fwd": "jt::k_march_fwd"}
 
 
 def per_launch(path):
@@ -35,13 +36,29 @@ def main(fetch_csv, write_csv, bench_json, out):
     n = roof["process_samples_per_launch"]
     res = {"note": " ".join(__doc__.split("\n\n")[-1].split()), "process_samples_per_launch": n,
            "process_launches": roof["process_launches"]}
+    # the density kernels: per LISTED sample of the walk (in-box samples with a density gradient) when the bench line
+    # counted them (roofline.density_backward: the timed launches' average), else per launch only
+    db = roof.get("density_backward") or {}
+    n_listed = db.get("samples_per_launch")
+    res["density_backward_listed_samples_per_launch"] = n_listed
     for key in KERNELS:
         if key not in f or key not in w:
             continue
         fetch, write = 2.0 * f[key][0], w[key][0]
         res[key] = {"launches_averaged": f[key][2], "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
-                    "hbm_bytes_per_launch": fetch + write, "hbm_bytes_per_sample": (fetch + write) / n,
-                    "avg_us_under_pmc": f[key][1]}
+                    "hbm_bytes_per_launch": fetch + write, "avg_us_under_pmc": f[key][1]}
+        if key.startswith("k_shade"):
+            res[key]["hbm_bytes_per_sample"] = (fetch + write) / n
+            alg = roof["bytes_per_sample"] / 2 * (2 if key == "k_shade_bwd" else 1)
+            res[key]["algorithmic_bytes_per_sample"] = alg
+            res[key]["hbm_over_algorithmic"] = (fetch + write) / n / alg
+        elif n_listed and key != "k_march_fwd":
+            res[key]["hbm_bytes_per_listed_sample"] = (fetch + write) / n_listed
+    if n_listed and "k_march_bwd_walk" in res and "k_march_bwd_scan" in res:
+        tot = res["k_march_bwd_walk"]["hbm_bytes_per_launch"] + res["k_march_bwd_scan"]["hbm_bytes_per_launch"]
+        res["density_backward"] = {"hbm_bytes_per_launch": tot, "hbm_bytes_per_listed_sample": tot / n_listed,
+                                   "algorithmic_bytes_per_listed_sample": db.get("bytes_per_sample"),
+                                   "hbm_over_algorithmic": tot / n_listed / db["bytes_per_sample"] if db.get("bytes_per_sample") else None}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
