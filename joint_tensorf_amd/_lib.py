@@ -12,7 +12,9 @@ import os
 import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libjt_render.so")
+# JT_LIB_PATH: a differently built copy of the SAME library (kernel-tuning experiments, tools/build_variant.py) -- still the
+# HIP path, still no fallback
+LIB_PATH = os.environ.get("JT_LIB_PATH") or os.path.join(HERE, "lib", "libjt_render.so")
 
 c_float_p = ctypes.c_void_p  # raw device pointers travel as integers
 c_f = ctypes.c_float

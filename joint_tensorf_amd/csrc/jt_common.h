@@ -74,7 +74,12 @@ inline int make_dev(const JtScene* s, const JtFactors* f, Dev* d) {
 // that two runs from the same state produce bit-identical gradients.  A debugging aid (race detection: SURVEY section 5);
 // slower, and the callers hand int64 shadow buffers where the header says so.
 int jt_deterministic();                      // defined in jt_march.hip
-constexpr double kFixedScale = 72057594037927936.0;  // 2^56: 1.4e-17 resolution, +-128 range
+// 2^48: 3.6e-15 resolution, +-32 768 range (a gradient element of this path is far below 1; round 2 used 2^56, whose
+// +-128 wrapped silently).  A non-finite addend is replaced by kFixedPoison = 2^61 (value 8 192): sums at or above 2^60
+// in magnitude are what the caller's conversion flags (ops.py: FINITE_GRAD bit of the status word), so an overflow or a
+// NaN can no longer pass as a wrong-but-plausible gradient.
+constexpr double kFixedScale = 281474976710656.0;
+constexpr long long kFixedPoison = 1ll << 61;
 
 #define JT_LAUNCH_CHECK()                      \
   do {                                         \
@@ -238,9 +243,10 @@ __device__ inline float4 ld4q(const float* base, unsigned byte_off, int q) {
   return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off)[q];
 }
 
-// order-independent accumulation: v as 2^56 fixed point into a 64-bit word
+// order-independent accumulation: v as 2^48 fixed point into a 64-bit word
 __device__ inline void fixed_add(long long* p, float v) {
-  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn((double)v * kFixedScale));
+  const long long w = (fabsf(v) < 8192.f) ? __double2ll_rn((double)v * kFixedScale) : kFixedPoison;  // NaN fails the test
+  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)w);
 }
 
 __device__ inline float wave_sum(float v) {

@@ -1,6 +1,7 @@
 // Ray marching kernels (gfx950): sampling, density interpolation, transmittance scan, compositing,
 // and their backward.  One 64-lane wavefront owns one ray; lanes stride over the ray's samples so
 // the transmittance product is a wave prefix scan with a carry between 64-sample chunks.
+#include <atomic>
 #include <cstdlib>
 
 #include "jt_common.h"
@@ -413,14 +414,28 @@ __global__ __launch_bounds__(256) void k_march_bwd_scan(Dev D, const float* __re
   }
 }
 
-constexpr int kWalkRun = 32;  // listed samples per 16-lane group
-constexpr int kWalkSub = 8;   // samples whose step records are built at a time
-constexpr int kWalkRecW = 3 * kRecWords + 4;  // per sample: three plane records + (g_feat, z, -, -)
+constexpr int kWalkRun = 32;   // listed samples per 16-lane group
+constexpr int kWalkSub = 16;   // samples whose step records are built at a time: one per lane of the group
+constexpr int kWalkRecW = kRecWords;  // per sample: the plane's step record; its two spare words carry (g_feat, z)
 
 __device__ inline int sel3(int i, int a, int b, int c) { return i == 0 ? a : (i == 1 ? b : c); }
+__device__ inline float sel3f(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
 
+// Work item = (ray, PLANE, run of 32 listed samples), one 16-lane group each (lane = density channel); the four groups
+// of a wave hold four consecutive runs of the same (ray, plane) (the host pads runs_per_ray to a multiple of 4).
+//
+// Why one plane per group (round 3; before, a group walked its run through all three planes, 96 dependent steps): the
+// walk is LATENCY-bound, not bandwidth- or atomic-rate-bound -- on the LLFF grid its HBM-side traffic is 0.2 x the
+// algorithmic bytes and its atomic segments would take 0.39 ms of the 0.93 ms launch (profiles/round3_llff_*_before*).
+// A wave's vector-memory operations retire IN ORDER (loads and atomics share vmcnt), so the tap load of step q + 1
+// cannot return before the flush atomics of step q - 1 have retired, ~3 000 cycles with every CU issuing; what hides
+// that is more independent chains per CU.  Per-plane items are three times as many chains of a third of the length, and
+// one walker instead of three fits 6 waves per SIMD instead of 4 (and nothing spills).
+#ifndef JT_WALK_WAVES
+#define JT_WALK_WAVES 6  // waves per SIMD the walk is compiled for: 80 registers, nothing spills (7: 72 registers, 9 spilled)
+#endif
 template <int CD, bool DET>
-__global__ __launch_bounds__(256, 4) void k_march_bwd_walk(Dev D, JtFactors G, const float* __restrict__ rays_o,
+__global__ __launch_bounds__(256, JT_WALK_WAVES) void k_march_bwd_walk(Dev D, JtFactors G, const float* __restrict__ rays_o,
                                                         const float* __restrict__ rays_d,
                                                         const float* __restrict__ jitter,
                                                         const float* __restrict__ zvals,
@@ -432,112 +447,116 @@ __global__ __launch_bounds__(256, 4) void k_march_bwd_walk(Dev D, JtFactors G, c
                                                         long long* __restrict__ rays_fixed) {
   constexpr int NCH = (CD + 15) / 16;
   // + 16 words per group: the four groups of a wave read their own records in the same instruction, and a group
-  // stride that is a multiple of the 64 LDS banks would put all four on the same banks (measured: 17 % of the
-  // kernel's CU cycles in bank-conflict stalls)
+  // stride that is a multiple of the 64 LDS banks would put all four on the same banks
   __shared__ __align__(16) float s_rec[16][kWalkSub * kWalkRecW + 16];
   const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  const long item = (long)blockIdx.x * 16 + grp;
-  const int ray = (int)(item / runs_per_ray);
-  const int run = (int)(item - (long)ray * runs_per_ray);
+  // (ray, plane) of the wave: scalar
+  const long witem = (long)blockIdx.x * 16 + (grp & ~3);
+  const int per_ray = 3 * runs_per_ray;
+  const int ray = __builtin_amdgcn_readfirstlane((int)(witem / per_ray));
   if (ray >= R) return;
+  const int rem = __builtin_amdgcn_readfirstlane((int)(witem - (long)ray * per_ray));
+  const int pl = __builtin_amdgcn_readfirstlane(rem / runs_per_ray);
+  const int run = rem - pl * runs_per_ray + (grp & 3);
   const int nv = nvalid[ray];
   const int k0 = run * kWalkRun;
-  if (k0 >= nv) return;
+  if ((rem - pl * runs_per_ray) * kWalkRun >= nv) return;  // the whole wave is past the ray's list
+  const bool has_run = k0 < nv;
   const int k1 = min(k0 + kWalkRun, nv);
   Ray r;
   load_ray(D, rays_o, rays_d, jitter, tmin_in, ray, r);
   const size_t row = (size_t)ray * D.S;
   float* rec = s_rec[grp];
-  RecWalker<NCH, CD, DET ? 1 : 0> wk[3];
-#pragma unroll
-  for (int pl = 0; pl < 3; ++pl) wk[pl].init(G.density_plane[pl], G.density_line[pl], cl, DET);
-  float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+  const int H = sel3(pl, D.ph[0], D.ph[1], D.ph[2]), W = sel3(pl, D.pw[0], D.pw[1], D.pw[2]),
+            LL = sel3(pl, D.ll[0], D.ll[1], D.ll[2]);
+  const float* P = pl == 0 ? D.dP[0] : (pl == 1 ? D.dP[1] : D.dP[2]);
+  const float* L = pl == 0 ? D.dL[0] : (pl == 1 ? D.dL[1] : D.dL[2]);
+  // axes of the plane: x <-> kM0(pl), y <-> kM1(pl), line <-> kV(pl)
+  const int a0 = pl == 2 ? 1 : 0, a1 = pl == 0 ? 1 : 2, a2 = 2 - pl;
+  RecWalker<NCH, CD, DET ? 1 : 0> wk;
+  wk.init(pl == 0 ? G.density_plane[0] : (pl == 1 ? G.density_plane[1] : G.density_plane[2]),
+          pl == 0 ? G.density_line[0] : (pl == 1 ? G.density_line[1] : G.density_line[2]), cl, DET);
+  const float sx = 0.5f * (float)(W - 1) * sel3f(a0, D.inv[0], D.inv[1], D.inv[2]),
+              sy = 0.5f * (float)(H - 1) * sel3f(a1, D.inv[0], D.inv[1], D.inv[2]),
+              sl = 0.5f * (float)(LL - 1) * sel3f(a2, D.inv[0], D.inv[1], D.inv[2]);
+  // the lane's un-reduced partials of dL/d(o, d) along the plane's x / y / line axes
+  float gox = 0.f, goy = 0.f, gol = 0.f, gdx = 0.f, gdy = 0.f, gdl = 0.f;
 
-  for (int kb = k0; kb < k1; kb += kWalkSub) {
-    const int ns = min(kWalkSub, k1 - kb);
-    // step records of the next kWalkSub listed samples: one lane per (sample, plane) pair; samples past the end
-    // of the run mirror the last live one with a zero gradient (a no-op for the walker)
-    for (int pp = cl; pp < 3 * kWalkSub; pp += 16) {
-      const int smp = pp & (kWalkSub - 1), pl = pp / kWalkSub;
-      const int kk = kb + min(smp, ns - 1);
-      const bool has_prev = (smp < ns) && (kk > k0);
-      const int i = vlist[row + kk], ip = vlist[row + (has_prev ? kk - 1 : kk)];
-      const float z = sample_z(D, r, zvals, i), zp = sample_z(D, r, zvals, ip);
-      float p[3], n[3], q[3], m[3];
-      sample_point(D, r, z, p);
-      normalize(D, p, n);
-      sample_point(D, r, zp, q);
-      normalize(D, q, m);
-      const float n0 = pl == 0 ? n[kM0(0)] : (pl == 1 ? n[kM0(1)] : n[kM0(2)]);
-      const float n1 = pl == 0 ? n[kM1(0)] : (pl == 1 ? n[kM1(1)] : n[kM1(2)]);
-      const float n2 = pl == 0 ? n[kV(0)] : (pl == 1 ? n[kV(1)] : n[kV(2)]);
-      const float m0 = pl == 0 ? m[kM0(0)] : (pl == 1 ? m[kM0(1)] : m[kM0(2)]);
-      const float m1 = pl == 0 ? m[kM1(0)] : (pl == 1 ? m[kM1(1)] : m[kM1(2)]);
-      const float m2 = pl == 0 ? m[kV(0)] : (pl == 1 ? m[kV(1)] : m[kV(2)]);
-      make_step_rec(n0, n1, n2, m0, m1, m2, has_prev, sel3(pl, D.ph[0], D.ph[1], D.ph[2]),
-                    sel3(pl, D.pw[0], D.pw[1], D.pw[2]), sel3(pl, D.ll[0], D.ll[1], D.ll[2]), CD,
-                    rec + smp * kWalkRecW + pl * kRecWords);
-      if (pl == 0) {
-        rec[smp * kWalkRecW + 3 * kRecWords] = (smp < ns) ? gfeat[row + i] : 0.f;
-        rec[smp * kWalkRecW + 3 * kRecWords + 1] = z;
+  if (has_run) {
+    for (int kb = k0; kb < k1; kb += kWalkSub) {
+      const int ns = min(kWalkSub, k1 - kb);
+      // step record of the listed sample kb + cl on this plane; lanes past the end of the run mirror the last live
+      // sample with a zero gradient (a no-op for the walker)
+      {
+        const int kk = kb + min(cl, ns - 1);
+        const bool has_prev = (cl < ns) && (kk > k0);
+        const int i = vlist[row + kk], ip = vlist[row + (has_prev ? kk - 1 : kk)];
+        const float z = sample_z(D, r, zvals, i), zp = sample_z(D, r, zvals, ip);
+        float p[3], n[3], q[3], m[3];
+        sample_point(D, r, z, p);
+        normalize(D, p, n);
+        sample_point(D, r, zp, q);
+        normalize(D, q, m);
+        float* rc = rec + cl * kWalkRecW;
+        make_step_rec(sel3f(a0, n[0], n[1], n[2]), sel3f(a1, n[0], n[1], n[2]), sel3f(a2, n[0], n[1], n[2]),
+                      sel3f(a0, m[0], m[1], m[2]), sel3f(a1, m[0], m[1], m[2]), sel3f(a2, m[0], m[1], m[2]), has_prev, H,
+                      W, LL, CD, rc);
+        rc[18] = (cl < ns) ? gfeat[row + i] : 0.f;
+        rc[19] = z;
       }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    // plane by plane over the sub-run (one walker's taps in flight at a time keeps the register count down)
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-      const float* rp = rec + pl * kRecWords;
-      const float sx = 0.5f * (float)(D.pw[pl] - 1) * D.inv[kM0(pl)], sy = 0.5f * (float)(D.ph[pl] - 1) * D.inv[kM1(pl)],
-                  sl = 0.5f * (float)(D.ll[pl] - 1) * D.inv[kV(pl)];
-      TapBuf<NCH> bufA, bufB;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      TapBuf<NCH> bufA, bufB, bufC;
       auto step = [&](TapBuf<NCH>& tv, int q) {
-        const float* rq = rp + q * kWalkRecW;
-        const float gc = rec[q * kWalkRecW + 3 * kRecWords], zc = rec[q * kWalkRecW + 3 * kRecWords + 1];
-        wk[pl].advance(rq);
+        const float* rq = rec + q * kWalkRecW;
+        const float gc = rq[18], zc = rq[19];
+        wk.advance(rq);
         float g[NCH];
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) g[k] = wk[pl].live[k] ? gc : 0.f;
+        for (int k = 0; k < NCH; ++k) g[k] = wk.live[k] ? gc : 0.f;
         float aix = 0.f, aiy = 0.f, ail = 0.f;
-        wk[pl].add(tv, rq, g, aix, aiy, ail);
-        // per-lane partials (its channels); reduced over the group at the end
-        aix *= sx;
-        aiy *= sy;
-        ail *= sl;
-        go[kM0(pl)] += aix;
-        gd[kM0(pl)] += aix * zc;
-        go[kM1(pl)] += aiy;
-        gd[kM1(pl)] += aiy * zc;
-        go[kV(pl)] += ail;
-        gd[kV(pl)] += ail * zc;
+        wk.add(tv, rq, g, aix, aiy, ail);
+        gox += aix;
+        gdx += aix * zc;
+        goy += aiy;
+        gdy += aiy * zc;
+        gol += ail;
+        gdl += ail * zc;
       };
-      wk[pl].load(bufA, D.dP[pl], D.dL[pl], rp);
+      // taps two steps ahead of the step that consumes them (three buffers in rotation)
+      wk.load(bufA, P, L, rec);
+      wk.load(bufB, P, L, rec + kWalkRecW);
 #pragma unroll 1
-      for (int q = 0; q < kWalkSub; q += 2) {
-        wk[pl].load(bufB, D.dP[pl], D.dL[pl], rp + (q + 1) * kWalkRecW);
+      for (int q = 0; q < kWalkSub; q += 3) {
+        if (q + 2 < kWalkSub) wk.load(bufC, P, L, rec + (q + 2) * kWalkRecW);
         step(bufA, q);
-        if (q + 2 < kWalkSub) wk[pl].load(bufA, D.dP[pl], D.dL[pl], rp + (q + 2) * kWalkRecW);
-        step(bufB, q + 1);
+        if (q + 3 < kWalkSub) wk.load(bufA, P, L, rec + (q + 3) * kWalkRecW);
+        if (q + 1 < kWalkSub) step(bufB, q + 1);
+        if (q + 4 < kWalkSub) wk.load(bufB, P, L, rec + (q + 4) * kWalkRecW);
+        if (q + 2 < kWalkSub) step(bufC, q + 2);
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+    wk.finish();
   }
+  // reduce over the group's channels, then over the wave's four groups (same ray, same plane): six atomics per wave
+  float v6[6] = {gox * sx, goy * sy, gol * sl, gdx * sx, gdy * sy, gdl * sl};
 #pragma unroll
-  for (int pl = 0; pl < 3; ++pl) wk[pl].finish();
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    go[a] = row16_sum(go[a]);
-    gd[a] = row16_sum(gd[a]);
+  for (int c = 0; c < 6; ++c) {
+    float v = row16_sum(v6[c]);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    v6[c] = v;
   }
-  if (DET) {  // JT_DETERMINISTIC: the runs of a ray meet in 64-bit fixed point, added to g_rays by k_rays_fixed_add
-    if (cl < 6)
-      fixed_add(rays_fixed + (size_t)ray * 6 + cl, cl == 0 ? go[0] : cl == 1 ? go[1] : cl == 2 ? go[2]
-                                                                  : cl == 3 ? gd[0] : cl == 4 ? gd[1] : gd[2]);
-    return;
+  const int lane = threadIdx.x & 63;
+  if (lane < 6) {
+    const int c = lane;
+    const float v = c == 0 ? v6[0] : c == 1 ? v6[1] : c == 2 ? v6[2] : c == 3 ? v6[3] : c == 4 ? v6[4] : v6[5];
+    const int ax = (c % 3) == 0 ? a0 : ((c % 3) == 1 ? a1 : a2);
+    if (DET) fixed_add(rays_fixed + (size_t)ray * 6 + (c < 3 ? 0 : 3) + ax, v);
+    else atomicAdd((c < 3 ? g_rays_o : g_rays_d) + ray * 3 + ax, v);
   }
-  if (cl < 3) atomicAdd(g_rays_o + ray * 3 + cl, cl == 0 ? go[0] : cl == 1 ? go[1] : go[2]);
-  else if (cl < 6) atomicAdd(g_rays_d + ray * 3 + (cl - 3), cl == 3 ? gd[0] : cl == 4 ? gd[1] : gd[2]);
 }
 
 __global__ void k_zero64(long long* p, long n) {
@@ -582,17 +601,21 @@ static int check_density_shape(const Dev& D) {
 
 extern "C" int jt_version(void) { return JT_VERSION; }
 
-static int g_deterministic = -1;  // -1: not yet read from the environment
+static std::atomic<int> g_deterministic{-1};  // -1: not yet read from the environment
 int jt::jt_deterministic() {
-  if (g_deterministic < 0) {
+  int v = g_deterministic.load(std::memory_order_relaxed);
+  if (v < 0) {
     const char* e = getenv("JT_DETERMINISTIC");
-    g_deterministic = (e && atoi(e) != 0) ? 1 : 0;
+    const int from_env = (e && atoi(e) != 0) ? 1 : 0;
+    int expected = -1;  // whoever gets here first decides; a concurrent jt_set_deterministic wins over the environment
+    g_deterministic.compare_exchange_strong(expected, from_env, std::memory_order_relaxed);
+    v = g_deterministic.load(std::memory_order_relaxed);
   }
-  return g_deterministic;
+  return v;
 }
 extern "C" int jt_set_deterministic(int on) {
   const int prev = jt_deterministic();
-  if (on == 0 || on == 1) g_deterministic = on;
+  if (on == 0 || on == 1) g_deterministic.store(on, std::memory_order_relaxed);
   return prev;
 }
 
@@ -742,8 +765,8 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
     hipLaunchKernelGGL(k_zero64, dim3((n_rays * 6 + 255) / 256), dim3(256), 0, st, rays_fixed, (long)n_rays * 6);
     JT_LAUNCH_CHECK();
   }
-  const int runs = (D.S + kWalkRun - 1) / kWalkRun;
-  const long items = (long)n_rays * runs;
+  const int runs = ((D.S + kWalkRun - 1) / kWalkRun + 3) & ~3;  // a wave's four groups: four runs of ONE (ray, plane)
+  const long items = (long)n_rays * runs * 3;
   const int blocks = (int)((items + 15) / 16);
 #define JT_WALK(CD_)                                                                                              \
   do {                                                                                                           \

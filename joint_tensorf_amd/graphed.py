@@ -343,6 +343,7 @@ class GraphedTrainStep:
         if coin is not None:
             tf.coin_override = coin
         ops.LOSS_WEIGHTS_STATIC = self._loss_weights(opt)
+        ops.status_word(dev)  # the non-finite guard's word must exist BEFORE the capture (graph-pool memory is recycled)
         # [lattice offset x, y | address of the supervising images (2 words) | address of the edge masks (2 words)]
         e.off = torch.zeros(6, device=dev, dtype=torch.int32)
         ops.poke_words(e.off, [0, 0] + self._supervision_words(var, sig[8]))

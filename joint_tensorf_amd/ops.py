@@ -36,7 +36,7 @@ def poke_words(dst, words, offset=0):
 
 
 # ---- non-finite guard (model/tensorf.py:43-44,147-151 without the per-iteration host reads) ----------------------
-FINITE_POSE, FINITE_RENDER, FINITE_LOSS = 1, 2, 4
+FINITE_POSE, FINITE_RENDER, FINITE_LOSS, FINITE_GRAD = 1, 2, 4, 8
 _STATUS = {}
 
 
@@ -557,8 +557,12 @@ class RenderRays(torch.autograd.Function):
             reducer.reduce(4, 4)  # basis + MLP
             reducer.wait()  # stream-level: whoever consumes the gradients next runs behind the collectives
         if det and want_fac:
-            # fixed point -> float (value = word / 2^56), in place of the zero-filled float buffers
-            gflat.copy_((gflat64.double() * (1.0 / 72057594037927936.0)).float())
+            # fixed point -> float (value = word / 2^48), in place of the zero-filled float buffers; a sum at or beyond
+            # 2^60 (value 4 096: out of the format's safe range, or a poisoned non-finite addend, jt_common.h) leaves the
+            # FINITE_GRAD bit in the device's status word -- read with the other non-finite checks (read_status)
+            gflat.copy_((gflat64.double() * (1.0 / 281474976710656.0)).float())
+            bad = (gflat64.abs() >= (1 << 60)).any()
+            status_word(dev).bitwise_or_(bad.to(torch.int32) * FINITE_GRAD)
             gfac = gfac_float
         if ctx.reg is not None and g_reg is not None and want_fac:
             # the regularisers' gradient joins the render gradient in place (after the collectives: it is the same
@@ -983,7 +987,10 @@ def blur_images(images, taps):
 
 
 def gaussian_taps(sigma_vox, kernel_size, device):
-    """kernels.get_gaussian_kernel (kernels.py:16-22): un-normalised taps clamped at 1, K even -> K+1 taps."""
+    """kernels.get_gaussian_kernel (kernels.py:16-22): un-normalised taps clamped at 1, K even -> K+1 taps.
+    ALWAYS evaluated on the host and then uploaded (`device` only says where the result goes): the eager path and the
+    taps a hipGraph replay pokes into static memory (graphed.GraphedTrainStep._poke_taps, device="cpu") are the same
+    floats bit for bit."""
     s = max(float(sigma_vox), 0.0001)
     ns = torch.arange(-(kernel_size // 2), kernel_size // 2 + 1, dtype=torch.float32)
     k = 1 / (s * math.sqrt(2 * math.pi)) * torch.exp(-0.5 * (ns / s) * (ns / s))

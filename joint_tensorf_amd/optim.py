@@ -22,6 +22,22 @@ class VMAdam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
+    def load_state_dict(self, state_dict):
+        """torch.optim.Optimizer.load_state_dict keeps the saved tensors' strides.  A checkpoint written by the reference
+        (torch.optim.Adam over contiguous NCHW factors, util.py:160-184) -- or by this build's save_checkpoint, which
+        stores plain contiguous tensors -- is then laid out differently from the channel-last parameters the step kernel
+        walks: every moment tensor is re-laid into its parameter's memory order by value."""
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if not st:
+                    continue
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if k in st and torch.is_tensor(st[k]) and not _same_layout(st[k], p):
+                        st[k] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[k])
+        self.__dict__.pop("_layout_memo", None)
+
     # The step is split in two so that a hipGraph can hold the launch (graphed.GraphedTrainStep): `prepare_step`
     # is the host half -- Adam's step counters, lr and bias corrections in Python doubles exactly as
     # torch.optim.Adam computes them -- and ends with ONE jt_poke that puts the coefficients of all tensors into

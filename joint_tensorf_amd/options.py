@@ -75,3 +75,33 @@ def make_options(name, device="cuda", **overrides):
     opt.device = device
     opt.H, opt.W = (int(v) for v in opt.data.image_size)
     return opt
+
+
+def compress_schedule(opt, factor):
+    """Shorten a run by `factor` without changing its SHAPE: every iteration-denominated key of the yaml (max_iter, grid
+    upsamplings, alpha-mask updates, ray-count / gradient-accumulation switches, pose reset and warm-up, edge-loss and
+    TV_depth horizons) is divided by it; the schedules that are functions of progress = it / max_iter (factor blur, 2-D
+    blur, near plane, learning-rate decay) follow by themselves.  Used by the convergence acceptance test and
+    tools/converge.py: the same stages in the same order, fewer iterations in each."""
+    f = float(factor)
+    if f == 1.0:
+        return opt
+
+    def div(v):
+        return max(1, int(round(v / f)))
+    opt.max_iter = div(opt.max_iter)
+    ts = opt.train_schedule
+    for k in ("upsample_iters", "update_alphamask_iters", "reset_pose_on_iters"):
+        if k in ts and ts[k] is not None:
+            ts[k] = [div(v) for v in ts[k]]
+    for k in ("change_n_rays_after_n_iters", "change_n_AccumPoseGrad_after_n_iters", "change_n_AccumGrad_after_n_iters",
+              "reset_pose_on_iter", "all_view_sample_after_n_iters", "single_view_sample_after_n_iters"):
+        if k in ts and ts[k] is not None:
+            ts[k] = div(ts[k])
+    if "edge_mask_before_iter" in opt and opt.edge_mask_before_iter is not None:
+        opt.edge_mask_before_iter = div(opt.edge_mask_before_iter)
+    if opt.optim.get("warmup_pose", None):
+        opt.optim.warmup_pose = div(opt.optim.warmup_pose)
+    if "TV_depth_until_iters" in opt.loss_weight and opt.loss_weight.TV_depth_until_iters is not None:
+        opt.loss_weight.TV_depth_until_iters = div(opt.loss_weight.TV_depth_until_iters)
+    return opt

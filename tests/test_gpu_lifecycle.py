@@ -157,3 +157,64 @@ def test_a_reference_checkpoint_renders_like_the_reference(tmp_path):
         print("reference checkpoint render: max |%s - reference| = %.2e" % (k, err))
         assert err <= 2e-6, (k, err)
     np.testing.assert_allclose(ret["depth"].cpu().numpy(), d["out.depth"], atol=2e-5)
+
+
+def test_resume_from_a_reference_checkpoint_steps_the_optimizer(tmp_path):
+    """opt.resume on the file the REFERENCE wrote: its Adam moments are contiguous NCHW tensors, this
+    build's factors are channel-last -- VMAdam.load_state_dict re-lays them by value, and the next optimizer step runs
+    and equals torch.optim.Adam's step from the same state."""
+    import os
+    import shutil
+    path, meta, d = reference_checkpoint_file(tmp_path)
+    shutil.copy(path, os.path.join(str(tmp_path), "model.ckpt"))
+    from joint_tensorf_amd.model import bat_hip
+    from joint_tensorf_amd.options import Opt
+    views = Opt(idx=torch.arange(3), pose=torch.from_numpy(np.array(d["in.pose_gt"])),
+                intr=torch.from_numpy(np.array(d["in.intr"])), intr_inv=torch.from_numpy(np.array(d["in.intr_inv"])),
+                image=torch.rand(3, 3, 32, 32))
+    opt = _small_opt(device=DEV, output_path=str(tmp_path), resume=True, camera=dict(noise=0.15),
+                     data=dict(image_size=[32, 32], num_views=3, train_views=views, test_views=views))
+    m = bat_hip.Model(opt)
+    m.load_dataset(opt)
+    m.build_networks(opt)
+    m.setup_optimizer(opt)
+    m.restore_checkpoint(opt)
+    assert m.iter_start == meta["iter"]
+    n_state = 0
+    ref_params, ref_state = [], {}
+    for gi, group in enumerate(m.optim.param_groups):
+        for p in group["params"]:
+            st = m.optim.state.get(p)
+            if not st:
+                continue
+            n_state += 1
+            for k in ("exp_avg", "exp_avg_sq"):
+                assert st[k].shape == p.shape and st[k].stride() == p.stride(), (k, st[k].stride(), p.stride())
+    assert n_state > 0, "the reference checkpoint carries optimizer state"
+    # the saved moments arrived by value
+    saved = {int(k.split(".")[2]): None for k in d.files if k.startswith("optim.state.")}
+    flat = [p for group in m.optim.param_groups for p in group["params"]]
+    for pid in saved:
+        np.testing.assert_array_equal(m.optim.state[flat[pid]]["exp_avg"].cpu().numpy(), d["optim.state.%d.exp_avg" % pid])
+    # one step from there against torch.optim.Adam on copies
+    torch.manual_seed(3)
+    clones = [p.detach().clone().contiguous().requires_grad_(True) for p in flat]
+    groups = []
+    k = 0
+    for group in m.optim.param_groups:
+        n = len(group["params"])
+        groups.append(dict(params=clones[k:k + n], lr=group["lr"]))
+        k += n
+    ref = torch.optim.Adam(groups, betas=(0.9, 0.99))
+    sd = m.optim.state_dict()
+    ref.load_state_dict({"state": {i: {kk: (vv.detach().clone().contiguous() if torch.is_tensor(vv) else torch.tensor(float(vv)))
+                                        for kk, vv in st.items()} for i, st in sd["state"].items()},
+                         "param_groups": ref.state_dict()["param_groups"]})
+    for p, c in zip(flat, clones):
+        g = torch.randn(p.shape, device=DEV) * 1e-3
+        p.grad = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
+        c.grad = g.clone()
+    m.optim.step()
+    ref.step()
+    for i, (p, c) in enumerate(zip(flat, clones)):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), c.detach().cpu().numpy(), rtol=0, atol=2e-7, err_msg=str(i))
