@@ -170,7 +170,6 @@ int jt_blur_batch_backward(const JtBlurItem* items, int n_items, void* stream);
  *   weight > thres, in order), opacity [R], depth [R] (batBase.py:147-151).
  * jt_shade_list: entry -> (ray, sample) map + the positions the appearance path needs.
  *   out: entry_ray [n], entry_smp [n] (int32), viewdirs [n][3] (normalised when ndc).
- * jt_app_gather_forward: prod [n][3*Ca] = plane_i^c(p) * line_i^c(p)  (bateRF.py:124-128).
  * jt_shade_forward (fused, MFMA): prod -> basis -> MLP -> sigmoid, rgb_s [n][3].
  * jt_composite_forward: rgb [R][3] = sum_k w_k c_k (+ white bg) clamped, clamp_mask [R] bit ch
  *   set when the un-clamped value lies in [0,1]. */
@@ -185,10 +184,6 @@ int jt_march_forward(const JtScene* scene, const JtFactors* factors, const float
 int jt_shade_list(const JtScene* scene, const float* rays_d, int n_rays, const int32_t* shade_offset,
                   const uint16_t* shade_idx, int32_t* entry_ray, int32_t* entry_smp, float* viewdirs,
                   int n_entries_max, void* stream);
-int jt_app_gather_forward(const JtScene* scene, const JtFactors* factors, const float* rays_o,
-                          const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
-                          const int32_t* shade_offset, int n_rays, const int32_t* entry_ray,
-                          const int32_t* entry_smp, float* prod, int n_entries_max, void* stream);
 int jt_composite_forward(const JtScene* scene, int n_rays, const int32_t* shade_offset,
                          const uint16_t* shade_idx, const float* weight, const float* rgb_s,
                          const float* opacity, float* rgb, int32_t* clamp_mask, void* stream);
@@ -197,7 +192,6 @@ int jt_composite_forward(const JtScene* scene, int n_rays, const int32_t* shade_
  * Staged renderer (backward) -- replaces autograd of all of the above (loss.all.backward(),
  * model/base.py:162; the scatter-adds of grid_sampler_2d_backward).
  * jt_composite_backward: g_rgb [R][3] -> g_rgb_s [n][3] (= weight * g_rgb masked by clamp).
- * jt_app_gather_backward: g_prod [n][3*Ca] -> += g_factors.app_*, g_xyz_app [n][3] (overwritten).
  * jt_march_backward: density + transmittance backward:
  *   += g_factors.density_* (g_factors may be NULL: gradients w.r.t. the rays only); g_rays_o, g_rays_d
  *   [R][3] overwritten (include the app path's
@@ -207,11 +201,6 @@ int jt_composite_backward(const JtScene* scene, int n_rays, const int32_t* shade
                           const int32_t* entry_ray, const int32_t* entry_smp, const float* weight,
                           const int32_t* clamp_mask, const float* g_rgb, float* g_rgb_s, int n_entries_max,
                           void* stream);
-int jt_app_gather_backward(const JtScene* scene, const JtFactors* factors, const float* rays_o,
-                           const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
-                           const int32_t* shade_offset, int n_rays, const int32_t* entry_ray,
-                           const int32_t* entry_smp, const float* g_prod, const JtFactors* g_factors,
-                           float* g_xyz_app, int n_entries_max, void* stream);
 int jt_march_backward(const JtScene* scene, const JtFactors* factors, const float* rays_o, const float* rays_d,
                       const float* jitter, const float* zvals, int n_rays, const float* sigma_feat,
                       const float* weight, const float* tmin, const int32_t* shade_offset,

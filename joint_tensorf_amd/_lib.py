@@ -84,10 +84,8 @@ SIGNATURES = {
     "jt_blur_backward": (I, [P, P, P, I, I, I, P, I, P]),
     "jt_march_forward": (I, [SP, FP, P, P, P, P, I, P, P, P, P, P, P, P, P, P]),
     "jt_shade_list": (I, [SP, P, I, P, P, P, P, P, I, P]),
-    "jt_app_gather_forward": (I, [SP, FP, P, P, P, P, P, P, I, P, P, P, I, P]),
     "jt_composite_forward": (I, [SP, I, P, P, P, P, P, P, P, P]),
     "jt_composite_backward": (I, [SP, I, P, P, P, P, P, P, P, I, P]),
-    "jt_app_gather_backward": (I, [SP, FP, P, P, P, P, P, P, I, P, P, P, FP, P, I, P]),
     "jt_march_backward": (I, [SP, FP, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, FP, P, P, P, ctypes.c_size_t, P]),
     "jt_march_backward_workspace_bytes": (ctypes.c_size_t, [SP, I]),
     "jt_shade_workspace_bytes": (ctypes.c_size_t, [SP, I]),

@@ -12,6 +12,11 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "lib", "libjt_render.so")
 SRCS = sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")))
 HDRS = sorted(glob.glob(os.path.join(HERE, "csrc", "*.h"))) + [os.path.join(ROOT, "include", "jt_render.h")]
+# test infrastructure, NOT part of the product library: the staged appearance path's two entry points
+# (tests/csrc/jt_app.hip -> tests/lib/libjt_test_staged.so), loaded by tests/staged_path.py only
+TEST_LIB = os.path.join(ROOT, "tests", "lib", "libjt_test_staged.so")
+TEST_SRCS = sorted(glob.glob(os.path.join(ROOT, "tests", "csrc", "*.hip")))
+TEST_HDRS = sorted(glob.glob(os.path.join(ROOT, "tests", "csrc", "*.h")))
 
 
 def hipcc():
@@ -22,10 +27,13 @@ def hipcc():
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or (TEST_SRCS and not os.path.exists(TEST_LIB)):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in SRCS + HDRS + [os.path.abspath(__file__)])
+    if any(os.path.getmtime(p) > t for p in SRCS + HDRS + [os.path.abspath(__file__)]):
+        return True
+    t = os.path.getmtime(TEST_LIB) if TEST_SRCS else 0
+    return any(os.path.getmtime(p) > t for p in TEST_SRCS + TEST_HDRS + HDRS)
 
 
 def build(force=False, verbose=True):
@@ -50,6 +58,14 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    if TEST_SRCS:
+        os.makedirs(os.path.dirname(TEST_LIB), exist_ok=True)
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-shared",
+               "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-I", os.path.join(ROOT, "tests", "csrc"),
+               "-Wall", "-Wno-unused-function", "-o", TEST_LIB] + TEST_SRCS
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return LIB
 
 

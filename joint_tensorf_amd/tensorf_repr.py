@@ -291,42 +291,53 @@ class BAT_VMSplit(torch.nn.Module):
 
     @torch.no_grad()
     def updateAlphaMask(self, gridSize=(200, 200, 200)):
-        """tensorBase.py:636-661: dense alpha -> 5^3 max-pool -> threshold -> mask volume; returns the box of the
-        kept voxels."""
-        gridSize = [int(v) for v in gridSize]
-        alpha, dense_xyz = self.getDenseAlpha(gridSize)
-        dense_xyz = dense_xyz.transpose(0, 2).contiguous()
-        alpha = alpha.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
-        ks = 5
-        alpha = F.max_pool3d(alpha, kernel_size=ks, padding=ks // 2, stride=1).view(gridSize[::-1])
-        alpha = (alpha >= self.alphaMask_thres).to(torch.float32)
-        self.alphaMask = AlphaGridMask(alpha.device, self.aabb, alpha)
-        valid_xyz = dense_xyz[alpha > 0.5]
-        return torch.stack((valid_xyz.amin(0), valid_xyz.amax(0)))
+        """Occupancy volume of the scene + the world box of what it keeps (what tensorBase.py:636-661 computes): the
+        one-step opacity on a lattice of `gridSize` points, dilated by two lattice cells in every direction (the 5^3
+        maximum filter, separable: a running maximum along z, then y, then x), thresholded at alphaMask_thres.  The
+        volume is stored [z][y][x] as the render kernels index it.  The box is read off the kept INDEX range per axis
+        (lattice coordinates are monotonic along an axis), with the lattice's own fp32 coordinate expression."""
+        gx, gy, gz = (int(v) for v in gridSize)
+        alpha, _ = self.getDenseAlpha((gx, gy, gz))                      # [gx, gy, gz]
+        vol = alpha.clamp(0, 1).permute(2, 1, 0).contiguous()            # [gz, gy, gx]
+        for axis in range(3):                                            # separable 5-wide maximum, -inf padded
+            moved = vol.movedim(axis, -1)
+            flat = moved.reshape(1, -1, moved.shape[-1])
+            vol = F.max_pool1d(flat, kernel_size=5, stride=1, padding=2).reshape(moved.shape).movedim(-1, axis)
+        keep = vol >= self.alphaMask_thres
+        self.alphaMask = AlphaGridMask(keep.device, self.aabb, keep.to(torch.float32))
+        lo, hi = self.aabb[0].float(), self.aabb[1].float()
+        box = torch.empty(2, 3)
+        for a, (n, reduce_dims) in enumerate(((gx, (0, 1)), (gy, (0, 2)), (gz, (1, 2)))):
+            idx = torch.nonzero(keep.any(dim=reduce_dims[1]).any(dim=reduce_dims[0])).flatten().cpu()
+            s = torch.linspace(0, 1, n)[torch.stack([idx.min(), idx.max()])]
+            box[:, a] = lo[a] * (1 - s) + hi[a] * s
+        return box.to(keep.device)
 
     @torch.no_grad()
     def shrink(self, new_aabb):
-        """tensoRF.py:297-334: crop every factor to the texels covering new_aabb (channel-last storage kept)."""
-        new_aabb = new_aabb.detach().to(self.aabb.device, dtype=torch.float32)  # box arithmetic on the host, fp32
-        xyz_min, xyz_max = new_aabb
-        t_l, b_r = (xyz_min - self.aabb[0]) / self.units, (xyz_max - self.aabb[0]) / self.units
-        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
-        b_r = torch.stack([b_r, self.gridSize.to(b_r.device)]).amin(0)
+        """Crop the scene to `new_aabb` (tensoRF.py:297-334's result): the texel range [first, last] that covers the box
+        on every axis, every factor narrowed to it (channel-last storage kept), and -- when the occupancy volume was
+        taken on another lattice than the factor grid -- the box snapped to the texels that were kept."""
+        box = new_aabb.detach().to(self.aabb.device, dtype=torch.float32)    # box arithmetic on the host, fp32
+        grid = self.gridSize.to(box.device)
+        first = torch.round((box[0] - self.aabb[0]) / self.units).long()
+        stop = torch.minimum(torch.round((box[1] - self.aabb[0]) / self.units).long() + 1, grid)  # one past the last
+        count = stop - first
+
+        def crop(p, dims):  # dims: {tensor dimension: scene axis}
+            for d, axis in dims.items():
+                p = p.narrow(d, int(first[axis]), int(count[axis]))
+            return _channel_last_param(p.contiguous())
         for i in range(3):
-            v = VEC_MODE[i]
             m0, m1 = MAT_MODE[i]
             for lines, planes in ((self.density_line, self.density_plane), (self.app_line, self.app_plane)):
-                lines[i] = _channel_last_param(lines[i].data[..., t_l[v]:b_r[v], :].contiguous())
-                planes[i] = _channel_last_param(planes[i].data[..., t_l[m1]:b_r[m1], t_l[m0]:b_r[m0]].contiguous())
-        if not torch.all(self.alphaMask.gridSize.cpu() == self.gridSize.cpu()):
-            t_l_r, b_r_r = t_l / (self.gridSize - 1), (b_r - 1) / (self.gridSize - 1)
-            correct_aabb = torch.zeros_like(new_aabb)
-            correct_aabb[0] = (1 - t_l_r) * self.aabb[0] + t_l_r * self.aabb[1]
-            correct_aabb[1] = (1 - b_r_r) * self.aabb[0] + b_r_r * self.aabb[1]
-            new_aabb = correct_aabb
-        newSize = b_r - t_l
-        self.aabb = new_aabb
-        self.update_stepSize((newSize[0], newSize[1], newSize[2]))
+                lines[i] = crop(lines[i].data, {2: VEC_MODE[i]})
+                planes[i] = crop(planes[i].data, {2: m1, 3: m0})
+        if not torch.equal(self.alphaMask.gridSize.cpu(), self.gridSize.cpu()):
+            f0, f1 = first / (grid - 1), (stop - 1) / (grid - 1)
+            box = torch.stack([(1 - f0) * self.aabb[0] + f0 * self.aabb[1], (1 - f1) * self.aabb[0] + f1 * self.aabb[1]])
+        self.aabb = box
+        self.update_stepSize([int(v) for v in count])
 
     # ---- checkpoint extras (tensorBase.py:508-552) ------------------------------------------------
     def get_reset_kwargs(self):

@@ -24,7 +24,7 @@ def pytest_configure(config):
     if torch.get_num_threads() > 8:
         torch.set_num_threads(8)
     try:
-        if not os.path.exists(mod.LIB):
+        if not os.path.exists(mod.LIB) or not os.path.exists(mod.TEST_LIB):
             mod.build(verbose=False)
     except Exception as e:  # no hipcc on this machine: tests that need the library will say so themselves
         print("joint_tensorf_amd: could not build libjt_render.so here (%r)" % (e,))

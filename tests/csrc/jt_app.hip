@@ -4,6 +4,7 @@
 // keeps the grid coordinates attached).  Used by the staged pipeline and as the cross-check for the
 // fused MFMA shade kernels in jt_shade.hip.
 #include "jt_common.h"
+#include "jt_test_staged.h"
 
 namespace jt {
 

@@ -3,10 +3,24 @@ path -- jt_app_gather_forward materialises the [n, 3*Ca] plane x line products, 
 run in stock torch ops (torch autograd for their backward), jt_app_gather_backward scatters the product gradients.
 tests/test_gpu_parity.py runs every fixture through it next to the fused MFMA path (ops.RenderRays): two independent
 implementations of the appearance chain against the same golden vectors.  One host sync per forward (the shaded count)."""
+import ctypes
+import os
+
 import torch
 
 from joint_tensorf_amd import _lib, ops
-from joint_tensorf_amd._lib import check, lib, ptr
+from joint_tensorf_amd._lib import FP, I, P, SP, check, lib, ptr
+
+# the staged path's own two kernels live in a TEST-ONLY library (tests/csrc/jt_app.hip, built next to the product library
+# by joint_tensorf_amd/build.py); everything else -- march, composite, density backward -- is the product library's
+_TEST_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libjt_test_staged.so")
+if not os.path.exists(_TEST_LIB):
+    raise ImportError("%s is missing: run `python joint_tensorf_amd/build.py`" % _TEST_LIB)
+tlib = ctypes.CDLL(_TEST_LIB)
+tlib.jt_app_gather_forward.restype = I
+tlib.jt_app_gather_forward.argtypes = [SP, FP, P, P, P, P, P, P, I, P, P, P, I, P]
+tlib.jt_app_gather_backward.restype = I
+tlib.jt_app_gather_backward.argtypes = [SP, FP, P, P, P, P, P, P, I, P, P, P, FP, P, I, P]
 from joint_tensorf_amd.ops import _factors_struct, _stream, factor_logical, factor_storage
 
 
@@ -71,7 +85,7 @@ class StagedRenderRays(torch.autograd.Function):
               "jt_shade_list")
         rgb_s = torch.empty(cap_alloc, 3, **f32)
         prod = torch.empty(cap_alloc, 3 * cfg.n_comp_app, **f32)
-        check(lib.jt_app_gather_forward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals), ptr(tmin),
+        check(tlib.jt_app_gather_forward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals), ptr(tmin),
                                         ptr(offset), R, ptr(eray), ptr(esmp), ptr(prod), cap, st), "jt_app_gather_forward")
         if n > 0:
             with torch.no_grad():
@@ -126,7 +140,7 @@ class StagedRenderRays(torch.autograd.Function):
             g_prod, g_mlp = grads[0].contiguous(), list(grads[1:])
         else:
             g_prod = torch.zeros(1, 3 * cfg.n_comp_app, **f32)
-        check(lib.jt_app_gather_backward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals), ptr(tmin),
+        check(tlib.jt_app_gather_backward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals), ptr(tmin),
                                          ptr(offset), R, ptr(eray), ptr(esmp), ptr(g_prod), gfac, ptr(g_xyz), cap, st),
               "jt_app_gather_backward")
         g_o, g_d = torch.empty(R, 3, **f32), torch.empty(R, 3, **f32)

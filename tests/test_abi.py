@@ -31,6 +31,17 @@ def test_header_vs_ctypes_vs_library():
     assert so.jt_version() >= 1001
 
 
+def test_product_library_has_no_test_only_entry_points():
+    """the staged cross-check path's kernels (tests/csrc/jt_app.hip) are built into tests/lib/libjt_test_staged.so, not
+    into the product library or its header (hygiene)"""
+    from joint_tensorf_amd import _lib
+    so = ctypes.CDLL(_lib.LIB_PATH)
+    for name in ("jt_app_gather_forward", "jt_app_gather_backward"):
+        assert not hasattr(so, name) and name not in _lib.SIGNATURES and name not in _header_functions()
+    t = ctypes.CDLL(os.path.join(ROOT, "tests", "lib", "libjt_test_staged.so"))
+    assert hasattr(t, "jt_app_gather_forward") and hasattr(t, "jt_app_gather_backward")
+
+
 def test_struct_layout_matches_header(tmp_path):
     """The ctypes mirrors must have the size and field offsets the C compiler gives the structs of the header."""
     import os
