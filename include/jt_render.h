@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define JT_VERSION 1001
+#define JT_VERSION 1002
 
 #define JT_OK 0
 #define JT_ERR_ARG 1         /* null pointer / bad size */
@@ -196,7 +196,9 @@ int jt_composite_forward(const JtScene* scene, int n_rays, const int32_t* shade_
  *   += g_factors.density_* (g_factors may be NULL: gradients w.r.t. the rays only); g_rays_o, g_rays_d
  *   [R][3] overwritten (include the app path's
  *   coordinate gradients read from g_xyz_app).  g_opacity [R] may be NULL.  workspace: caller-provided,
- *   jt_march_backward_workspace_bytes(scene, n_rays) bytes (per-sample density gradients + run lists). */
+ *   jt_march_backward_workspace_bytes(scene, n_rays) bytes (per-sample density gradients + run lists + the rays'
+ *   gradient sums in 2^48 fixed point: the runs of a ray meet in integer atomics, so g_rays_o / g_rays_d do not depend
+ *   on the order in which they arrive -- the density part of a pose gradient is bit-reproducible in every mode). */
 int jt_composite_backward(const JtScene* scene, int n_rays, const int32_t* shade_offset,
                           const int32_t* entry_ray, const int32_t* entry_smp, const float* weight,
                           const int32_t* clamp_mask, const float* g_rgb, float* g_rgb_s, int n_entries_max,
@@ -262,6 +264,29 @@ int jt_shade_backward(const JtScene* scene, const JtFactors* factors, const JtMl
                       const JtFactors* g_factors, const JtMlp* g_mlp, float* g_xyz_app, int n_entries_max,
                       void* workspace, size_t workspace_bytes, int flags, void* stream, void* aux_stream,
                       void* ev_fork, void* ev_join);
+
+/* ---------------------------------------------------------------------------------------------
+ * Single-launch render + photometric loss + backward to the rays (csrc/jt_fused.hip) -- test-time pose optimisation,
+ * model/bat.py:265-292: per iteration Graph.forward(mode "test-optim") -> compute_loss -> loss.all.backward() with only a
+ * 6-vector trained (scene frozen).  Replaces, for that mode, tensorf.Graph.render_rays + BatBase.forward
+ * (model/tensorf.py:169-267, batBase.py:44-165), the render term of compute_loss (model/tensorf.py:96-124 with
+ * base.py:259-261's mean over the 3 R colour values) and autograd's walk back to (center, ray_dir): one wave owns one ray
+ * from its first sample to its gradient, nothing is recorded between forward and backward.
+ *   rays_o / rays_d [R][3]; zvals [S] for NDC scenes (no jitter at test time); image [views][3][image_pixels] and
+ *   ray_idx [rays_per_view] (int64): ray r looks at pixel ray_idx[r % rays_per_view] of view r / rays_per_view.
+ *   loss_scale = 1 / (3 R) times whatever weight the caller wants folded in.  Values are assumed finite (the mean is
+ *   over all 3 R values; the reference's nanmean would drop NaNs -- the caller's non-finite guard reports those).
+ *   out: rgb [R][3], depth [R], opacity [R], sqerr [R] (per-ray sum of squared colour differences), loss [1] =
+ *   loss_scale * sum(sqerr), g_rays_o / g_rays_d [R][3] = d loss / d rays (plain stores: bit-reproducible).
+ *   workspace: jt_pose_fused_workspace_bytes(scene) bytes, ZERO before the first launch that uses it (its head holds the
+ *   loss accumulator and an arrival counter, which every launch leaves zeroed again); contents otherwise scratch.
+ * No blur (the caller blurs factors itself if a schedule asks for it and hands the blurred ones), alpha mask honoured. */
+size_t jt_pose_fused_workspace_bytes(const JtScene* scene);
+int jt_pose_fused(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp, const float* rays_o,
+                  const float* rays_d, const float* zvals, int n_rays, const float* image, const int64_t* ray_idx,
+                  int rays_per_view, int image_pixels, float loss_scale, float* rgb, float* depth, float* opacity,
+                  float* sqerr, float* loss, float* g_rays_o, float* g_rays_d, void* workspace, size_t workspace_bytes,
+                  void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Regularisers over one channel-last factor [H][W][C] (a line is W = 1) in a single pass.

@@ -113,6 +113,8 @@ SIGNATURES = {
     "jt_factor_reg_forward": (I, [P, I, I, I, P, P]),
     "jt_factor_reg_backward": (I, [P, I, I, I, P, P, I, P]),
     "jt_shade_forward": (I, [SP, FP, MP, P, P, P, P, P, P, I, P, P, P, P, I, P, ctypes.c_size_t, I, P]),
+    "jt_pose_fused_workspace_bytes": (ctypes.c_size_t, [SP]),
+    "jt_pose_fused": (I, [SP, FP, MP, P, P, P, I, P, P, I, I, F, P, P, P, P, P, P, P, P, ctypes.c_size_t, P]),
     "jt_shade_backward": (I, [SP, FP, MP, P, P, P, P, P, P, I, P, P, P, P, P, FP, MP, P, I, P, ctypes.c_size_t, I, P, P, P, P]),
 }
 

@@ -263,7 +263,8 @@ __global__ __launch_bounds__(256) void k_march_bwd_scan(Dev D, const float* __re
                                                         const float* __restrict__ g_xyz_app,
                                                         float* __restrict__ gfeat, uint16_t* __restrict__ vlist,
                                                         int* __restrict__ nvalid_out, float* __restrict__ g_rays_o,
-                                                        float* __restrict__ g_rays_d, int Spad) {
+                                                        float* __restrict__ g_rays_d, long long* __restrict__ rays_fixed,
+                                                        int Spad) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -402,6 +403,7 @@ __global__ __launch_bounds__(256) void k_march_bwd_scan(Dev D, const float* __re
     go[a] = wave_sum(go[a]);
     gd[a] = wave_sum(gd[a]);
   }
+  if (lane < 6) rays_fixed[(size_t)ray * 6 + lane] = 0;  // the walk's sums for this ray start from zero
   if (lane == 0) {
     nvalid_out[ray] = nvalid;
 #pragma unroll
@@ -554,13 +556,11 @@ __global__ __launch_bounds__(256, JT_WALK_WAVES) void k_march_bwd_walk(Dev D, Jt
     const int c = lane;
     const float v = c == 0 ? v6[0] : c == 1 ? v6[1] : c == 2 ? v6[2] : c == 3 ? v6[3] : c == 4 ? v6[4] : v6[5];
     const int ax = (c % 3) == 0 ? a0 : ((c % 3) == 1 ? a1 : a2);
-    if (DET) fixed_add(rays_fixed + (size_t)ray * 6 + (c < 3 ? 0 : 3) + ax, v);
-    else atomicAdd((c < 3 ? g_rays_o : g_rays_d) + ray * 3 + ax, v);
+    // ALWAYS in fixed point (integer atomics commute): the pose gradient does not depend on the order in which the runs of
+    // a ray arrive -- test-time pose optimisation and the camera trajectory of a training run are reproducible bit for bit
+    // in their density part, for one extra 5 us launch (k_rays_fixed_add)
+    fixed_add(rays_fixed + (size_t)ray * 6 + (c < 3 ? 0 : 3) + ax, v);
   }
-}
-
-__global__ void k_zero64(long long* p, long n) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0;
 }
 
 // g_rays_o/d [R][3] += fixed-point sums [R][6]
@@ -744,8 +744,8 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
   size_t o_vlist, o_nvalid, o_fixed;
   if (workspace_bytes < march_bwd_ws_layout(D.S, n_rays, &o_vlist, &o_nvalid, &o_fixed)) return JT_ERR_ARG;
   // JT_DETERMINISTIC with factor gradients wanted: g_factors points at int64 shadow buffers, ray sums in fixed point
-  long long* rays_fixed = jt_deterministic() ? reinterpret_cast<long long*>(reinterpret_cast<char*>(workspace) + o_fixed)
-                                             : nullptr;
+  const bool det = jt_deterministic() != 0;
+  long long* rays_fixed = reinterpret_cast<long long*>(reinterpret_cast<char*>(workspace) + o_fixed);
   JtFactors no_grads = {};  // g_factors == NULL: gradients w.r.t. the rays only (the walk writes no factor gradient)
   const JtFactors& GF = g_factors ? *g_factors : no_grads;
   float* gfeat = reinterpret_cast<float*>(workspace);
@@ -759,18 +759,14 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
                             (int)lds);
   hipLaunchKernelGGL(k_march_bwd_scan, dim3((n_rays + 3) / 4), dim3(256), lds, st, D, rays_o, rays_d, jitter, zvals,
                      n_rays, sigma_feat, weight, tmin, shade_offset, shade_idx, rgb_s, clamp_mask, g_rgb, g_opacity,
-                     g_xyz_app, gfeat, vlist, nvalid, g_rays_o, g_rays_d, Spad);
+                     g_xyz_app, gfeat, vlist, nvalid, g_rays_o, g_rays_d, rays_fixed, Spad);
   JT_LAUNCH_CHECK();
-  if (rays_fixed) {
-    hipLaunchKernelGGL(k_zero64, dim3((n_rays * 6 + 255) / 256), dim3(256), 0, st, rays_fixed, (long)n_rays * 6);
-    JT_LAUNCH_CHECK();
-  }
   const int runs = ((D.S + kWalkRun - 1) / kWalkRun + 3) & ~3;  // a wave's four groups: four runs of ONE (ray, plane)
   const long items = (long)n_rays * runs * 3;
   const int blocks = (int)((items + 15) / 16);
 #define JT_WALK(CD_)                                                                                              \
   do {                                                                                                           \
-    if (rays_fixed)                                                                                              \
+    if (det)                                                                                                     \
       hipLaunchKernelGGL((k_march_bwd_walk<CD_, true>), dim3(blocks), dim3(256), 0, st, D, GF, rays_o, rays_d,   \
                          jitter, zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d, rays_fixed); \
     else                                                                                                         \
@@ -783,10 +779,8 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
   else return JT_ERR_UNSUPPORTED;
 #undef JT_WALK
   JT_LAUNCH_CHECK();
-  if (rays_fixed) {
-    hipLaunchKernelGGL(k_rays_fixed_add, dim3((n_rays * 6 + 255) / 256), dim3(256), 0, st, rays_fixed, n_rays, g_rays_o,
-                       g_rays_d);
-    JT_LAUNCH_CHECK();
-  }
+  hipLaunchKernelGGL(k_rays_fixed_add, dim3((n_rays * 6 + 255) / 256), dim3(256), 0, st, rays_fixed, n_rays, g_rays_o,
+                     g_rays_d);
+  JT_LAUNCH_CHECK();
   return JT_OK;
 }

@@ -38,6 +38,10 @@ class _Entry:
     pass
 
 
+def has_key(o, k):
+    return (k in o) and o[k] is not None
+
+
 def capture(fn, pool=None):
     """Capture the launches of `fn()` into a hipGraph; returns (graph, fn's result).  A Python exception inside the
     capture is held until the capture has ended in an orderly way (ending a capture that an exception tore open
@@ -119,21 +123,24 @@ class GraphedTrainStep:
                 and opt.data.dataset in ("blender", "llff")
                 and (not opt.optim.warmup_pose or m.it >= int(opt.optim.warmup_pose))   # past the pose-lr warm-up
                 and (not has(opt.optim, "grad_accum_iter") or int(opt.optim.grad_accum_iter) == 1)
-                and (not has(opt.optim, "pose_grad_accum_iter") or int(opt.optim.pose_grad_accum_iter) == 1)
-                and self._near_plane_settled(opt)
                 and isinstance(m.optim, VMAdam)
                 and ops.data_parallel_world() == 1 and not ops._DP["force"] and self.model.graph.ray_shard is None)
 
-    def _near_plane_settled(self, opt):
-        """LLFF: the near plane follows tensorf_near_plane_schedule (model/tensorf.py:230-232) and is a launch argument
-        of the march kernels; iterations are captured once the schedule has stopped moving (bat_llff_VM_MLP: from
-        progress 0.5 on, i.e. all of the large-grid stages)."""
-        if opt.data.dataset == "blender":
-            return True
-        from .model.bat_hip import interp_schedule
-        p = self.model.graph.nerf.progress_host
-        sch = opt.tensorf_near_plane_schedule
-        return interp_schedule(p, sch) == interp_schedule(min(1.0, p + 1.0 / opt.max_iter), sch) == interp_schedule(1.0, sch)
+    def _zvals_static(self, opt, tf, S, refresh=True):
+        """NDC scenes: static [S] row of un-jittered sample depths + [1] jitter scale that BAT_VMSplit.forward reads while
+        a graph is captured / replayed; `refresh` writes linspace(near, far, S) for the CURRENT near plane with the very
+        kernel the eager path uses (bit-identical rows) -- two small launches in front of a replay.  The near plane
+        follows tensorf_near_plane_schedule over the first half of an LLFF run (model/tensorf.py:230-232); round 2
+        refused to capture those 25 000 iterations."""
+        buf = self.__dict__.setdefault("_zv", {})
+        if S not in buf:
+            buf[S] = (torch.zeros(S, device=opt.device, dtype=torch.float32), torch.zeros(1, device=opt.device, dtype=torch.float32))
+        base, scale = buf[S]
+        if refresh:
+            near, far = float(tf.near_far[0]), float(tf.near_far[1])
+            torch.linspace(near, far, S, out=base)
+            scale.fill_((far - near) / S)
+        return base, scale
 
     def _blur_scheduled(self, opt):
         """True while the factor-blur schedule is above its cut-off (model/tensorf.py:208-220) whatever the random
@@ -177,7 +184,9 @@ class GraphedTrainStep:
         return (id(m.optim), getattr(m.optim, "_dyn_gen", 0), ops.workspace_generation(), tuple(g.nerf.resolution),
                 int(g.nerf.n_samples), int(opt.nerf.n_rays), ny, nx, use_edge, weights, ptrs, float(view_pe),
                 float(fea_pe), float(getattr(m, "render_loss_scale", 1.0)), tf.alphaMask is not None,
-                tuple(float(v) for v in tf.near_far), id(tf.jitter_override))
+                # NDC scenes: the near plane reaches the graph through static memory (_zvals_static), only far is structure
+                (float(tf.near_far[1]),) if bool(opt.camera.ndc) else tuple(float(v) for v in tf.near_far),
+                id(tf.jitter_override))
 
     def _lattice_shapes(self, H, W, step):
         memo = self.__dict__.setdefault("_shape_memo", {})
@@ -201,7 +210,7 @@ class GraphedTrainStep:
             return self._eager(opt, var)
         g.it = m.it
         tf = g.nerf.tensorf
-        if opt.data.dataset != "blender":  # what render_rays does per call (model/tensorf.py:230-232); settled by now
+        if opt.data.dataset != "blender":  # what render_rays does per call (model/tensorf.py:230-232)
             from .model.bat_hip import interp_schedule
             tf.near_far[0] = interp_schedule(g.nerf.progress_host, opt.tensorf_near_plane_schedule)
             opt.nerf.depth.range[0] = tf.near_far[0]
@@ -262,6 +271,8 @@ class GraphedTrainStep:
         ops.poke_words(e.off, [ox, oy] + self._supervision_words(var, sig[8]))
         if blur_key is not None:
             self._poke_taps(opt, blur)
+        if bool(opt.camera.ndc):
+            self._zvals_static(opt, tf, int(g.nerf.n_samples))   # this iteration's near plane
         ops.poke_floats(self._loss_weights(opt), list(m.fused_loss_weights(opt)))
         m.optim.prepare_step(e.stepped)
         e.graph.replay()
@@ -272,9 +283,21 @@ class GraphedTrainStep:
             pg["lr"] *= min(1, m.it / opt.optim.warmup_pose)
         m.it += 1
         w = g.se3_refine.weight
-        w.grad = e.pose_grad
-        m.optim_pose.step()
-        w.grad = None
+        accum = int(opt.optim.pose_grad_accum_iter) if has_key(opt.optim, "pose_grad_accum_iter") else 1
+        if accum <= 1:
+            w.grad = e.pose_grad
+            m.optim_pose.step()
+            w.grad = None
+        else:
+            # pose gradients accumulate over `accum` iterations (model/bat.py:103-106; bat_llff_VM_MLP: 8 until iteration
+            # 20 000), in the eager path's order.  e.pose_grad is graph memory: the next replay overwrites it.
+            if w.grad is None:
+                w.grad = e.pose_grad.clone()
+            else:
+                w.grad.add_(e.pose_grad)
+            if m.it % accum == 0:
+                m.optim_pose.step()
+                w.grad = None
         if opt.optim.warmup_pose:
             pg["lr"] = pg["lr_orig"]
         if m.sched_pose is not None:
@@ -339,6 +362,8 @@ class GraphedTrainStep:
         if blur[2] is not None:
             buf = self._poke_taps(opt, blur)
             tf.taps_static = (buf[0], buf[1])
+        if bool(opt.camera.ndc):
+            tf.zvals_static = self._zvals_static(opt, tf, int(g.nerf.n_samples))
         coin_prev = tf.coin_override
         if coin is not None:
             tf.coin_override = coin
@@ -359,7 +384,10 @@ class GraphedTrainStep:
             return (sx[None, :] + sy[:, None] * W).reshape(-1), ny, nx
 
         m.optim.zero_grad()
-        m.optim_pose.zero_grad()
+        # pose gradients may be mid-accumulation (pose_grad_accum_iter > 1, model/bat.py:103-106): the capture must not lose
+        # what the iterations before it have summed
+        pose_acc = g.se3_refine.weight.grad
+        g.se3_refine.weight.grad = None
         # The captured backward must not meet the parameters' cached AccumulateGrad nodes: such a node carries the
         # stream it was created on -- the legacy stream of an earlier eager iteration whose autograd graph is still
         # alive somewhere (a loss kept for logging is enough) -- and the engine would synchronise that stream with the
@@ -389,10 +417,14 @@ class GraphedTrainStep:
                 return v, loss
 
             e.graph, (v, loss) = capture(body, pool=self.pool)
+        except BaseException:
+            g.se3_refine.weight.grad = pose_acc
+            raise
         finally:
             ops.USE_AUX_STREAM = aux_was
             g.lattice_override = None
             tf.taps_static = None
+            tf.zvals_static = None
             tf.coin_override = coin_prev
             ops.LOSS_WEIGHTS_STATIC = None
             ops.SUPERVISION_SLOTS_STATIC = None
@@ -403,7 +435,7 @@ class GraphedTrainStep:
         e.pose_grad = g.se3_refine.weight.grad
         e.stepped = {id(p) for grp in m.optim.param_groups for p in grp["params"] if p.grad is not None}
         m.optim.zero_grad()
-        g.se3_refine.weight.grad = None
+        g.se3_refine.weight.grad = pose_acc
         return e
 
 

@@ -315,7 +315,12 @@ class Graph(torch.nn.Module):
             else:
                 assert strat == "single_view_rand_rays"
                 var.ray_idx = torch.randperm(opt.H * opt.W, device=opt.device)[:opt.nerf.n_rays]
-            ret = self.render(opt, pose, intr_inv=var.intr_inv, ray_idx=var.ray_idx, mode=mode, intr=var.intr)
+            ret = None
+            if mode == "test-optim":
+                var.pop("fused_render_loss", None)
+                ret = self.render_test_fused(opt, pose, var)   # one launch for render + loss + backward, when it applies
+            if ret is None:
+                ret = self.render(opt, pose, intr_inv=var.intr_inv, ray_idx=var.ray_idx, mode=mode, intr=var.intr)
         elif _has(opt.nerf, "eval_graph") and opt.nerf.eval_graph and not torch.is_grad_enabled():
             # the whole sliced render of a view as one hipGraph, replayed per held-out view (graphed.GraphedEvalRender)
             if self.eval_graph is None:
@@ -335,6 +340,35 @@ class Graph(torch.nn.Module):
         # rays for the sampled pixels only, NDC folded in (camera.py:231-261, 303-340)
         center, ray = ops.ray_gen(pose, intr_inv, intr, ray_idx, opt.W, ndc=bool(opt.camera.ndc), ndc_near=ndc_near)
         return self.render_rays(opt, center, ray, mode, n_views=len(pose), n_pixels_per_view=center.shape[1])
+
+    def render_test_fused(self, opt, pose, var):
+        """Test-time pose optimisation (model/bat.py:265-292) through the single-launch kernel (csrc/jt_fused.hip): the
+        scene is frozen, so render + photometric loss + the backward to the rays are ONE launch and nothing is recorded in
+        between.  Returns None when the staged path must run instead: opt.optim.test_fused not set, a factor blur
+        active for this call (LLFF's test_kernel_schedule), scene parameters that want gradients, or no GT images."""
+        if not (_has(opt.optim, "test_fused") and opt.optim.test_fused):
+            return None   # opt-in: measured on MI355X it does not beat the staged kernels (DESIGN.md section 3, X1)
+        tf = self.nerf.tensorf
+        if not (pose.is_cuda and torch.is_grad_enabled() and torch.is_tensor(var.get("image"))
+                and not any(p.requires_grad for p in tf.parameters())):
+            return None
+        # the host draws of render_rays happen whichever path runs (same random streams)
+        pd, pc, c2f_mode, ksize = self.resolve_blur(opt, "test-optim")
+        if c2f_mode is not None:
+            self._blur_memo = (pd, pc, c2f_mode, ksize)   # render_rays must not draw a second time
+            return None
+        if opt.data.dataset != "blender":
+            tf.near_far[0] = interp_schedule(self.nerf.progress_host, opt.tensorf_near_plane_schedule)
+            opt.nerf.depth.range[0] = tf.near_far[0]
+        view_pe = interp_schedule(self.nerf.progress_host, opt.c2f_view_pe_schedule) if _has(opt, "c2f_view_pe_schedule") else 1.0
+        fea_pe = interp_schedule(self.nerf.progress_host, opt.c2f_fea_pe_schedule) if _has(opt, "c2f_fea_pe_schedule") else 1.0
+        ndc_near = float(opt.arch.ndc_near_plane) if _has(opt.arch, "ndc_near_plane") else 1.0
+        center, ray = ops.ray_gen(pose, var.intr_inv, var.intr, var.ray_idx, opt.W, ndc=bool(opt.camera.ndc), ndc_near=ndc_near)
+        B, r = center.shape[0], center.shape[1]
+        render, rgb, depth, opacity = tf.render_pose_fused(
+            opt, center.reshape(-1, 3), ray.reshape(-1, 3), var.image, var.ray_idx, r, white_bg=opt.nerf.setbg_opaque,
+            ndc_ray=opt.camera.ndc, N_samples=self.nerf.n_samples, view_pe_progress=view_pe, fea_pe_progress=fea_pe)
+        return Opt(rgb=rgb.view(B, r, 3), depth=depth.view(B, r, 1), opacity=opacity.view(B, r, 1), fused_render_loss=render)
 
     def render_by_slices(self, opt, pose, intr_inv=None, mode=None, intr=None):
         """model/nerf.py:728-740.  Rays are independent and nothing is random at eval time, so the slice size only
@@ -373,7 +407,8 @@ class Graph(torch.nn.Module):
     def render_rays(self, opt, center, ray, mode=None, n_views=None, n_pixels_per_view=None):
         batch_size = n_views if n_views else center.shape[0]
         dim1 = n_pixels_per_view if n_pixels_per_view else center.shape[1]
-        pd, pc, c2f_mode, ksize = self.resolve_blur(opt, mode)
+        memo = self.__dict__.pop("_blur_memo", None)   # render_test_fused already took this call's draw
+        pd, pc, c2f_mode, ksize = memo if memo is not None else self.resolve_blur(opt, mode)
         tf = self.nerf.tensorf
         if opt.data.dataset != "blender":
             tf.near_far[0] = interp_schedule(self.nerf.progress_host, opt.tensorf_near_plane_schedule)
@@ -397,7 +432,9 @@ class Graph(torch.nn.Module):
     def compute_loss(self, opt, var, mode=None):
         loss = Opt()
         batch_size = len(var.idx)
-        if opt.loss_weight.render is not None:
+        if opt.loss_weight.render is not None and mode == "test-optim" and var.get("fused_render_loss") is not None:
+            loss.render = var.fused_render_loss   # came out of the render launch itself (Graph.render_test_fused)
+        elif opt.loss_weight.render is not None:
             edge_on = False
             if _has(opt, "edge_mask_on_render_loss") and opt.edge_mask_on_render_loss:
                 edge_on = (self.it % 2 == 0) if (_has(opt, "alternate_edge_loss") and opt.alternate_edge_loss) else True

@@ -78,6 +78,8 @@ def poke_floats(dst, values, offset=0):
           "jt_poke")
 
 
+# shaded-sample capacity above which the render reads the actual shaded count back instead of allocating for rays x samples
+TAPE_SYNC_ENTRIES = int(float(os.environ.get("JT_TAPE_SYNC_GB", "8")) * 2 ** 30 / 1920)
 KEEP_INTERMEDIATES = False
 # roctx ranges with the reference's record_function names (model/base.py:119-153, tensorBase.py:774) when
 # opt.profiling is set (Model.train_iteration switches this on): they show up in rocprofv3 --marker-trace output.
@@ -370,6 +372,14 @@ class RenderRays(torch.autograd.Function):
                                    ptr(sigma_feat), ptr(weight), ptr(tmin), ptr(count), ptr(offset), ptr(sidx),
                                    ptr(opacity), ptr(depth), st), "jt_march_forward")
         n = cap = R * S  # worst case; kernels bound themselves by shade_offset[R] on the device
+        if cap > TAPE_SYNC_ENTRIES and not torch.cuda.is_current_stream_capturing():
+            # a batch whose worst-case tape (1.9 KB per sample) would run into tens of GB: ONE host read of the shaded
+            # count the march just produced, and everything per shaded sample -- entry lists, colours, the record
+            # workspace -- is sized by it (configs[3] on one GPU: 62 500 rays x 1 000 samples = 120 GB worst case,
+            # 86 GB for the all-shaded random-init field, a few GB for a trained one).  Such an iteration takes 100 ms:
+            # the synchronisation is not what it waits for.  Smaller batches (every training config) keep the
+            # sync-free worst-case sizing.
+            n = cap = max(32, (int(offset[R].item()) + 31) // 32 * 32)
         cap_alloc = max(cap, 1)
         eray = torch.empty(cap_alloc, device=dev, dtype=torch.int32)
         esmp = torch.empty(cap_alloc, device=dev, dtype=torch.int32)
@@ -589,6 +599,68 @@ def render_rays(cfg, rays_o, rays_d, jitter, zvals, density_plane, density_line,
                            *app_line, basis, *mlp_params)
     cfg.reg3 = out[3]  # None unless cfg.reg_flags asked for the regularisers
     return out[0], out[1], out[2]
+
+
+# ----------------------------------------------------------------------------------------------
+# single-launch render + loss + backward to the rays (test-time pose optimisation)
+# ----------------------------------------------------------------------------------------------
+class RenderPoseFused(torch.autograd.Function):
+    """(rays of a frozen scene, supervising pixels) -> photometric loss, with d loss / d rays produced by the SAME launch
+    (csrc/jt_fused.hip: one wave per ray, forward and backward fused, no tape).  Drop-in, for mode "test-optim"
+    (model/bat.py:265-292), for render_rays + the render term of compute_loss + their autograd.  Returns
+    (render loss = mean squared colour error over the 3 R values, rgb [R,3], depth [R], opacity [R]); only the loss is
+    differentiable, and only w.r.t. rays_o / rays_d."""
+
+    @staticmethod
+    def forward(ctx, cfg, rays_o, rays_d, zvals, image, ray_idx, rays_per_view, *params):
+        dp, dl, ap, al = params[0:3], params[3:6], params[6:9], params[9:12]
+        dev = rays_o.device
+        assert dev.type == "cuda", "joint_tensorf_amd renders on the GPU only (no CPU fallback)"
+        R = rays_o.shape[0]
+        rays_o = rays_o.detach().contiguous().float()
+        rays_d = rays_d.detach().contiguous().float()
+        zvals = None if zvals is None else zvals.detach().contiguous().float().view(-1)
+        img = image.detach().contiguous().float()
+        n_views = R // int(rays_per_view)
+        assert img.dim() == 4 and img.shape[0] == n_views and img.shape[1] == 3 and R == n_views * int(rays_per_view)
+        idx = ray_idx.detach().contiguous().to(torch.int64)
+        assert idx.numel() == int(rays_per_view)
+        sd = [[factor_storage(p) for p in lst] for lst in (dp, dl, ap, al)]
+        mlp_t = [t.detach().contiguous() for t in params[12:19]]
+        scene = cfg.scene()
+        fac = _factors_struct(*sd, cfg.alpha_mask[0] if cfg.alpha_mask is not None else None)
+        mlp = _mlp_struct(*mlp_t)
+        nbytes = lib.jt_pose_fused_workspace_bytes(scene)
+        key = (str(dev), "pose_fused")
+        ws = _WS.get(key)
+        if ws is None or ws.numel() < nbytes:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("workspace 'pose_fused' would grow during hipGraph capture")
+            # zero-filled: the head of the workspace is the kernel's loss accumulator + arrival counter
+            _WS[key] = ws = torch.zeros(max(int(nbytes), 16), device=dev, dtype=torch.uint8)
+            _WS_GEN[0] += 1
+        f32 = dict(device=dev, dtype=torch.float32)
+        buf = torch.empty(R * 12 + 1, **f32)   # rgb 3 | depth | opacity | sqerr | g_o 3 | g_d 3 | loss: one allocation
+        rgb, depth, opacity, sqerr = buf[0:3 * R].view(R, 3), buf[3 * R:4 * R], buf[4 * R:5 * R], buf[5 * R:6 * R]
+        g_o, g_d, loss = buf[6 * R:9 * R].view(R, 3), buf[9 * R:12 * R].view(R, 3), buf[12 * R:12 * R + 1]
+        check(lib.jt_pose_fused(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(zvals), R, ptr(img), ptr(idx),
+                                int(rays_per_view), int(img.shape[2] * img.shape[3]), 1.0 / (3.0 * R), ptr(rgb), ptr(depth),
+                                ptr(opacity), ptr(sqerr), ptr(loss), ptr(g_o), ptr(g_d), ptr(ws), nbytes, _stream()),
+              "jt_pose_fused")
+        ctx.grads = (g_o, g_d)
+        ctx.mark_non_differentiable(rgb, depth, opacity)
+        return loss[0], rgb, depth, opacity
+
+    @staticmethod
+    def backward(ctx, g_loss, g_rgb=None, g_depth=None, g_opacity=None):
+        g_o, g_d = ctx.grads
+        return (None, g_o * g_loss, g_d * g_loss, None, None, None, None) + (None,) * 19
+
+
+def render_pose_fused(cfg, rays_o, rays_d, zvals, image, ray_idx, rays_per_view, density_plane, density_line, app_plane,
+                      app_line, basis, mlp_params):
+    return RenderPoseFused.apply(cfg, rays_o, rays_d, zvals, image, ray_idx, rays_per_view, *density_plane, *density_line,
+                                 *app_plane, *app_line, basis, *mlp_params)
 
 
 # ----------------------------------------------------------------------------------------------

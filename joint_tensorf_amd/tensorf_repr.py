@@ -403,6 +403,44 @@ class BAT_VMSplit(torch.nn.Module):
         if bool(get("detach_ndc_center_shift", False)):
             raise NotImplementedError("arch.detach_ndc_center_shift=true is not built (false in bat_llff_VM_MLP)")
 
+    def _render_cfg(self, S, ndc_ray, white_bg, plane_hw=None, view_pe_progress=1.0, fea_pe_progress=1.0, use_mask=True):
+        """the scene description a render launch takes (ops.RenderCfg mirrors JtScene)"""
+        g = self.gridSize.tolist()
+        if plane_hw is None:
+            plane_hw = [(g[MAT_MODE[i][1]], g[MAT_MODE[i][0]]) for i in range(3)]
+        if len(set(self.density_n_comp)) != 1 or len(set(self.app_n_comp)) != 1:
+            raise NotImplementedError("per-plane component counts must be equal (they are in both BAT yamls)")
+        return ops.RenderCfg(
+            aabb=self.aabb.view(-1).tolist(), plane_hw=plane_hw, line_len=[g[VEC_MODE[i]] for i in range(3)],
+            n_comp_density=self.density_n_comp[0], n_comp_app=self.app_n_comp[0], step_size=float(self.stepSize),
+            near_far=(float(self.near_far[0]), float(self.near_far[1])), distance_scale=self.distance_scale,
+            density_shift=self.density_shift,
+            density_act=_lib.JT_ACT_SOFTPLUS if self.fea2denseAct == "softplus" else _lib.JT_ACT_RELU,
+            weight_thres=self.rayMarch_weight_thres, n_samples=S, ndc=ndc_ray, white_bg=white_bg, app_dim=self.app_dim,
+            mlp_kind=self.renderModule.kind, mlp_hidden=self.featureC, view_pe=self.view_pe, fea_pe=self.fea_pe,
+            view_pe_progress=view_pe_progress, fea_pe_progress=fea_pe_progress,
+            alpha_mask=self.alphaMask.kernel_args() if (self.alphaMask is not None and use_mask) else None)
+
+    def render_pose_fused(self, opt, center, ray_dir, image, ray_idx, rays_per_view, white_bg=True, ndc_ray=False,
+                          N_samples=-1, view_pe_progress=1.0, fea_pe_progress=1.0):
+        """Test-time pose optimisation's render (scene frozen, no blur, no jitter): loss and its gradient w.r.t. the rays
+        from ONE launch (ops.render_pose_fused / csrc/jt_fused.hip).  Same arguments as forward() plus the supervising
+        images [views,3,H,W] and the lattice's pixel indices; returns (render loss, rgb [R,3], depth [R], opacity [R])."""
+        self._check_flags(opt)
+        self.opt = opt
+        self.__dict__.setdefault("_reg_cache", {}).clear()
+        self.kernel_density = self.kernel_color = None
+        self.c2f_mode = None
+        S = N_samples if N_samples > 0 else self.nSamples
+        near, far = float(self.near_far[0]), float(self.near_far[1])
+        zvals = torch.linspace(near, far, S, device=center.device, dtype=torch.float32) if ndc_ray else None
+        cfg = self._render_cfg(S, ndc_ray, bool(white_bg), None, view_pe_progress, fea_pe_progress, use_mask=True)
+        out = ops.render_pose_fused(cfg, center, ray_dir, zvals, image, ray_idx, rays_per_view, list(self.density_plane),
+                                    list(self.density_line), list(self.app_plane), list(self.app_line), self.basis_mat.weight,
+                                    self.renderModule.weights())
+        self.last_render_cfg = cfg
+        return out
+
     # ---- the renderer (batBase.py:44-165) -----------------------------------------------------------
     def forward(self, opt, center, ray_dir, white_bg=True, is_train=False, ndc_ray=False, N_samples=-1,
                 c2f_parameter_density=None, c2f_parameter_color=None, c2f_mode=None, c2f_kernel_size=None,
@@ -416,10 +454,17 @@ class BAT_VMSplit(torch.nn.Module):
         R = center.shape[0]
         jitter = zvals = None
         if ndc_ray:
-            zvals = torch.linspace(near, far, S, device=dev, dtype=torch.float32).unsqueeze(0)
+            zs = getattr(self, "zvals_static", None)
+            if zs is not None and zs[0].numel() == S:
+                # hipGraph capture / replay (graphed.GraphedTrainStep): the un-jittered row linspace(near, far, S) and the
+                # jitter scale (far - near) / S live in static device memory, refreshed in front of every replay -- the
+                # near plane follows a schedule (model/tensorf.py:230-232) and must not be baked into the graph
+                zvals, zscale = zs[0].view(1, -1), zs[1]
+            else:
+                zvals, zscale = torch.linspace(near, far, S, device=dev, dtype=torch.float32).unsqueeze(0), (far - near) / S
             if is_train:
                 u = self.jitter_override if self.jitter_override is not None else torch.rand_like(zvals)
-                zvals = zvals + u.to(dev).view(1, -1) * ((far - near) / S)
+                zvals = zvals + u.to(dev).view(1, -1) * zscale
         elif is_train:
             # (tests pin the draws with a [>= R, 1] tensor; the first R rows are this batch's)
             jitter = self.jitter_override[:R] if self.jitter_override is not None else torch.rand(R, 1, device=dev)
@@ -452,20 +497,9 @@ class BAT_VMSplit(torch.nn.Module):
             wb = coin < 0.5
         else:
             wb = False
-        if len(set(self.density_n_comp)) != 1 or len(set(self.app_n_comp)) != 1:
-            raise NotImplementedError("per-plane component counts must be equal (they are in both BAT yamls)")
-        cfg = ops.RenderCfg(
-            aabb=self.aabb.view(-1).tolist(), plane_hw=plane_hw, line_len=[g[VEC_MODE[i]] for i in range(3)],
-            n_comp_density=self.density_n_comp[0], n_comp_app=self.app_n_comp[0], step_size=float(self.stepSize),
-            near_far=(near, far), distance_scale=self.distance_scale, density_shift=self.density_shift,
-            density_act=_lib.JT_ACT_SOFTPLUS if self.fea2denseAct == "softplus" else _lib.JT_ACT_RELU,
-            weight_thres=self.rayMarch_weight_thres, n_samples=S, ndc=ndc_ray, white_bg=wb, app_dim=self.app_dim,
-            mlp_kind=self.renderModule.kind, mlp_hidden=self.featureC, view_pe=self.view_pe, fea_pe=self.fea_pe,
-            view_pe_progress=view_pe_progress, fea_pe_progress=fea_pe_progress,
-            # empty-space samples are dropped only while the blur is off (batBase.py:76-82)
-            alpha_mask=self.alphaMask.kernel_args() if (self.alphaMask is not None and c2f_mode is None
-                                                         and c2f_parameter_density is None
-                                                         and c2f_parameter_color is None) else None)
+        cfg = self._render_cfg(S, ndc_ray, wb, plane_hw, view_pe_progress, fea_pe_progress,
+                               # empty-space samples are dropped only while the blur is off (batBase.py:76-82)
+                               use_mask=(c2f_mode is None and c2f_parameter_density is None and c2f_parameter_color is None))
         # blur off and a backward to come: the regularisers ride on the render node (ops.RenderRays), so that their
         # gradient is added into the render gradient in place; _reg() then finds the values in its cache
         lw = opt.get("loss_weight", None) if isinstance(opt, dict) else getattr(opt, "loss_weight", None)

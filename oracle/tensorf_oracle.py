@@ -420,6 +420,8 @@ def _relu(x, mask, report):
     if report is not None:
         report["units"] = report.get("units", 0) + x.numel()
         report["flips"] = report.get("flips", 0) + int(diff.sum())
+        # direction of the disagreements (a systematic bias of the implementation under test would show as one-sided)
+        report["flips_oracle_on"] = report.get("flips_oracle_on", 0) + int((diff & own).sum())
         if diff.any():
             report["max_abs"] = max(report.get("max_abs", 0.0), float(x.detach()[diff].abs().max()))
     return x * mask.to(x.dtype)

@@ -212,7 +212,7 @@ def run_oracle(opt, model, var_all, ctx, dtype=torch.float32, slice_rays=4096, p
     ref = dict(rgb=torch.empty(B, n_lat, 3, device=DEV, dtype=dtype), depth=torch.empty(B, n_lat, device=DEV, dtype=dtype),
                opacity=torch.empty(B, n_lat, device=DEV, dtype=dtype))
     per_view = max(1, slice_rays // B) if kd is None else n_lat
-    total, shaded, in_box, flips, tie = 0.0, 0, 0, 0, 0.0
+    total, shaded, in_box, flips, tie, flips_on = 0.0, 0, 0, 0, 0.0, 0
     relu_rep = {}
     noise = g.pose_noise.detach().to(dtype) if (opt.data.dataset == "blender" and opt.camera.noise) else None
     intr_inv, intr = var_all.intr_inv.to(dtype), var_all.intr.to(dtype)
@@ -255,6 +255,7 @@ def run_oracle(opt, model, var_all, ctx, dtype=torch.float32, slice_rays=4096, p
             # samples the two sides decided differently must be near-ties of `weight > thres`
             diff = aux["own_app_mask"] != pin
             flips += int(diff.sum())
+            flips_on += int((diff & aux["own_app_mask"]).sum())   # the oracle shades, the product path did not
             if diff.any():
                 w = aux["weight"].detach()[diff]
                 tie = max(tie, float((w / cfg.rayMarch_weight_thres - 1).abs().max()))
@@ -278,7 +279,8 @@ def run_oracle(opt, model, var_all, ctx, dtype=torch.float32, slice_rays=4096, p
     grads = {nme: v.grad for nme, v in O.flat_params(params)}
     grads["se3"] = se3.grad
     return dict(rgb=ref["rgb"].reshape(R, 3), depth=ref["depth"].reshape(R), opacity=ref["opacity"].reshape(R),
-                total=total, grads=grads, shaded=shaded, in_box=in_box, blur=kd is not None, flips=flips, tie=tie, relu=relu_rep)
+                total=total, grads=grads, shaded=shaded, in_box=in_box, blur=kd is not None, flips=flips, flips_oracle_on=flips_on,
+                tie=tie, relu=relu_rep)
 
 
 def compare(name, opt, model, hip, ref, truth=None, ref_b=None):
@@ -289,6 +291,7 @@ def compare(name, opt, model, hip, ref, truth=None, ref_b=None):
     ctx = hip["ctx"]
     rep = dict(case=name, rays=ctx["R"], samples_per_ray=ctx["S"], grid=tf.gridSize.tolist(), blur=ref["blur"],
                shaded=ref["shaded"], in_box=ref["in_box"], shaded_hip=int(ctx["shade_mask"].sum()), mask_flips=ref["flips"],
+               mask_flips_oracle_on=ref.get("flips_oracle_on", 0), relu_flips_oracle_on=ref["relu"].get("flips_oracle_on", 0),
                mask_flip_max_rel_distance_from_threshold=ref["tie"], relu_units=ref["relu"].get("units", 0),
                relu_flips=ref["relu"].get("flips", 0), relu_flip_max_abs_preactivation=ref["relu"].get("max_abs", 0.0), loss_hip=hip["total"], loss_oracle=ref["total"], values={},
                grads={})
@@ -325,6 +328,9 @@ def report(rep):
         rep.get("shaded_hip"), rep.get("mask_flips"), rep.get("mask_flip_max_rel_distance_from_threshold", 0.0)))
     print("   ReLU signs: %s units, %s decided differently by the oracle (largest |pre-activation| among them %.1e)" % (
         rep.get("relu_units"), rep.get("relu_flips"), rep.get("relu_flip_max_abs_preactivation", 0.0)))
+    print("   direction of the disagreements (oracle ON, product path off / the other way): shading mask %s / %s, ReLU %s / %s"
+          % (rep.get("mask_flips_oracle_on"), (rep.get("mask_flips") or 0) - (rep.get("mask_flips_oracle_on") or 0),
+             rep.get("relu_flips_oracle_on"), (rep.get("relu_flips") or 0) - (rep.get("relu_flips_oracle_on") or 0)))
     print("   max abs error vs fp32 oracle: " + ", ".join("%s %.2e" % kv for kv in rep["values"].items()))
     if "values64" in rep:
         print("   max abs error vs fp64 oracle (hip | fp32 oracle): " +

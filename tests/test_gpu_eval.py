@@ -53,12 +53,15 @@ def test_prealign_cameras():
     np.testing.assert_allclose(err.t.cpu().numpy(), fx.arrays["align.err.t"], atol=1e-5)
 
 
-def test_test_time_optim_and_eval_render():
+@pytest.mark.parametrize("fused", [False, True])
+def test_test_time_optim_and_eval_render(fused):
+    """fused = True: the same reference trace through the single-launch kernel (opt.optim.test_fused, csrc/jt_fused.hip)"""
     from joint_tensorf_amd import ops
     from joint_tensorf_amd.options import Opt
     fx = Fixture("blender_test_optim")
     m = fx.meta
     opt, model = _model(fx)
+    opt.optim.test_fused = fused
     g = model.graph
     g.sim3 = Opt(t0=fx.t("sim3.t0", "cuda"), t1=fx.t("sim3.t1", "cuda"), s0=fx.t("sim3.s0", "cuda"),
                  s1=fx.t("sim3.s1", "cuda"), R=fx.t("sim3.R", "cuda"))

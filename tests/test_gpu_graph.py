@@ -241,8 +241,13 @@ def _build_llff(it0):
     return opt, model, var0
 
 
-def test_graph_replay_of_llff_iterations_is_bit_identical_to_eager():
-    """bat_llff_VM_MLP past the point where its near-plane schedule has settled (progress 0.5): NDC rays, WeakView MLP,
+@pytest.mark.parametrize("it0", [30000, 7000])
+def test_graph_replay_of_llff_iterations_is_bit_identical_to_eager(it0):
+    """bat_llff_VM_MLP: it0 = 30 000, past the point where its near-plane schedule has settled (progress 0.5), and -- round
+    3 -- it0 = 7 000, in the FIRST half of the run, which round 2 refused to capture: the near plane moves every iteration
+    (the un-jittered depth row and the jitter scale reach the graph through static memory, GraphedTrainStep._zvals_static),
+    the factor blur is on, and pose gradients accumulate over 8 iterations before a pose step (model/bat.py:103-106: two
+    pose steps fall into the 20 iterations).  NDC rays, WeakView MLP,
     the white-background COIN of every training call (two graph variants, the draw handed to whichever path runs), TV
     weights that decay every iteration (read from device memory inside the graph), pose-lr warm-up bookkeeping.
     Run in JT_DETERMINISTIC mode, where neither path has order-dependent sums: every loss term of every iteration and
@@ -252,7 +257,7 @@ def test_graph_replay_of_llff_iterations_is_bit_identical_to_eager():
     from joint_tensorf_amd._lib import lib
     from joint_tensorf_amd.graphed import GraphedTrainStep
     from joint_tensorf_amd.options import Opt
-    K, it0 = 20, 30000
+    K = 20
     res = []
     prev = lib.jt_set_deterministic(1)
     try:
@@ -277,6 +282,8 @@ def test_graph_replay_of_llff_iterations_is_bit_identical_to_eager():
     (l_e, sd_e, _, r_e, tv_e, _), (l_g, sd_g, stats, r_g, tv_g, lw) = res
     assert stats["replayed"] >= K - 8 and stats["captured"] >= 2, stats
     assert r_e == r_g and tv_e == tv_g and tv_e[0] > tv_e[-1] > 0   # same coin stream consumed, TV weights decaying
+    if it0 < 20000:  # the first half of the run: pose steps every 8th iteration, the near plane on its way down
+        assert int(opt.optim.pose_grad_accum_iter) == 8 and 0.0 < float(opt.nerf.depth.range[0]) < 0.4
     np.testing.assert_array_equal(l_g, l_e)
     for k in sd_e:
         assert torch.equal(sd_e[k], sd_g[k]), k

@@ -217,4 +217,4 @@ def test_resume_from_a_reference_checkpoint_steps_the_optimizer(tmp_path):
     m.optim.step()
     ref.step()
     for i, (p, c) in enumerate(zip(flat, clones)):
-        np.testing.assert_allclose(p.detach().cpu().numpy(), c.detach().cpu().numpy(), rtol=0, atol=2e-7, err_msg=str(i))
+        np.testing.assert_allclose(p.detach().cpu().numpy(), c.detach().cpu().numpy(), rtol=3e-7, atol=1e-7, err_msg=str(i))

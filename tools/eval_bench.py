@@ -23,6 +23,10 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--scene", default="random", choices=["random", "blobs"], help="see bench.py --scene")
     ap.add_argument("--graph", action="store_true", help="replay the sliced render from one hipGraph (nerf.eval_graph)")
+    ap.add_argument("--fused", action="store_true",
+                    help="test-time optimisation through the single-launch fused kernel (csrc/jt_fused.hip, "
+                         "opt.optim.test_fused) instead of the staged kernels + pose-only backward")
+    ap.add_argument("--no-render", action="store_true", help="skip the full-image render timing")
     args = ap.parse_args()
     sys.argv = [sys.argv[0]]
     import bench
@@ -36,6 +40,7 @@ def main():
                        nerf=dict(sample_intvs=args.samples), optim=dict(test_iter=args.test_iters))
     opt.nerf.eval_graph = bool(args.graph)
     opt.optim.test_graph = bool(args.graph)
+    opt.optim.test_fused = bool(args.fused)
     stage, it0 = bench.stage_setup(opt, -1)
     opt.nerf.n_rays = opt.train_schedule.n_rays_rest
     model = bench.build_model(opt, it0, int(opt.data.num_views))
@@ -52,14 +57,20 @@ def main():
     g.eval()
     old_photo = opt.optim.test_photo
     opt.optim.test_photo = False
+    t_render = float("nan")
     with torch.no_grad():
-        g.forward(opt, Opt(dict(var)), mode="eval")
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.reps):
-            out = g.forward(opt, Opt(dict(var)), mode="eval")
-        torch.cuda.synchronize()
-        t_render = (time.perf_counter() - t0) / args.reps
+        if args.no_render:
+            raise_skip = True
+        else:
+            raise_skip = False
+            g.forward(opt, Opt(dict(var)), mode="eval")
+        if not raise_skip:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.reps):
+                g.forward(opt, Opt(dict(var)), mode="eval")
+            torch.cuda.synchronize()
+            t_render = (time.perf_counter() - t0) / args.reps
     opt.optim.test_photo = old_photo
     torch.cuda.synchronize()
     model.evaluate_test_time_photometric_optim(opt, Opt(dict(var)))  # warm-up
@@ -75,7 +86,9 @@ def main():
                         "rays_per_s": rays / t_render, "launch": "hipGraph replay" if args.graph else "eager", "Msamples_per_s": rays * g.nerf.n_samples / t_render / 1e6},
         "test_time_optim": {"rays_per_iter": int(v.rgb.shape[1]), "ms_per_iter": t_opt * 1e3,
                             "iters": args.test_iters, "scene": args.scene,
-                            "launch": dict(model._test_optim_graph.stats) if args.graph else "eager", "backward": "pose-only (no factor / weight gradients)"}}))
+                            "launch": dict(model._test_optim_graph.stats) if args.graph else "eager", "backward": "pose-only (no factor / weight gradients)",
+                            "path": "staged kernels + autograd" if not args.fused else "single launch: render + loss + backward "
+                                                                                    "to the rays (jt_pose_fused)"}}))
 
 
 if __name__ == "__main__":
