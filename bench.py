@@ -48,10 +48,14 @@ def parse():
     ap.add_argument("--n-voxel-final", type=int, default=0,
                     help="override train_schedule.n_voxel_final (e.g. 27000000 = the 300^3 of the parent yaml "
                          "options/tensorf_blender_VM.yaml that BASELINE.json's configs[1] text quotes)")
-    ap.add_argument("--scene", default="random", choices=["random", "blobs"],
+    ap.add_argument("--scene", default="random", choices=["random", "blobs", "fitted"],
                     help="random = the reference's random-init factors (every in-box sample is shaded: the worst case "
                          "and the default); blobs = a few opaque Gaussian blobs baked into the density factors "
-                         "(SURVEY 8(d) structured scene: a few per cent of the samples shaded, like a trained field)")
+                         "(SURVEY 8(d) structured scene: a few per cent of the samples shaded, like a trained field), random "
+                         "appearance, noise images; fitted = the self-consistent scene: the model HOLDS the ground-truth "
+                         "field (blobs + smooth textured appearance, synthetic.make_gt_scene resampled onto the model's grid) "
+                         "and is supervised with images rendered from it at the ground-truth cameras -- the sharp last stage "
+                         "of a run that has converged")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--probe-only", action="store_true",
@@ -310,9 +314,9 @@ ATOMIC_SEGMENTS_PER_S = 20.9e9   # measured: tools/atomic_rate.hip on MI355X (pr
 def pmc_traffic_instep(roof, hidden=None):
     """HBM-side bytes per launch of k_shade_bwd from the committed rocprofv3 --pmc passes over THIS command (separate
     FETCH_SIZE / WRITE_SIZE runs of `bench.py --no-cpu-baseline --no-probe --no-torch-baseline --no-extras`,
-    tools/pmc_traffic.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), per shaded sample, scaled
+    tools/profile_cmd.sh -> tools/pmc_traffic_instep.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), per shaded sample, scaled
     by the samples of the live launches; null when no in-step file is committed."""
-    path = os.path.join(ROOT, "profiles", "round2_pmc_traffic_instep.json")
+    path = os.path.join(ROOT, "profiles", "round3_default_pmc_traffic.json")
     try:
         rec = json.load(open(path))
         k = rec["k_shade_bwd"]
@@ -320,7 +324,7 @@ def pmc_traffic_instep(roof, hidden=None):
         if abs(n - rec["process_samples_per_launch"]) > 0.1 * n:
             return {"traffic": None}  # another workload than the one the counters were collected on
         out = {"traffic": k["hbm_bytes_per_sample"] * n, "traffic_unit": "bytes/launch",
-               "traffic_source": "profiles/round2_pmc_traffic_instep.json", "traffic_detail": rec}
+               "traffic_source": "profiles/round3_default_pmc_traffic.json", "traffic_detail": rec}
         if hidden:
             # the second bound of a scatter kernel: the chip retires ~20.9 G float-atomic 64-byte segments per second
             # whatever the access pattern (tools/atomic_rate.hip, profiles/round2_atomic_rate.txt).  Segments of a launch =
@@ -405,6 +409,9 @@ def run_extras():
              ("llff_final_grid_it30000_hipgraph", ["--config", "bat_llff_VM_MLP", "--it", "30000"], {"JT_GRAPH": "1"}),
              # the N = 1 point of the strong-scaling curve: the WHOLE 62 500-ray iteration of BASELINE.json configs[3]
              ("configs3_single_gpu", ["--total-rays", "65536", "--steps", "8", "--warmup", "2"], {}),
+             # the sharp last stage of a CONVERGED run on the self-consistent scene (few per cent of the samples shaded)
+             ("fitted_scene_eager", ["--scene", "fitted"], {}),
+             ("fitted_scene_hipgraph", ["--scene", "fitted"], {"JT_GRAPH": "1"}),
              ("blobs_eager", ["--scene", "blobs"], {}),
              ("blobs_hipgraph", ["--scene", "blobs"], {"JT_GRAPH": "1"})]
     out = {}
@@ -417,6 +424,9 @@ def run_extras():
             j = json.loads(line)
             out[name] = {"rays_per_s": j["value"], "ms_per_step": j["ms_per_step"], "workload": j["config"]["workload"],
                          "launch": j["config"]["launch"]}
+            for k in ("shaded_samples_per_iter", "nominal_samples_per_iter", "shaded_over_nominal"):
+                if k in j["config"]:
+                    out[name][k] = j["config"][k]
             if "roofline" in j and "launch_ms" in j["roofline"]:
                 out[name]["k_shade_bwd_ms"] = j["roofline"]["launch_ms"]
                 out[name]["k_shade_bwd_frac"] = j["roofline"]["frac"]
@@ -469,6 +479,15 @@ def main():
         from joint_tensorf_amd.synthetic import bake_blobs
         bake_blobs(model.graph.nerf.tensorf, n_blobs=12, seed=0)
     var_all = make_views(opt, n_views, seed=0, device=dev)
+    if args.scene == "fitted":
+        from joint_tensorf_amd.synthetic import gt_scene_for, load_scene_into, render_views
+        g_opt, g_graph = gt_scene_for(opt, seed=0)
+        with torch.no_grad():
+            load_scene_into(model.graph.nerf.tensorf, g_graph.nerf.tensorf)
+            var_all.image = render_views(g_opt, g_graph, var_all)   # pictures of THE scene from the ground-truth cameras
+            if hasattr(model.graph, "pose_noise"):   # converged: the cameras have been recovered (tests/test_gpu_convergence.py)
+                model.graph.pose_noise.copy_(torch.eye(3, 4, device=dev).expand_as(model.graph.pose_noise))
+        torch.cuda.empty_cache()
     if world > 1 or FORCE_DIST:
         # the scene gradients are all-reduced inside the renderer's backward, the pose gradients behind it; the host
         # draws (lattice offsets, blur scale) come from NumPy's global generator, seeded identically on every rank
@@ -640,9 +659,12 @@ def main():
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (%s, random-init appearance factors / MLP, random images, 100 cameras on a radius-4 "
-                    "sphere)" % ("random-init density factors" if args.scene == "random"
-                                 else "12 opaque Gaussian blobs baked into the density factors"),
+            "data": ("synthetic (%s, random-init appearance factors / MLP, random images, 100 cameras on a radius-4 "
+                     "sphere)" % ("random-init density factors" if args.scene == "random"
+                                  else "12 opaque Gaussian blobs baked into the density factors")) if args.scene != "fitted" else
+                    "synthetic, self-consistent: the model holds the ground-truth field (12 opaque blobs, smooth textured "
+                    "appearance) and is supervised with images rendered from it at the ground-truth cameras (100 on a "
+                    "radius-4 sphere), cameras at their recovered (ground-truth) poses",
             "config": {
                 "workload": "%s stage %d: grid %s, S=%d samples/ray, %d rays/iter/GPU (%s lattice over %d views), "
                             "blur %s, full train step (fwd+loss+bwd+Adam+pose Adam)"
@@ -697,6 +719,10 @@ def main():
                     # really shaded (in the box and above the weight threshold), read from the launches' device-side counts
                     out["config"]["Msamples_per_s_shaded"] = (ins["bwd"]["samples_per_launch"] * ins["bwd"]["launches"]
                                                               * world / dt / 1e6)
+                    out["config"]["shaded_samples_per_iter"] = ins["bwd"]["samples_per_launch"] * ins["bwd"]["launches"] / args.steps
+                    out["config"]["nominal_samples_per_iter"] = rays_all / args.steps / world * S
+                    out["config"]["shaded_over_nominal"] = (out["config"]["shaded_samples_per_iter"]
+                                                            / max(out["config"]["nominal_samples_per_iter"], 1.0))
                     # every k_shade_bwd launch of the process (priming and warm-up included): what a profiler sees
                     alls = [int(off[-1]) for k, a, b, off in all_timers if k == "bwd"]
                     out["roofline"]["process_launches"] = len(alls)

@@ -379,7 +379,11 @@ class RenderRays(torch.autograd.Function):
             # 86 GB for the all-shaded random-init field, a few GB for a trained one).  Such an iteration takes 100 ms:
             # the synchronisation is not what it waits for.  Smaller batches (every training config) keep the
             # sync-free worst-case sizing.
-            n = cap = max(32, (int(offset[R].item()) + 31) // 32 * 32)
+            # (rounded up to whole 2^22-sample backward chunks: the sizes of consecutive iterations repeat, so the caching
+            #  allocator hands the same multi-GB blocks back instead of going to hipMalloc / hipFree every iteration --
+            #  measured: 814 ms per 62 500-ray step with exact sizes, 100 ms with repeating ones)
+            gran = int(lib.jt_shade_chunk_entries())
+            n = cap = min(R * S, max(gran, (int(offset[R].item()) + gran - 1) // gran * gran))
         cap_alloc = max(cap, 1)
         eray = torch.empty(cap_alloc, device=dev, dtype=torch.int32)
         esmp = torch.empty(cap_alloc, device=dev, dtype=torch.int32)

@@ -97,15 +97,27 @@ def _unpinned_case(name, opt, model, var, **kw):
     assert rep["values"]["rgb"] <= TOL_VAL and rep["values"]["opacity"] <= TOL_VAL, rep["values"]
     np.testing.assert_allclose(hip["total"], ref["total"], rtol=2e-5)
     assert abs(rep["shaded"] - rep["shaded_hip"]) <= MAX_FLIP_FRACTION * max(rep["shaded"], 1) + 2
-    for k, (mx, l2) in ((k, v[:2]) for k, v in rep["grads"].items()):
-        assert rep["bulk"][k] <= TOL_BULK, (k, rep["bulk"][k])
-        assert l2 <= TOL_L2_UNPINNED, (k, l2)
-        assert mx <= TOL_MAX_UNPINNED, (k, mx)
+    bad = [k for k, v in rep["grads"].items() if rep["bulk"][k] > TOL_BULK or v[1] > TOL_L2_UNPINNED]
+    if bad:
+        # as in the pinned cases: two fp32 evaluations cannot agree better than either agrees with the exact result.  The
+        # tensors that miss the bounds (seen: the density-line gradients of the 771 x 859 x 771 grid, 10^4 signed float
+        # sums per element on BOTH sides) are measured against the un-pinned fp64 oracle, and the product path must be as
+        # close to it as the fp32 oracle is (within 2x), in the bulk and in l2
+        truth = U.run_oracle(opt, model, var, hip["ctx"], dtype=torch.float64, pin_mask=False)
+        for k in bad:
+            h, a, t = hip["grads"][k], ref["grads"][k], truth["grads"][k]
+            eh, ea = (U.rel_quantile(h, t), U.rel_l2(h, t)), (U.rel_quantile(a, t), U.rel_l2(a, t))
+            print("   grad %-18s vs un-pinned fp64 oracle (99.9 %% quantile / l2): product path %.2e / %.2e, fp32 oracle "
+                  "%.2e / %.2e" % (k, *eh, *ea))
+            rep["grads"][k] += [*eh, *ea]
+            assert eh[0] <= 2 * ea[0] + 1e-6 and eh[1] <= 2 * ea[1] + 1e-6, (k, eh, ea)
+    for k, v in rep["grads"].items():
+        assert v[0] <= TOL_MAX_UNPINNED, (k, v[0])
     U.record(rep)
     return rep
 
 
-TOL_BULK = 1e-4           # 99.9 % quantile of |diff| / max |ref|, un-pinned
+TOL_BULK = 1e-4           # 99.9 % quantile of |diff| / max |ref|, un-pinned (measured: <= 4.6e-5 on the Blender grid)
 TOL_L2_UNPINNED = 2e-3    # relative l2, un-pinned (a flipped unit is a handful of texels)
 TOL_MAX_UNPINNED = 5e-2   # sanity bound on the outliers
 
@@ -127,7 +139,10 @@ def test_llff_final_grid_unpinned():
 def test_blender_middle_stages_blurred(stage, grid, S):
     """(vii) the three middle grid stages of bat_blender_VM at their real size, factor blur ON (the schedule's sigma at the
     first iteration of the stage, random density scale 0.6): 101^3 / S = 349, 159^3 / 550, 252^3 / 872, ~2 000 rays."""
-    opt, model, var, it0 = U.build("bat_blender_VM", stage=stage, density_scale=25.0)
+    # (an odd iteration: on even ones before 8 000 the loss is the edge-weighted one, which the sliced oracle loop of
+    #  fullsize_util does not restate -- tests/test_gpu_trajectory.py and the fixtures cover it)
+    first = {1: 2001, 2: 6001, 3: 7501}[stage]
+    opt, model, var, it0 = U.build("bat_blender_VM", stage=stage, it=first, density_scale=25.0)
     tf = model.graph.nerf.tensorf
     assert tf.gridSize.tolist() == [grid] * 3 and model.graph.nerf.n_samples == S
     assert model.graph.resolve_blur(opt, "vis")[2] is not None
