@@ -38,10 +38,21 @@ def make_views(opt, n_views, seed=0, device="cpu", with_images=True):
             poses.append(look_at(eye))
         f = 0.5 * W / math.tan(0.5 * 0.69)  # camera_angle_x ~ 0.69 rad (data/blender.py:29)
     else:
+        # forward-facing capture (data/llff.py:43-97 after its recentering): cameras near the origin looking along +z.
+        # opt.data.llff_baseline (default 0.3) = width of the square they are spread over; with opt.data.llff_focus (a depth)
+        # set, every camera is turned towards the point (0, 0, focus) as a hand-held capture is -- otherwise no rotation
+        base = float(opt.data.get("llff_baseline", None) or 0.3)
+        focus = opt.data.get("llff_focus", None)
         for i in range(n_views):
-            P = np.eye(3, 4, dtype=np.float32)
-            P[:, 3] = -np.array([0.3 * (rng.rand() - 0.5), 0.3 * (rng.rand() - 0.5), 0.05 * (rng.rand() - 0.5)])
-            poses.append(P)
+            eye = np.array([base * (rng.rand() - 0.5), base * (rng.rand() - 0.5), base / 6 * (rng.rand() - 0.5)])
+            R = np.eye(3)
+            if focus:
+                fwd = np.array([0.0, 0.0, float(focus)]) - eye
+                fwd /= np.linalg.norm(fwd)
+                right = np.cross(np.array([0.0, 1.0, 0.0]), fwd)
+                right /= np.linalg.norm(right)
+                R = np.stack([right, np.cross(fwd, right), fwd], 0)
+            poses.append(np.concatenate([R, (-R @ eye)[:, None]], 1).astype(np.float32))
         f = 0.8 * W
     pose = torch.tensor(np.stack(poses))
     intr = torch.tensor([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]], dtype=torch.float32)[None].repeat(n_views, 1, 1)
@@ -55,7 +66,7 @@ def make_views(opt, n_views, seed=0, device="cpu", with_images=True):
 
 
 @torch.no_grad()
-def bake_blobs(tensorf, n_blobs=12, seed=0, amplitude=60.0, radius=(0.12, 0.3), background=-12.0):
+def bake_blobs(tensorf, n_blobs=12, seed=0, amplitude=60.0, radius=(0.12, 0.3), background=-12.0, z_range=(0.25, 0.75)):
     """Overwrite the DENSITY factors with a few opaque Gaussian blobs (the "structured" scene).
 
     exp(-|p - c|^2 / 2 s^2) factorises into an (x, y) plane times a z line, i.e. one blob is exactly one rank-1
@@ -77,7 +88,9 @@ def bake_blobs(tensorf, n_blobs=12, seed=0, amplitude=60.0, radius=(0.12, 0.3), 
     Y = lo[1] + (hi[1] - lo[1]) * torch.linspace(0, 1, H, device=dev)
     Z = lo[2] + (hi[2] - lo[2]) * torch.linspace(0, 1, L, device=dev)
     for k in range(n_blobs):
-        c = (lo + (hi - lo) * torch.tensor(0.25 + 0.5 * rng.rand(3), device=dev, dtype=torch.float32))
+        frac = 0.25 + 0.5 * rng.rand(3)
+        frac[2] = z_range[0] + (z_range[1] - z_range[0]) * (frac[2] - 0.25) / 0.5   # blob centres along z (fractions of the box)
+        c = (lo + (hi - lo) * torch.tensor(frac, device=dev, dtype=torch.float32))
         s = float(radius[0] + (radius[1] - radius[0]) * rng.rand())
         plane[0, k] = amplitude * torch.exp(-((X[None, :] - c[0]) ** 2 + (Y[:, None] - c[1]) ** 2) / (2 * s * s))
         line[0, k, :, 0] = torch.exp(-((Z - c[2]) ** 2) / (2 * s * s))
@@ -150,9 +163,14 @@ def make_gt_scene(opt, seed=0, res=None, n_blobs=12):
             torch.cuda.set_rng_state(dev_state, torch.device(opt.device))
     tf = graph.nerf.tensorf
     ndc = bool(opt.camera.ndc)
-    n = bake_blobs(tf, n_blobs=min(n_blobs, tf.density_plane[0].shape[1] - (2 if ndc else 1)), seed=seed)
     if ndc:
-        bake_wall(tf)
+        # NDC depth 1 - 2 n / z: real forward-facing content sits at z_ndc in [0.2, 0.9] (2.5 ... 20 near-plane distances);
+        # the box's z runs from -2 to 1, so that is the far 27 % of it; a textured wall closes the scene behind the blobs
+        n = bake_blobs(tf, n_blobs=min(n_blobs, tf.density_plane[0].shape[1] - 2), seed=seed, radius=(0.08, 0.2),
+                       z_range=tuple(opt.data.get("gt_z_range", None) or (0.74, 0.93)))
+        bake_wall(tf, axis_frac=float(opt.data.get("gt_wall", None) or 0.975), thickness=0.012)
+    else:
+        n = bake_blobs(tf, n_blobs=min(n_blobs, tf.density_plane[0].shape[1] - 1), seed=seed)
     bake_appearance(tf, seed=seed)
     graph.nerf.set_progress(1.0)
     graph.eval()

@@ -23,6 +23,10 @@ def build(args, device="cuda:0"):
     from joint_tensorf_amd.model import bat_hip
     from joint_tensorf_amd.options import compress_schedule, make_options
     over = dict(data=dict(synthetic="rendered", num_views=args.views, num_test_views=args.test_views, gt_res=args.gt_res))
+    if getattr(args, "llff_baseline", 0):
+        over["data"]["llff_baseline"] = args.llff_baseline
+    if getattr(args, "llff_focus", 0):
+        over["data"]["llff_focus"] = args.llff_focus
     opt = make_options(args.config, device=device, **over)
     if args.image_size:
         h, w = opt.data.image_size
@@ -75,6 +79,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--graph", action="store_true")
     ap.add_argument("--report-every", type=int, default=0)
+    ap.add_argument("--llff-baseline", type=float, default=0.0)
+    ap.add_argument("--llff-focus", type=float, default=0.0)
     args = ap.parse_args()
     torch.cuda.set_device(0)
     opt, model = build(args)
