@@ -20,6 +20,10 @@
 
 #include "jt_shade_core.h"
 
+#ifndef JT_BF16X3_DEFAULT
+#define JT_BF16X3_DEFAULT 3
+#endif
+
 namespace jt {
 
 // REC = 1 (training): besides rgb the kernel leaves the tile-blocked records of the layer inputs (see BwdCfg) so
@@ -76,6 +80,92 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
       if (REC == 1) rec_store<C::MT>(rt, B::R_H1, h1.v, j, h, on);
     }
     Hidden<C> h2 = layer2<C>(smem, h1, j, h);
+    relu_<C>(h2);
+    if (REC) {
+      unsigned mask2 = 0u;
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mask2 |= (h2.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
+      if (on) rec_st(rec_at(rt, B::R_MASK + 2, 4u * (unsigned)j + 128u * (unsigned)h), __uint_as_float(mask2));
+      if (REC == 1) rec_store<C::MT>(rt, B::R_MID + HOFF, h2.v, j, h, on);
+      if (REC == 1 && C::KIND != JT_MLP_FEA) {
+        float pe[12];
+        view_pe(vd, pm, pe);
+        if (on && h == 0) {
+#pragma unroll
+          for (int k = 0; k < 12; ++k) rec_st(rec_at(rt, B::R_MID + k, 4u * (unsigned)j), pe[k]);
+        }
+      }
+    }
+    float o[3];
+    layer3<C>(smem, h2, vd, pm, h, o);
+    if (on && h == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rgb_s[(size_t)e * 3 + c] = 1.f / (1.f + expf(-o[c]));
+    }
+  }
+}
+
+
+// The same forward with the three matrix stages on the bf16 matrix cores at fp32-level accuracy (jt_shade_core.h, "bf16x3"):
+// one workgroup of eight waves per CU around a 114 KB pre-split weight image.  Selected by JT_BF16X3 (launch_shade_fwd_t).
+template <class C, int REC>
+__global__ __launch_bounds__(JT_B16_THREADS) void k_shade_fwd_b16(Dev D, MlpDev M, PeMask pm, const float* __restrict__ rays_o,
+                                                      const float* __restrict__ rays_d,
+                                                      const float* __restrict__ jitter,
+                                                      const float* __restrict__ zvals,
+                                                      const float* __restrict__ tmin,
+                                                      const int* __restrict__ offset, int R,
+                                                      const int* __restrict__ eray, const int* __restrict__ esmp,
+                                                      const float* __restrict__ vdir, float* __restrict__ rgb_s,
+                                                      float* __restrict__ rec, int cap) {
+  typedef BwdCfg<C> B;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  typedef B16Cfg<C> Q;
+  const uint4* img = reinterpret_cast<const uint4*>(smem_raw);
+  const float* tail = reinterpret_cast<const float*>(smem_raw + (size_t)Q::V_END * 16);
+  const float* smem = tail - C::O_W3;  // layer3 reads W3 / b3 at their fp32-image offsets: the tail keeps that relative layout
+  const int total = min(offset[R], cap);
+  const int ntiles = (total + 31) >> 5;
+  constexpr int NW = JT_B16_THREADS / 64;
+  if ((int)blockIdx.x * NW >= ntiles) return;
+  load_weights_lds_b16<C>(smem_raw, M);
+  __syncthreads();
+  // (the wave index as a scalar: everything derived from it -- tile, record block -- stays in scalar registers)
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j_ = lane & 31, h_ = lane >> 5;
+  constexpr int HOFF = (C::KIND == JT_MLP_FEA) ? 0 : 12;
+  for (int tile = blockIdx.x * NW + wv; tile < ntiles; tile += gridDim.x * NW) {
+    int j = j_, h = h_;  // see k_shade_bwd: keeps per-lane address math from being hoisted out of the loop
+    asm volatile("" : "+v"(j), "+v"(h));
+    const int e = tile * 32 + j;
+    const bool on = e < total;
+    const int ee = on ? e : total - 1;
+    float* rt = REC ? rec + (size_t)tile * B::REC_FLOATS * 32 : nullptr;
+    EntryGeom g = entry_geom(D, rays_o, rays_d, jitter, zvals, tmin, eray, esmp, ee);
+    float vd[3] = {vdir[(size_t)ee * 3], vdir[(size_t)ee * 3 + 1], vdir[(size_t)ee * 3 + 2]};
+    if (REC && on && h == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (REC == 1) rec_st(rec_at(rt, B::R_VD + c, 4u * (unsigned)j), vd[c]);
+        rec_st(rec_at(rt, B::R_GEO + c, 4u * (unsigned)j), g.n[c]);
+      }
+    }
+    f32x16 facc = gather_basis_b16<C, REC == 1>(D, img, g.n, j, h, lane, rt, on);
+    if (REC) rec_store<1>(rt, B::R_F, &facc, j, h, on);
+    Hidden<C> h1 = layer1_b16<C>(img, tail, facc, vd, pm, h, lane);
+    relu_<C>(h1);
+    if (REC) {
+      unsigned mask1 = 0u;
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mask1 |= (h1.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
+      if (on) rec_st(rec_at(rt, B::R_MASK, 4u * (unsigned)j + 128u * (unsigned)h), __uint_as_float(mask1));
+      if (REC == 1) rec_store<C::MT>(rt, B::R_H1, h1.v, j, h, on);
+    }
+    Hidden<C> h2 = layer2_b16<C>(img, tail, h1, h, lane);
     relu_<C>(h2);
     if (REC) {
       unsigned mask2 = 0u;
@@ -437,6 +527,37 @@ __device__ inline void mask_tail(float v[16], int h, int nl) {
   for (int q = 0; q < 16; ++q) v[q] = (16 * h + q < nl) ? v[q] : 0.f;
 }
 
+// epilogue of the weight-gradient GEMMs: sum the four waves' tiles through LDS and park the block's partial result in its
+// slab (plain 256-byte stores).  Many blocks atomically adding into the same few-KB weight matrix would run at a fraction of
+// the float-atomic rate, so the cross-block sum is a second, deterministic pass (k_wgrad_reduce).
+template <int MT, int NT>
+__device__ inline void wgrad_epilogue(f32x16 (*acc)[NT], const float* asum, float (*s_red)[16][64], float* slab, int lane,
+                                      int wv, int m, int h) {
+  float* my = slab + (size_t)blockIdx.x * (MT * NT * 1024 + MT * 32);
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_red[wv][r][lane] = acc[a][b][r];
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = wv * 4 + rr;
+        my[(a * NT + b) * 1024 + r * 64 + lane] =
+            s_red[0][r][lane] + s_red[1][r][lane] + s_red[2][r][lane] + s_red[3][r][lane];
+      }
+    }
+    __syncthreads();
+    s_red[wv][0][lane] = asum[a];
+    __syncthreads();
+    if (wv == 0 && h == 0)
+      my[MT * NT * 1024 + a * 32 + m] = s_red[0][0][m] + s_red[0][0][m + 32] + s_red[1][0][m] + s_red[1][0][m + 32] +
+                                       s_red[2][0][m] + s_red[2][0][m + 32] + s_red[3][0][m] + s_red[3][0][m + 32];
+  }
+}
+
 template <int MT, int NT, int XF>
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ rec, int a_row0, int M, int b_row0, int N,
                                                int f_row0, int vd_row0, int rec_rows, PeMask pm, int APP,
@@ -566,33 +687,139 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ rec, in
         for (int q = 0; q < 16; ++q) av[a][q] = an[a][q];
     }
   }
-  // epilogue: sum the four waves' tiles through LDS and park the block's partial result in its slab
-  // (plain 256-byte stores).  Many blocks atomically adding into the same few-KB weight matrix would run at
-  // a fraction of the float-atomic rate, so the cross-block sum is a second, deterministic pass
-  // (k_wgrad_reduce).
-  float* my = slab + (size_t)blockIdx.x * (MT * NT * 1024 + MT * 32);
+  wgrad_epilogue<MT, NT>(acc, asum, s_red, slab, lane, wv, m, h);
+}
+
+// The same skinny GEMM on the bf16 matrix cores at fp32-level accuracy (jt_shade_core.h, "bf16x3"): both operands are
+// per-sample data here, so both are split in registers -- (MT + NT) x 16 values per lane and tile -- and a tile's 32 samples
+// are two 16-deep K steps (lane half h feeds samples 16 h + 8 s .. + 7 to step s: the contraction order is free as long as
+// A and B agree).  Per (M tile, N tile) and tile of samples: 12 MFMAs of 32 cycles instead of 16 of 64.
+template <int MT, int NT, int XF>
+__global__ __launch_bounds__(256) void k_wgrad_b16(const float* __restrict__ rec, int a_row0, int M, int b_row0, int N,
+                                                   int f_row0, int vd_row0, int rec_rows, PeMask pm, int APP,
+                                                   const int* __restrict__ offset, int R, int cap, int chunk_start,
+                                                   int chunk_cap, float* __restrict__ slab) {
+  __shared__ float s_red[4][16][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int m = lane & 31, h = lane >> 5;
+  const int total = min(offset[R], cap);
+  const int n = min(total - chunk_start, chunk_cap);
+  if (n <= 0) return;
+  const int ntiles = (n + 31) >> 5;
+  const int nwaves = gridDim.x * 4;
+  const int per = (ntiles + nwaves - 1) / nwaves;
+  const int w = blockIdx.x * 4 + wv;
+  const int t_begin = min(w * per, ntiles), t_end = min(t_begin + per, ntiles);
+  f32x16 acc[MT][NT];
+  float asum[MT];
 #pragma unroll
   for (int a = 0; a < MT; ++a) {
+    asum[a] = 0.f;
 #pragma unroll
-    for (int b = 0; b < NT; ++b) {
-      __syncthreads();
+    for (int b = 0; b < NT; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s_red[wv][r][lane] = acc[a][b][r];
-      __syncthreads();
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int r = wv * 4 + rr;
-        my[(a * NT + b) * 1024 + r * 64 + lane] =
-            s_red[0][r][lane] + s_red[1][r][lane] + s_red[2][r][lane] + s_red[3][r][lane];
-      }
-    }
-    __syncthreads();
-    s_red[wv][0][lane] = asum[a];
-    __syncthreads();
-    if (wv == 0 && h == 0)
-      my[MT * NT * 1024 + a * 32 + m] = s_red[0][0][m] + s_red[0][0][m + 32] + s_red[1][0][m] + s_red[1][0][m + 32] +
-                                       s_red[2][0][m] + s_red[2][0][m + 32] + s_red[3][0][m] + s_red[3][0][m + 32];
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   }
+  const size_t tstride = (size_t)rec_rows * 32;
+  auto loadA = [&](int t, float (*dst)[16]) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+      const int c = a * 32 + m;
+      load_row_half(rec + (size_t)t * tstride + (size_t)(a_row0 + min(c, M - 1)) * 32, c < M, h, dst[a]);
+    }
+  };
+  // A of the current tile: masked, summed for the bias gradient, split once for all N tiles
+  auto prepA = [&](float (*av)[16], int nl, B3 (*a3)[2]) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+      if (nl < 32) mask_tail(av[a], h, nl);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) asum[a] += av[a][q];
+      a3[a][0] = split8(av[a]);
+      a3[a][1] = split8(av[a] + 8);
+    }
+  };
+  float av[MT][16], an[MT][16];
+  B3 a3[MT][2];
+  if (XF == 0) {
+    auto loadB = [&](int t, int b, float* dst) {
+      const int c = b * 32 + m;
+      load_row_half(rec + (size_t)t * tstride + (size_t)(b_row0 + min(c, N - 1)) * 32, c < N, h, dst);
+    };
+    float bv[16], bn[16];
+    if (t_begin < t_end) {
+      loadA(t_begin, av);
+      loadB(t_begin, 0, bv);
+    }
+    for (int t = t_begin; t < t_end; ++t) {
+      const int nl = min(32, n - t * 32);
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+        if (b + 1 < NT) {
+          loadB(t, b + 1, bn);
+        } else if (t + 1 < t_end) {
+          loadA(t + 1, an);
+          loadB(t + 1, 0, bn);
+        }
+        if (b == 0) prepA(av, nl, a3);
+        if (nl < 32) mask_tail(bv, h, nl);  // never-written record slots may hold anything, 0 * NaN is NaN
+        const B3 b0 = split8(bv), b1 = split8(bv + 8);
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+          acc[a][b] = mfma6(a3[a][0], b0, acc[a][b]);
+          acc[a][b] = mfma6(a3[a][1], b1, acc[a][b]);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bv[q] = bn[q];
+      }
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) av[a][q] = an[a][q];
+    }
+  } else {
+    const bool feat = m < APP, view = (XF == 1) && !feat && (m < APP + 3);
+    const int srow = feat ? f_row0 + m : vd_row0 + (view ? m - APP : 0);
+    const float m0 = view ? pm.v0 : pm.f0, m1 = view ? pm.v1 : pm.f1;
+    const bool live = feat || view;
+    float x[16], xn[16];
+    if (t_begin < t_end) {
+      loadA(t_begin, av);
+      load_row_half(rec + (size_t)t_begin * tstride + (size_t)srow * 32, live, h, x);
+    }
+    for (int t = t_begin; t < t_end; ++t) {
+      const int nl = min(32, n - t * 32);
+      if (t + 1 < t_end) {
+        loadA(t + 1, an);
+        load_row_half(rec + (size_t)(t + 1) * tstride + (size_t)srow * 32, live, h, xn);
+      }
+      if (nl < 32) mask_tail(x, h, nl);  // never-written record slots may hold anything, 0 * NaN is NaN
+      prepA(av, nl, a3);
+      float sn[16], cs[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sincos_grad(x[q], &sn[q], &cs[q]);
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+        float bv[16];
+        // the A operand is zero past nl, so the (finite) encoding of a padding sample never contributes
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bv[q] = live ? pe_pick<XF>(b, x[q], sn[q], cs[q], m0, m1) : 0.f;
+        const B3 b0 = split8(bv), b1 = split8(bv + 8);
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+          acc[a][b] = mfma6(a3[a][0], b0, acc[a][b]);
+          acc[a][b] = mfma6(a3[a][1], b1, acc[a][b]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) x[q] = xn[q];
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) av[a][q] = an[a][q];
+    }
+  }
+  wgrad_epilogue<MT, NT>(acc, asum, s_red, slab, lane, wv, m, h);
 }
 
 // dW[i][k] += sum over the live chunks' block slabs; grid.y slab groups, a few atomics per element
@@ -640,6 +867,14 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 }  // namespace jt
 
 using namespace jt;
+
+// which stages run on the bf16 matrix cores with three-piece operands (fp32-level accuracy, jt_shade_core.h): bit 0 the
+// forward chain (k_shade_fwd_b16), bit 1 the weight-gradient GEMMs (k_wgrad_b16).  JT_BF16X3 (read once) overrides the build
+// default; 0 = everything on the fp32 matrix cores.
+static int bf16x3_mode() {
+  static const int mode = [] { const char* e = getenv("JT_BF16X3"); return e ? atoi(e) : JT_BF16X3_DEFAULT; }();
+  return mode;
+}
 
 typedef ShadeCfg<48, 27, 64, JT_MLP_FEA> CfgBlender;     // bat_blender_VM: VM-48, MLP_Fea 150->64->64->3
 typedef ShadeCfg<20, 20, 32, JT_MLP_WEAKVIEW> CfgLlff;   // bat_llff_VM_MLP: VM-20, WeakView 100->32->32, 44->3
@@ -724,10 +959,22 @@ static int launch_shade_fwd_t(const Dev& D, const MlpDev& M, const PeMask& pm, c
                               const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
                               const int32_t* offset, int R, const int32_t* eray, const int32_t* esmp,
                               const float* vdir, float* rgb_s, float* rec, int cap, hipStream_t st) {
+  long tiles = ((long)cap + 31) / 32;
+  // JT_BF16X3 (read once): the forward's matrix stages as six bf16 MFMAs per fp32 product sum (jt_shade_core.h)
+  if (bf16x3_mode() & 1) {
+    const size_t lds16 = B16Cfg<C>::LDS_BYTES;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_fwd_b16<C, REC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+    constexpr int NW = JT_B16_THREADS / 64;
+    int blocks16 = (int)std::min<long>((tiles + NW - 1) / NW, 256);
+    hipLaunchKernelGGL((k_shade_fwd_b16<C, REC>), dim3(blocks16), dim3(JT_B16_THREADS), lds16, st, D, M, pm, rays_o, rays_d, jitter,
+                       zvals, tmin, offset, R, eray, esmp, vdir, rgb_s, rec, cap);
+    JT_LAUNCH_CHECK();
+    return JT_OK;
+  }
   const size_t lds = C::LDS_FLOATS * sizeof(float);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_fwd<C, REC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  long tiles = ((long)cap + 31) / 32;
   int blocks = (int)std::min<long>((tiles + 3) / 4, 512);
   hipLaunchKernelGGL((k_shade_fwd<C, REC>), dim3(blocks), dim3(256), lds, st, D, M, pm, rays_o, rays_d, jitter, zvals,
                      tmin, offset, R, eray, esmp, vdir, rgb_s, rec, cap);
@@ -839,18 +1086,25 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     float* s2 = s3 + W::P3 * nb;
     float* s1 = s2 + W::P2 * nb;
     float* sb = s1 + W::P1 * nb;
-    hipLaunchKernelGGL((k_wgrad<1, NT3, 0>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_GO, 3, B::R_MID, C::IN3, B::R_F,
-                       B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s3);
-    JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad<C::MT, C::MT, 0>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_G2, C::HID, B::R_H1, C::HID,
-                       B::R_F, B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s2);
-    JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad<C::MT, NT1, XF1>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_G1, C::HID, B::R_F, C::IN1,
-                       B::R_F, B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s1);
-    JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad<1, NTB, 0>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_GF, C::APP, B::R_PROD, C::NC,
-                       B::R_F, B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, sb);
-    JT_LAUNCH_CHECK();
+#define JT_WGRAD_LAUNCH(KERNEL)                                                                                          \
+  hipLaunchKernelGGL((KERNEL<1, NT3, 0>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_GO, 3, B::R_MID, C::IN3, B::R_F,      \
+                     B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s3);                                          \
+  JT_LAUNCH_CHECK();                                                                                                     \
+  hipLaunchKernelGGL((KERNEL<C::MT, C::MT, 0>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_G2, C::HID, B::R_H1, C::HID,    \
+                     B::R_F, B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s2);                                  \
+  JT_LAUNCH_CHECK();                                                                                                     \
+  hipLaunchKernelGGL((KERNEL<C::MT, NT1, XF1>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_G1, C::HID, B::R_F, C::IN1,     \
+                     B::R_F, B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s1);                                  \
+  JT_LAUNCH_CHECK();                                                                                                     \
+  hipLaunchKernelGGL((KERNEL<1, NTB, 0>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_GF, C::APP, B::R_PROD, C::NC, B::R_F, \
+                     B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, sb);                                          \
+  JT_LAUNCH_CHECK();
+    if (bf16x3_mode() & 2) {
+      JT_WGRAD_LAUNCH(k_wgrad_b16)
+    } else {
+      JT_WGRAD_LAUNCH(k_wgrad)
+    }
+#undef JT_WGRAD_LAUNCH
     return JT_OK;
   };
   for (int ci = 0; ci < nchunks; ++ci) {

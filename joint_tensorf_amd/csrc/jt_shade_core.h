@@ -13,6 +13,9 @@ namespace jt {
 #define JT_REC_NT 1
 #endif
 __device__ inline void rec_st(float* p, float v) {
+#if JT_ABL_NOST
+  return;
+#endif
 #if JT_REC_NT
   __builtin_nontemporal_store(v, p);
 #else
@@ -27,13 +30,21 @@ __device__ inline float rec_ld(const float* p) {
 #endif
 }
 // record slot of tile block `rt` (uniform: it depends on the wave, not on the lane), row `row` (a constant at every use),
-// lane part `lane_bytes` (4 * sample [+ 512 * lane half for rows rowmap(r, 0) + 4 h]): scalar base + 32-bit lane offset,
-// the form global loads / stores address without 64-bit vector arithmetic
+// lane part `lane_bytes` (4 * sample [+ 512 * lane half for rows rowmap(r, 0) + 4 h]).
+// Address of (record row, lane part) of a tile's record block.  The block base is wave-uniform: pinning the 4 KB window of
+// the row into a scalar register pair makes every access (scalar base) + (32-bit lane offset) + immediate, the form the
+// hardware addresses by itself -- no 64-bit vector address arithmetic per 4 KB of rows
+typedef __attribute__((address_space(1))) char rec_gchar;   // (the pin must not cost the pointer its address space)
+__device__ inline char* rec_window(const float* rt, int row) {
+  rec_gchar* win = (rec_gchar*)(const_cast<char*>(reinterpret_cast<const char*>(rt)) + (((size_t)row * 128) & ~(size_t)4095));
+  asm("" : "+s"(win));
+  return (char*)win;
+}
 __device__ inline float* rec_at(float* rt, int row, unsigned lane_bytes) {
-  return reinterpret_cast<float*>(reinterpret_cast<char*>(rt) + (size_t)row * 128 + lane_bytes);
+  return reinterpret_cast<float*>(rec_window(rt, row) + lane_bytes + (((unsigned)row * 128u) & 4095u));
 }
 __device__ inline const float* rec_at(const float* rt, int row, unsigned lane_bytes) {
-  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(rt) + (size_t)row * 128 + lane_bytes);
+  return reinterpret_cast<const float*>(rec_window(rt, row) + lane_bytes + (((unsigned)row * 128u) & 4095u));
 }
 __device__ inline float4 rec_ld4(const float* p) {
 #if JT_REC_NT
@@ -112,23 +123,24 @@ __host__ __device__ constexpr int l1_rsteps() {
   return n;
 }
 
+// The weight image of a workgroup (75 KB for MLP_Fea): one wave per matrix row, lanes along the row -- coalesced 256-byte
+// reads, no index division, every load independent of the others (the first version walked a flat index with a division
+// and a modulo per element: ~60 us per launch, which is most of k_shade_fwd / k_shade_bwd on a trained, sparsely shaded
+// scene where a launch has one tile per wave).
 template <class C>
 __device__ inline void load_weights_lds(float* s, const MlpDev& M) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int a = wv; a < 32; a += nw) {            // basis [APP][NC] -> [32][LDB], rows >= APP and the pad column zero
+    const bool row = a < C::APP;
+    for (int c = lane; c < C::LDB; c += 64) s[C::O_BASIS + a * C::LDB + c] = (row && c < C::NC) ? M.basis[a * C::NC + c] : 0.f;
+  }
+  for (int u = wv; u < C::HID; u += nw) {        // W1 [HID][IN1] -> [HID][LD1]; W2 [HID][HID] -> [HID][LD2]
+    for (int c = lane; c < C::LD1; c += 64) s[C::O_W1 + u * C::LD1 + c] = (c < C::IN1) ? M.w1[u * C::IN1 + c] : 0.f;
+    for (int c = lane; c < C::LD2; c += 64) s[C::O_W2 + u * C::LD2 + c] = (c < C::HID) ? M.w2[u * C::HID + c] : 0.f;
+  }
   const int tid = threadIdx.x, nt = blockDim.x;
-  for (int i = tid; i < 32 * C::LDB; i += nt) {
-    int a = i / C::LDB, c = i - a * C::LDB;
-    s[C::O_BASIS + i] = (a < C::APP && c < C::NC) ? M.basis[a * C::NC + c] : 0.f;
-  }
-  for (int i = tid; i < C::HID * C::LD1; i += nt) {
-    int u = i / C::LD1, c = i - u * C::LD1;
-    s[C::O_W1 + i] = (c < C::IN1) ? M.w1[u * C::IN1 + c] : 0.f;
-  }
-  for (int i = tid; i < C::HID * C::LD2; i += nt) {
-    int u = i / C::LD2, c = i - u * C::LD2;
-    s[C::O_W2 + i] = (c < C::HID) ? M.w2[u * C::HID + c] : 0.f;
-  }
-  for (int i = tid; i < C::IN3 * 4; i += nt) {
-    int k = i >> 2, c = i & 3;
+  for (int i = tid; i < C::IN3 * 4; i += nt) {   // W3 [3][IN3] -> [IN3][4] (c = 0..2, pad)
+    const int k = i >> 2, c = i & 3;
     s[C::O_W3 + i] = (c < 3) ? M.w3[c * C::IN3 + k] : 0.f;
   }
   for (int i = tid; i < C::HID; i += nt) {
@@ -215,7 +227,9 @@ __device__ inline f32x16 gather_basis(const Dev& D, const float* s, const float 
         float av = sb[i * C::CA + c0 + k];
         facc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, facc, 0, 0, 0);
       }
-      if (m & 1) __builtin_amdgcn_sched_barrier(0);  // at most two quad slots of taps in flight
+      // at most two quad slots of taps in flight (3, 6 or all 18 measured the same 0.734 ms: the forward is not waiting for
+      // its gathers)
+      if (m & 1) __builtin_amdgcn_sched_barrier(0);
     }
   }
   return facc;
@@ -403,6 +417,372 @@ static inline PeMask pe_masks(float fea_progress, float view_progress, int fea_p
   pm.v0 = fminf(fmaxf(view_progress * view_pe - 0.f, 0.f), 1.f);
   pm.v1 = fminf(fmaxf(view_progress * view_pe - 1.f, 0.f), 1.f);
   return pm;
+}
+
+// =================================================================================================
+// Split-bf16 forward chain ("bf16x3").  gfx950 runs fp32-input MFMA at 64 FLOP / clk / SIMD and bf16-input MFMA at 1024:
+// an fp32 product sum is emulated at 2.7 x the fp32 matrix rate by splitting BOTH operands into three bf16 pieces
+// (x = p0 + p1 + p2 exactly to 2^-27 |x|: bf16 carries 8 significant bits) and issuing six v_mfma_f32_32x32x16_bf16 per
+// 16-deep K step -- a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0, fp32 accumulation; the dropped terms are below 2^-27.
+// Measured against double precision (tools/mfma_bf16_probe.hip, K = 160): max error 9.1e-6 on sums of magnitude 33, against
+// 1.2e-5 for an fp32 FMA chain -- fp32-level products, not a reduced-precision mode.
+// Layout: the 32x32x16 instruction takes 8 consecutive-k values per lane (lane half = k block) and leaves D in the SAME
+// register layout as the fp32 32x32x2 form (row = rowmap(r, half)), so the transposed chain keeps its property: the
+// accumulator of a layer is, after ReLU / encoding, the B operand of the next one, in registers.  Which logical k the 8
+// values of a (step, half) stand for is free as long as A agrees: the weights are pre-split into an LDS image
+// [stage][step][M tile][piece][lane] of 16-byte vectors that a lane reads with one ds_read_b128 per piece.
+// =================================================================================================
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+
+struct B3 {
+  bf8 p0, p1, p2;
+};
+
+// x = p0 + p1 + p2 to 2^-26 |x|: each piece a bf16 (round to nearest even: the remainders are signed and at most 2^-9 and
+// 2^-18 of x, which is what makes the three dropped cross terms of mfma6 smaller than an fp32 rounding).  Two values at a
+// time: one packed conversion per piece, a shift and a mask to get the pieces back as fp32, one packed subtraction (nine
+// VALU instructions per pair).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+
+__device__ inline unsigned pack_bf16(f32x2 x) { return __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf2)); }
+__device__ inline f32x2 unpack_bf16(unsigned w) {
+  f32x2 o;
+  o.x = __uint_as_float(w << 16);
+  o.y = __uint_as_float(w & 0xffff0000u);
+  return o;
+}
+
+__device__ inline B3 split8(const float v[8]) {
+  unsigned w0[4], w1[4], w2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f32x2 x;
+    x.x = v[2 * e], x.y = v[2 * e + 1];
+    w0[e] = pack_bf16(x);
+    const f32x2 r1 = x - unpack_bf16(w0[e]);
+    w1[e] = pack_bf16(r1);
+    const f32x2 r2 = r1 - unpack_bf16(w1[e]);
+    w2[e] = pack_bf16(r2);
+  }
+  B3 o;
+  o.p0 = __builtin_bit_cast(bf8, make_uint4(w0[0], w0[1], w0[2], w0[3]));
+  o.p1 = __builtin_bit_cast(bf8, make_uint4(w1[0], w1[1], w1[2], w1[3]));
+  o.p2 = __builtin_bit_cast(bf8, make_uint4(w2[0], w2[1], w2[2], w2[3]));
+  return o;
+}
+
+// acc += A B over one 16-deep K step, fp32-level: six bf16 MFMAs, small terms first
+__device__ inline f32x16 mfma6(const B3& a, const B3& b, f32x16 acc) {
+#if JT_ABL_NOMFMA
+  asm volatile("" ::"v"(a.p0), "v"(a.p1), "v"(a.p2), "v"(b.p0), "v"(b.p1), "v"(b.p2));
+  return acc;
+#endif
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p2, b.p0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b.p2, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b.p1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p1, b.p0, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b.p1, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p0, b.p0, acc, 0, 0, 0);
+  return acc;
+}
+
+template <class C>
+struct B16Cfg {
+  static constexpr int SPP = (C::NSLOT + 1) / 2;          // K steps per plane of the basis product (two quad slots each)
+  static constexpr int NSB = 3 * SPP;
+  static constexpr int RS = l1_rsteps<C>();
+  static constexpr int NS1 = (RS * 5 + 7) / 8;            // layer 1: five values per accumulator row and half
+  static constexpr int NS2 = 2 * C::MT;                   // layer 2: 16 MT values per half
+  // LDS carve in 16-byte vectors: [step][M tile][piece][64 lanes]
+  static constexpr int V_BASIS = 0;
+  static constexpr int V_W1 = V_BASIS + NSB * 3 * 64;
+  static constexpr int V_W2 = V_W1 + NS1 * C::MT * 3 * 64;
+  static constexpr int V_END = V_W2 + NS2 * C::MT * 3 * 64;
+  // fp32 tail (floats, behind the vectors): W3 [IN3][4], b1, b2, b3
+  static constexpr int F_W3 = 0;
+  static constexpr int F_B1 = F_W3 + C::IN3 * 4;
+  static constexpr int F_B2 = F_B1 + C::HID;
+  static constexpr int F_B3 = F_B2 + C::HID;
+  static constexpr int F_END = F_B3 + 4;
+  static constexpr size_t LDS_BYTES = (size_t)V_END * 16 + (size_t)F_END * 4;
+};
+
+__device__ inline void store_b3(uint4* img, int vec0, int lane, const float w[8]) {
+  const B3 p = split8(w);
+  img[vec0 + lane] = __builtin_bit_cast(uint4, p.p0);
+  img[vec0 + 64 + lane] = __builtin_bit_cast(uint4, p.p1);
+  img[vec0 + 128 + lane] = __builtin_bit_cast(uint4, p.p2);
+}
+
+template <class C>
+__device__ inline void load_weights_lds_b16(unsigned char* smem, const MlpDev& M) {
+  typedef B16Cfg<C> Q;
+  uint4* img = reinterpret_cast<uint4*>(smem);
+  float* tail = reinterpret_cast<float*>(smem + (size_t)Q::V_END * 16);
+  const int items = (Q::NSB + Q::NS1 * C::MT + Q::NS2 * C::MT) * 64;
+  for (int it = threadIdx.x; it < items; it += blockDim.x) {
+    const int lane = it & 63, blk = it >> 6, i = lane & 31, h = lane >> 5;
+    float w[8];
+    if (blk < Q::NSB) {                                   // basis: unit a = i, channels of two quad slots of one plane
+      const int pl = blk / Q::SPP, sp = blk - pl * Q::SPP;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int m = 2 * sp + (e >> 2), c = (2 * m + h) * 4 + (e & 3);
+        w[e] = (i < C::APP && m < C::NSLOT && c < C::CA) ? M.basis[i * C::NC + pl * C::CA + c] : 0.f;
+      }
+      store_b3(img, Q::V_BASIS + blk * 3 * 64, lane, w);
+    } else if (blk < Q::NSB + Q::NS1 * C::MT) {           // layer 1: unit u, the (row, encoding slot) pairs 8 s .. 8 s + 7
+      const int b = blk - Q::NSB, st = b / C::MT, mt = b - st * C::MT, u = mt * 32 + i;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = 8 * st + e, r = idx / 5, t = idx - 5 * r;
+        const int col = (r < Q::RS) ? (h ? w1_col<C>(1, r, t) : w1_col<C>(0, r, t)) : C::IN1;
+        w[e] = (col < C::IN1) ? M.w1[u * C::IN1 + col] : 0.f;
+      }
+      store_b3(img, Q::V_W1 + b * 3 * 64, lane, w);
+    } else {                                              // layer 2: unit u, hidden units of (tile mk, rows r) 8 s .. 8 s + 7
+      const int b = blk - Q::NSB - Q::NS1 * C::MT, st = b / C::MT, mt = b - st * C::MT, u = mt * 32 + i;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = 8 * st + e, mk = idx >> 4, r = idx & 15;
+        w[e] = M.w2[u * C::HID + mk * 32 + rowmap(r, 0) + 4 * h];
+      }
+      store_b3(img, Q::V_W2 + b * 3 * 64, lane, w);
+    }
+  }
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < C::IN3 * 4; i += nt) {
+    const int k = i >> 2, c = i & 3;
+    tail[Q::F_W3 + i] = (c < 3) ? M.w3[c * C::IN3 + k] : 0.f;
+  }
+  for (int i = tid; i < C::HID; i += nt) {
+    tail[Q::F_B1 + i] = M.b1[i];
+    tail[Q::F_B2 + i] = M.b2[i];
+  }
+  if (tid < 4) tail[Q::F_B3 + tid] = (tid < 3) ? M.b3[tid] : 0.f;
+}
+
+__device__ inline B3 load_b3(const uint4* img, int vec0, int lane) {
+  B3 a;
+  a.p0 = __builtin_bit_cast(bf8, img[vec0 + lane]);
+  a.p1 = __builtin_bit_cast(bf8, img[vec0 + 64 + lane]);
+  a.p2 = __builtin_bit_cast(bf8, img[vec0 + 128 + lane]);
+  return a;
+}
+
+template <class C>
+struct BwdCfg;
+
+// gather + products + basis_mat on the bf16 matrix cores (gather_basis's twin; the records, if any, get the same fp32
+// products).  The taps of the NEXT pair of quad slots are in flight while the current pair is multiplied and split: the
+// nine (VM-48) K steps of the basis product form one software pipeline across the three planes.
+#ifndef JT_B16_PIPE
+#define JT_B16_PIPE 1
+#endif
+#ifndef JT_B16_THREADS
+#define JT_B16_THREADS 512
+#endif
+struct TapGeo {
+  unsigned b00, b10, b01, b11, bl0, bl1;   // byte offsets of the six taps (this lane half's first channel quad)
+  float w00, w10, w01, w11, lw0, lw1;
+};
+struct TapSlot {
+  float4 a, b, c, d, u, v;
+};
+
+template <class C, bool REC>
+__device__ inline f32x16 gather_basis_b16(const Dev& D, const uint4* img, const float n[3], int j, int h, int lane,
+                                          float* rt, bool onrec) {
+  typedef B16Cfg<C> Q;
+  f32x16 facc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) facc[r] = 0.f;
+  const unsigned hb = 16u * (unsigned)h;
+  TapGeo geo[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const PlaneTaps t = plane_taps(n[kM0(i)], n[kM1(i)], D.ph[i], D.pw[i], C::CA);
+    const Axis l = axis_taps(n[kV(i)], D.ll[i]);
+    geo[i].b00 = 4u * (unsigned)t.o00 + hb;
+    geo[i].b10 = 4u * (unsigned)t.o10 + hb;
+    geo[i].b01 = 4u * (unsigned)t.o01 + hb;
+    geo[i].b11 = 4u * (unsigned)t.o11 + hb;
+    geo[i].bl0 = 4u * (unsigned)(l.c0 * C::CA) + hb;
+    geo[i].bl1 = 4u * (unsigned)(l.c1 * C::CA) + hb;
+    geo[i].w00 = t.w00;
+    geo[i].w10 = t.w10;
+    geo[i].w01 = t.w01;
+    geo[i].w11 = t.w11;
+    geo[i].lw0 = l.w0;
+    geo[i].lw1 = l.w1;
+  }
+  auto load_slot = [&](int i, int m, TapSlot& s) {
+    const TapGeo& g = geo[i];
+    const float* P = D.aP[i];
+    const float* L = D.aL[i];
+#if JT_ABL_NOLD
+    s.a = s.b = s.c = s.d = make_float4(g.w00, g.w10, g.w01, g.w11), s.u = s.v = make_float4(g.lw0, g.lw1, g.w00, g.w11);
+    return;
+#endif
+    if (C::CA % 8 == 0 || m + 1 < C::NSLOT) {
+      s.a = ld4q(P, g.b00, 2 * m), s.b = ld4q(P, g.b10, 2 * m), s.c = ld4q(P, g.b01, 2 * m), s.d = ld4q(P, g.b11, 2 * m);
+      s.u = ld4q(L, g.bl0, 2 * m), s.v = ld4q(L, g.bl1, 2 * m);
+    } else {  // last slot of an odd quad count (VM-20): half 1 has no quad there and re-reads half 0's (zeroed below)
+      s.a = ld4q(P, g.b00 - hb, 2 * m), s.b = ld4q(P, g.b10 - hb, 2 * m), s.c = ld4q(P, g.b01 - hb, 2 * m);
+      s.d = ld4q(P, g.b11 - hb, 2 * m), s.u = ld4q(L, g.bl0 - hb, 2 * m), s.v = ld4q(L, g.bl1 - hb, 2 * m);
+    }
+  };
+  constexpr int NP = 3 * Q::SPP;   // pairs of quad slots = K steps
+  TapSlot buf[2][2];
+  if (JT_B16_PIPE) {
+    load_slot(0, 0, buf[0][0]);
+    if (1 < C::NSLOT) load_slot(0, 1, buf[0][1]);
+  }
+#pragma unroll
+  for (int pp = 0; pp < NP; ++pp) {
+    const int i = pp / Q::SPP, sp = pp - i * Q::SPP;
+    if (JT_B16_PIPE && pp + 1 < NP) {  // the next pair's taps go out before this pair is touched
+      const int i1 = (pp + 1) / Q::SPP, sp1 = (pp + 1) - i1 * Q::SPP;
+      load_slot(i1, 2 * sp1, buf[(pp + 1) & 1][0]);
+      if (2 * sp1 + 1 < C::NSLOT) load_slot(i1, 2 * sp1 + 1, buf[(pp + 1) & 1][1]);
+    }
+    if (!JT_B16_PIPE) {
+      load_slot(i, 2 * sp, buf[pp & 1][0]);
+      if (2 * sp + 1 < C::NSLOT) load_slot(i, 2 * sp + 1, buf[pp & 1][1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const TapGeo& g = geo[i];
+    float bv8[8];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int m = 2 * sp + half;
+      if (m < C::NSLOT) {
+        const TapSlot& s = buf[pp & 1][half];
+        const bool live = C::CA % 8 == 0 || (2 * m + h) * 4 < C::CA;
+        float pr[4];
+        pr[0] = (g.w00 * s.a.x + g.w10 * s.b.x + g.w01 * s.c.x + g.w11 * s.d.x) * (g.lw0 * s.u.x + g.lw1 * s.v.x);
+        pr[1] = (g.w00 * s.a.y + g.w10 * s.b.y + g.w01 * s.c.y + g.w11 * s.d.y) * (g.lw0 * s.u.y + g.lw1 * s.v.y);
+        pr[2] = (g.w00 * s.a.z + g.w10 * s.b.z + g.w01 * s.c.z + g.w11 * s.d.z) * (g.lw0 * s.u.z + g.lw1 * s.v.z);
+        pr[3] = (g.w00 * s.a.w + g.w10 * s.b.w + g.w01 * s.c.w + g.w11 * s.d.w) * (g.lw0 * s.u.w + g.lw1 * s.v.w);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (REC && live && onrec)
+            rec_st(rec_at(rt, BwdCfg<C>::R_PROD + i * C::CA + 8 * m + k, 4u * (unsigned)j + 512u * (unsigned)h), pr[k]);
+          bv8[4 * half + k] = live ? pr[k] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bv8[4 * half + k] = 0.f;
+      }
+    }
+    const B3 bb = split8(bv8);
+    const B3 aa = load_b3(img, Q::V_BASIS + pp * 3 * 64, lane);
+    facc = mfma6(aa, bb, facc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return facc;
+}
+
+// scheduling hint for one K step whose matrix instructions overlap the NEXT step's operand preparation: alternate one MFMA
+// (32 cycles on the matrix pipe, 4 to issue) with up to `valu` vector instructions.  A wave issues in order, so the overlap has
+// to be in the program order; the compiler left to itself emits the twelve MFMAs of a step back to back.
+template <int N, int VALU, int DS, int LEAD>
+__device__ inline void interleave_mfma() {
+  __builtin_amdgcn_sched_group_barrier(0x100, DS, 0);      // the step's A operands leave the LDS first ...
+  __builtin_amdgcn_sched_group_barrier(0x002, LEAD, 0);    // ... and have LEAD vector instructions to arrive
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+    __builtin_amdgcn_sched_group_barrier(0x002, VALU, 0);  // VALU
+  }
+}
+
+#ifndef JT_B16_IL1
+#define JT_B16_IL1 8
+#endif
+#ifndef JT_B16_LEAD
+#define JT_B16_LEAD 16
+#endif
+#ifndef JT_B16_IL2
+#define JT_B16_IL2 3
+#endif
+
+template <class C>
+__device__ inline Hidden<C> layer1_b16(const uint4* img, const float* tail, const f32x16& facc, const float vd[3],
+                                       const PeMask& pm, int h, int lane) {
+  typedef B16Cfg<C> Q;
+  Hidden<C> acc;
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc.v[mt][r] = tail[Q::F_B1 + mt * 32 + rowmap(r, h)];
+  float v8[8];
+  B3 cur;   // the split operand of the previous K step: its MFMAs are issued among this step's encodings and split
+#pragma unroll
+  for (int r = 0; r < (Q::NS1 * 8 + 4) / 5; ++r) {
+    float in[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, sn, cs;
+    if (r < Q::RS) l1_inputs<C>(facc, vd, pm, h, r, in, &sn, &cs);
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int idx = 5 * r + t;
+      if (idx < Q::NS1 * 8) {
+        v8[idx & 7] = in[t];
+        if ((idx & 7) == 7) {
+          const int st = idx >> 3;
+          const B3 nb = split8(v8);
+          if (st > 0) {
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt) {
+              const B3 aa = load_b3(img, Q::V_W1 + ((st - 1) * C::MT + mt) * 3 * 64, lane);
+              acc.v[mt] = mfma6(aa, cur, acc.v[mt]);
+            }
+            interleave_mfma<6 * C::MT, JT_B16_IL1, 3 * C::MT, JT_B16_LEAD>();
+          }
+          cur = nb;
+          __builtin_amdgcn_sched_barrier(0);  // one step's encodings at a time (VGPR pressure)
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt) {
+    const B3 aa = load_b3(img, Q::V_W1 + ((Q::NS1 - 1) * C::MT + mt) * 3 * 64, lane);
+    acc.v[mt] = mfma6(aa, cur, acc.v[mt]);
+  }
+  return acc;
+}
+
+template <class C>
+__device__ inline Hidden<C> layer2_b16(const uint4* img, const float* tail, const Hidden<C>& h1, int h, int lane) {
+  typedef B16Cfg<C> Q;
+  Hidden<C> acc;
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc.v[mt][r] = tail[Q::F_B2 + mt * 32 + rowmap(r, h)];
+  B3 cur;
+#pragma unroll
+  for (int st = 0; st <= Q::NS2; ++st) {
+    B3 nb;
+    if (st < Q::NS2) {
+      float v8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v8[e] = h1.v[(8 * st + e) >> 4][(8 * st + e) & 15];
+      nb = split8(v8);
+    }
+    if (st > 0) {
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) {
+        const B3 aa = load_b3(img, Q::V_W2 + ((st - 1) * C::MT + mt) * 3 * 64, lane);
+        acc.v[mt] = mfma6(aa, cur, acc.v[mt]);
+      }
+      if (st < Q::NS2) interleave_mfma<6 * C::MT, JT_B16_IL2, 3 * C::MT, 8>();
+    }
+    cur = nb;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return acc;
 }
 
 template <class C>
