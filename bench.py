@@ -674,7 +674,10 @@ def main():
                 "rays_per_iter_per_gpu": rays_all / args.steps / world,
                 "samples_per_ray": S,
                 "Msamples_per_s": rays_all * S / dt / 1e6,
-                "shade_impl": "mfma",
+                "shade_impl": {0: "fp32 MFMA", 1: "bf16x3 MFMA forward chain, fp32 MFMA backward chain and weight gradients",
+                               2: "fp32 MFMA chains, bf16x3 MFMA weight gradients",
+                               3: "bf16x3 MFMA (three-piece operands, fp32-level accuracy) forward chain and weight-gradient "
+                                  "GEMMs, fp32 MFMA backward chain"}.get(__import__("joint_tensorf_amd._lib", fromlist=["lib"]).lib.jt_shade_matrix_mode() & 3),
                 "launch": ("hipGraph replay (%(replayed)d replayed / %(captured)d captured / %(eager)d eager steps)"
                            % stepper.stats) if stepper is not None else "eager",
                 "abi_calls_per_step": n_calls[0] or None,

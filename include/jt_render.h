@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define JT_VERSION 1002
+#define JT_VERSION 1003
 
 #define JT_OK 0
 #define JT_ERR_ARG 1         /* null pointer / bad size */
@@ -251,6 +251,15 @@ int jt_shade_record_layout(const JtScene* scene, int32_t* out);
  * the previous setting; any argument other than 0 / 1 only queries.  A debugging aid (race detection), slower. */
 int jt_set_deterministic(int on);
 int jt_shade_chunk_entries(void);
+/* Which matrix stages of the appearance path run on the bf16 matrix cores with every fp32 operand split into three bf16
+ * pieces and six products accumulated per K step (fp32-level accuracy; the reference's fp32 torch.nn.Linear chain,
+ * tensorBase.py:43-131, is what both variants are held to): bit 0 the forward chain (basis product, layers 1 and 2),
+ * bit 1 the weight-gradient GEMMs.  0 = everything on the fp32 matrix cores.  The environment variable JT_BF16X3 (read
+ * once) overrides the build default; jt_shade_set_matrix_mode(mode) sets it for the launches that follow and returns the
+ * previous value (a mode outside 0..3 only queries).  A forward and its backward may run under different modes: the
+ * records they exchange are the same fp32 values in the same layout. */
+int jt_shade_matrix_mode(void);
+int jt_shade_set_matrix_mode(int mode);
 int jt_shade_set_chunk_log2(int log2_entries);
 int jt_shade_forward(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp, const float* rays_o,
                      const float* rays_d, const float* jitter, const float* zvals, const float* tmin,

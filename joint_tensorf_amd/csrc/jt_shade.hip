@@ -13,6 +13,7 @@
 // map  row(r, h) = (r & 3) + 8 (r >> 2) + 4 h, and the A operand (weights, read from LDS with an odd
 // row stride => conflict-free) simply reads the matching column.  The gather is split the same way:
 // half h loads the channel quads q with q % 2 == h as 16-byte vectors.
+#include <atomic>
 #include <cstdlib>
 
 #include "jt_common.h"
@@ -871,9 +872,15 @@ using namespace jt;
 // which stages run on the bf16 matrix cores with three-piece operands (fp32-level accuracy, jt_shade_core.h): bit 0 the
 // forward chain (k_shade_fwd_b16), bit 1 the weight-gradient GEMMs (k_wgrad_b16).  JT_BF16X3 (read once) overrides the build
 // default; 0 = everything on the fp32 matrix cores.
+static std::atomic<int> g_matrix_mode{-1};
 static int bf16x3_mode() {
-  static const int mode = [] { const char* e = getenv("JT_BF16X3"); return e ? atoi(e) : JT_BF16X3_DEFAULT; }();
-  return mode;
+  int m = g_matrix_mode.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = getenv("JT_BF16X3");
+    m = (e ? atoi(e) : JT_BF16X3_DEFAULT) & 3;
+    g_matrix_mode.store(m, std::memory_order_relaxed);
+  }
+  return m;
 }
 
 typedef ShadeCfg<48, 27, 64, JT_MLP_FEA> CfgBlender;     // bat_blender_VM: VM-48, MLP_Fea 150->64->64->3
@@ -903,6 +910,12 @@ static int chunk_entries() {
   return 1 << g_chunk_log2;
 }
 extern "C" int jt_shade_chunk_entries(void) { return chunk_entries(); }
+extern "C" int jt_shade_matrix_mode(void) { return bf16x3_mode(); }
+extern "C" int jt_shade_set_matrix_mode(int mode) {
+  const int prev = bf16x3_mode();
+  if (mode >= 0 && mode <= 3) g_matrix_mode.store(mode, std::memory_order_relaxed);
+  return prev;
+}
 // returns the previous log2; values outside 16..22 only query.  The caller re-sizes its workspace afterwards
 // (jt_shade_workspace_bytes depends on the chunk size); not to be changed between a forward and its backward.
 extern "C" int jt_shade_set_chunk_log2(int log2_entries) {
