@@ -213,7 +213,8 @@ int jt_march_backward(const JtScene* scene, const JtFactors* factors, const floa
 size_t jt_march_backward_workspace_bytes(const JtScene* scene, int n_rays);
 
 /* ---------------------------------------------------------------------------------------------
- * Fused appearance path on the matrix cores (fp32 MFMA, exact-f32 numerics):
+ * Fused appearance path on the matrix cores (fp32 accuracy: fp32 MFMA, or bf16 MFMA on three-piece operands, see
+ * jt_shade_matrix_mode):
  * gather(app planes/lines) -> outer product -> basis_mat -> PE -> MLP -> sigmoid, per shaded
  * sample, without materialising the [n][3*Ca] product matrix.
  * Replaces compute_appfeature + basis_mat + MLPRender_Fea[_WeakView].forward and their autograd.
