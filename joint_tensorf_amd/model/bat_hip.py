@@ -774,8 +774,12 @@ class Model(torch.nn.Module):
         images_all = data_all.image
         loss, t0 = None, time.time()
         stepper = None
-        if _has(opt, "train_graph") and opt.train_graph and str(opt.device).startswith("cuda"):
-            # every steady-state iteration replayed from a hipGraph (graphed.GraphedTrainStep): one launch per iteration
+        want_graph = bool(opt.train_graph) if _has(opt, "train_graph") else True
+        if want_graph and str(opt.device).startswith("cuda"):
+            # every steady-state iteration replayed from a hipGraph (graphed.GraphedTrainStep): one launch per iteration.
+            # On by default (`train_graph: false` turns it off): a trained scene shades a few per cent of its samples and
+            # the eager step is bound by the host's ~60 launches (1.8 ms eager against 1.0 ms replayed on the converged
+            # synthetic scene); iterations the stepper cannot capture (sharded ranks, first iterations of a stage) run eager
             from ..graphed import GraphedTrainStep
             stepper = GraphedTrainStep(self)
         for it in range(int(opt.max_iter)):
