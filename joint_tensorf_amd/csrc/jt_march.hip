@@ -127,29 +127,42 @@ __global__ __launch_bounds__(256) void k_march_fwd(Dev D, const float* __restric
   }
 }
 
-// exclusive scan of per-ray shade counts (one workgroup; R <= a few 100k)
+// exclusive scan of per-ray shade counts: one workgroup walks the rays in coalesced chunks of 1 024 (wave scan by
+// shuffles, the sixteen wave totals through LDS, a running carry), 3 us for a training batch, ~1 us per further chunk
 __global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ count, int* __restrict__ offset,
                                                       int R) {
-  __shared__ int part[1024];
-  const int t = threadIdx.x;
-  const int per = (R + 1023) / 1024;
-  const int b = t * per, e = min(b + per, R);
-  int s = 0;
-  for (int i = b; i < e; ++i) s += count[i];
-  part[t] = s;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    int v = (t >= o) ? part[t - o] : 0;
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  int carry = 0;
+  for (int base = 0; base < R; base += 1024) {
+    const int i = base + t;
+    const int v = (i < R) ? count[i] : 0;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(inc, o);
+      if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[wv] = inc;
     __syncthreads();
-    part[t] += v;
+    if (wv == 0) {
+      int w = (lane < 16) ? wsum[lane] : 0;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const int u = __shfl_up(w, o);
+        if (lane >= o) w += u;
+      }
+      if (lane < 16) wsum[lane] = w;  // inclusive over the waves
+      if (lane == 15) carry_s = w;
+    }
+    __syncthreads();
+    const int before = carry + (wv ? wsum[wv - 1] : 0);
+    if (i < R) offset[i] = before + inc - v;
+    carry += carry_s;
     __syncthreads();
   }
-  int run = (t == 0) ? 0 : part[t - 1];
-  for (int i = b; i < e; ++i) {
-    offset[i] = run;
-    run += count[i];
-  }
-  if (t == 1023) offset[R] = part[1023];
+  if (t == 0) offset[R] = carry;
 }
 
 // entry -> (ray, sample) map, one wave per ray
