@@ -165,10 +165,12 @@ def _aux_stream(dev):
     return _AUX[key]
 
 
-def _zeros_flat(groups, with_flat=False):
+def _zeros_flat(groups, with_flat=False, unzeroed=()):
     """Zero tensors shaped like the tensors of `groups` (a list of lists), carved out of ONE flat buffer: one fill
     launch instead of one per tensor (19 per backward).  Offsets are rounded up to 16 bytes.  with_flat: also
-    return the flat buffer and the [start, end) float span of every group (contiguous: one collective each)."""
+    return the flat buffer and the [start, end) float span of every group (contiguous: one collective each).
+    unzeroed: indices of groups the caller is about to OVERWRITE completely -- they are left uninitialised (the
+    regularisers' gradient is written in place of the zeros, RenderRays.backward)."""
     flat_n, plan, spans = 0, [], []
     for grp in groups:
         start = flat_n
@@ -177,7 +179,20 @@ def _zeros_flat(groups, with_flat=False):
             flat_n += (t.numel() + 3) // 4 * 4
         spans.append((start, flat_n))
     ref = groups[0][0]
-    flat = torch.zeros(flat_n, device=ref.device, dtype=ref.dtype)
+    if unzeroed:
+        flat = torch.empty(flat_n, device=ref.device, dtype=ref.dtype)
+        k = 0
+        while k < len(groups):  # one fill per run of consecutive groups that do need their zeros
+            if k in unzeroed:
+                k += 1
+                continue
+            j = k
+            while j + 1 < len(groups) and (j + 1) not in unzeroed:
+                j += 1
+            flat[spans[k][0]:spans[j][1]].zero_()
+            k = j + 1
+    else:
+        flat = torch.zeros(flat_n, device=ref.device, dtype=ref.dtype)
     it = iter(plan)
     views = [[flat[o:o + t.numel()].view(t.shape) for (o, t) in (next(it) for _ in grp)] for grp in groups]
     return (views, flat, spans) if with_flat else views
@@ -473,6 +488,7 @@ class RenderRays(torch.autograd.Function):
         want_mlp = any(nig[17:24])
         fused_mlp_zero = want_fac and want_mlp
         det = bool(lib.jt_set_deterministic(-1))  # JT_DETERMINISTIC: factor gradients summed in 64-bit fixed point
+        reg_first = False
         if det and want_fac:
             if _DP["world"] > 1 or _DP["force"]:
                 raise RuntimeError("JT_DETERMINISTIC is a single-process debugging mode")
@@ -485,12 +501,24 @@ class RenderRays(torch.autograd.Function):
             fused_mlp_zero = False
             g_mlp_z = None
         elif want_fac:
-            # gradient buffers (channel-last storage, zero-initialised: the kernels accumulate with atomics)
+            # gradient buffers (channel-last storage; the kernels accumulate with atomics).  Single process with the
+            # regularisers in this node: their gradient covers every element of the density factors (L1) and, with TV on
+            # the colours, of the appearance planes -- it is WRITTEN first, in place of those tensors' zero fill (the
+            # atomics of the render backward then land on top of it; before: fill + read-modify-write of the same bytes)
+            reg_first = (ctx.reg is not None and g_reg is not None and _DP["world"] <= 1 and not _DP["force"])
+            skip = ((0, 1, 2) if ctx.reg[4] else (0, 1)) if reg_first else ()
             if fused_mlp_zero:
-                (gdp, gdl, gap, gal, g_mlp_z), gflat, spans = _zeros_flat([sdp, sdl, sap, sal, mlp_t], with_flat=True)
+                (gdp, gdl, gap, gal, g_mlp_z), gflat, spans = _zeros_flat([sdp, sdl, sap, sal, mlp_t], with_flat=True,
+                                                                          unzeroed=skip)
             else:
-                (gdp, gdl, gap, gal), gflat, spans = _zeros_flat([sdp, sdl, sap, sal], with_flat=True)
+                (gdp, gdl, gap, gal), gflat, spans = _zeros_flat([sdp, sdl, sap, sal], with_flat=True, unzeroed=skip)
             gfac = _factors_struct(gdp, gdl, gap, gal)
+            if reg_first:
+                hw, Cd, Ca, wd, wa = ctx.reg
+                scratch = torch.empty(36, **f32)
+                g3c = g_reg.contiguous().float()
+                check(lib.jt_reg_losses_backward(fac, (ctypes.c_int32 * 9)(*hw), Cd, Ca, ptr(g3c), int(wd), int(wa), gfac, 0,
+                                                 ptr(scratch), st), "jt_reg_losses_backward")
         else:
             gfac = None
         g_xyz = torch.empty(cap_alloc, 3, **f32)
@@ -578,9 +606,11 @@ class RenderRays(torch.autograd.Function):
             bad = (gflat64.abs() >= (1 << 60)).any()
             status_word(dev).bitwise_or_(bad.to(torch.int32) * FINITE_GRAD)
             gfac = gfac_float
-        if ctx.reg is not None and g_reg is not None and want_fac:
+        if reg_first:
+            pass  # written before the render backward, above
+        elif ctx.reg is not None and g_reg is not None and want_fac:
             # the regularisers' gradient joins the render gradient in place (after the collectives: it is the same
-            # on every rank and is not part of the exchange)
+            # on every rank and is not part of the exchange; after the fixed-point conversion in deterministic mode)
             hw, Cd, Ca, wd, wa = ctx.reg
             scratch = torch.empty(36, **f32)
             g3c = g_reg.contiguous().float()
