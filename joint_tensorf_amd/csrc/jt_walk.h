@@ -14,6 +14,16 @@
 // an accumulator that never received anything needs no atomic
 #define JT_FLUSH_COND(x) ((x) != 0.f)
 
+// profiling knob (tools/build_variant.py -DJT_ABL_WALK_ATOMICS=1 / 2): the flush of a walker as nothing at all (1) or as a
+// plain store of the same value to the same address (2) instead of the float atomic -- what the atomic unit costs a scatter
+#if JT_ABL_WALK_ATOMICS == 1
+#define JT_WALK_ATOMIC(p, v) asm volatile("" ::"v"(p), "v"(v))
+#elif JT_ABL_WALK_ATOMICS == 2
+#define JT_WALK_ATOMIC(p, v) (*(p) = (v))
+#else
+#define JT_WALK_ATOMIC(p, v) atomicAdd(p, v)
+#endif
+
 namespace jt {
 
 // ---------------------------------------------------------------------------------------------
@@ -188,9 +198,9 @@ struct RecWalker {
         if (FX == 1 || (FX == 2 && fixed))  // byte offset of a float element -> the same element of the 64-bit shadow buffer
           fixed_add(reinterpret_cast<long long*>(reinterpret_cast<char*>(base) + 2 * (size_t)(off + ck[k])), a[k]);
         else if (k < CA / 16)
-          atomicAdd(t0 + 16 * k, a[k]);
+          JT_WALK_ATOMIC(t0 + 16 * k, a[k]);
         else
-          atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (off + ck[k])), a[k]);
+          JT_WALK_ATOMIC(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (off + ck[k])), a[k]);
       }
     }
 #pragma unroll
