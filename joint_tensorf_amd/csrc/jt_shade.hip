@@ -843,17 +843,15 @@ __global__ __launch_bounds__(256) void k_wgrad_b16(const float* __restrict__ rec
   wgrad_epilogue<MT, NT>(acc, asum, s_red, slab, lane, wv, m, h);
 }
 
-// dW[i][k] += sum over the live chunks' block slabs; grid.y slab groups, a few atomics per element
+// dW[i][k] += sum over the live chunks' block slabs; grid.y slab groups, a few atomics per element.  `xblock` = the block
+// index inside this GEMM's range of the launch (k_wgrad_reduce4 serves the four GEMMs with one launch).
 template <int MT, int NT, int XF>
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slabs, int blocks_per_chunk,
-                                                      size_t chunk_stride, int chunk_entries,
-                                                      const int* __restrict__ offset, int R, int cap, int M, int N,
-                                                      int APP, float* __restrict__ dW, int ldw,
-                                                      float* __restrict__ db) {
-  const int total = min(offset[R], cap);
+__device__ inline void wgrad_reduce_body(int xblock, const float* __restrict__ slabs, int blocks_per_chunk,
+                                         size_t chunk_stride, int chunk_entries, int total, int M, int N, int APP,
+                                         float* __restrict__ dW, int ldw, float* __restrict__ db) {
   const int nchunks = (total + chunk_entries - 1) / chunk_entries;
   constexpr int PER = MT * NT * 1024 + MT * 32;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx = xblock * blockDim.x + threadIdx.x;
   if (idx >= PER) return;
   // blockIdx.y strides over the slabs of every chunk's ACTIVE blocks; four independent partial sums keep loads in flight
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -882,6 +880,49 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     const int i = idx - MT * NT * 1024;
     if (i < M) atomicAdd(db + i, sum);
   }
+}
+
+// tile counts and per-block slab sizes (floats) of the four weight-gradient GEMMs: dW3 / db3, dW2 / db2, dW1 / db1, dBasis
+template <class C>
+struct WgradDims {
+  static constexpr int NT3 = (C::IN3 + 31) / 32, NT1 = 5, NTB = (C::NC + 31) / 32;
+  static constexpr size_t P3 = 1 * NT3 * 1024 + 32, P2 = (size_t)C::MT * C::MT * 1024 + C::MT * 32,
+                          P1 = (size_t)C::MT * NT1 * 1024 + C::MT * 32, PB = 1 * NTB * 1024 + 32;
+};
+
+// gradient tensors of the MLP as the reduce kernel's argument
+struct MlpGrad {
+  float *basis, *w1, *b1, *w2, *b2, *w3, *b3;
+};
+
+// the cross-block sums of the four weight-gradient GEMMs in ONE launch: grid.x is the concatenation of the four element
+// ranges, 256 elements per block
+template <class C>
+__global__ __launch_bounds__(256) void k_wgrad_reduce4(const float* __restrict__ slabs, int blocks_per_chunk,
+                                                       size_t chunk_stride, int chunk_entries,
+                                                       const int* __restrict__ offset, int R, int cap, MlpGrad GM) {
+  typedef WgradDims<C> W;
+  constexpr int NT3 = W::NT3, NT1 = W::NT1, NTB = W::NTB;
+  constexpr int XF1 = (C::KIND == JT_MLP_FEA) ? 1 : 2;
+  constexpr int B3 = (int)((W::P3 + 255) / 256), B2 = (int)((W::P2 + 255) / 256), B1 = (int)((W::P1 + 255) / 256);
+  const int total = min(offset[R], cap);
+  const float* s3 = slabs;
+  const float* s2 = s3 + W::P3 * blocks_per_chunk;
+  const float* s1 = s2 + W::P2 * blocks_per_chunk;
+  const float* sb = s1 + W::P1 * blocks_per_chunk;
+  const int x = blockIdx.x;
+  if (x < B3)
+    wgrad_reduce_body<1, NT3, 0>(x, s3, blocks_per_chunk, chunk_stride, chunk_entries, total, 3, C::IN3, C::APP,
+                                 GM.w3, C::IN3, GM.b3);
+  else if (x < B3 + B2)
+    wgrad_reduce_body<C::MT, C::MT, 0>(x - B3, s2, blocks_per_chunk, chunk_stride, chunk_entries, total, C::HID, C::HID,
+                                       C::APP, GM.w2, C::HID, GM.b2);
+  else if (x < B3 + B2 + B1)
+    wgrad_reduce_body<C::MT, NT1, XF1>(x - B3 - B2, s1, blocks_per_chunk, chunk_stride, chunk_entries, total, C::HID,
+                                       C::IN1, C::APP, GM.w1, C::IN1, GM.b1);
+  else
+    wgrad_reduce_body<1, NTB, 0>(x - B3 - B2 - B1, sb, blocks_per_chunk, chunk_stride, chunk_entries, total, C::APP, C::NC,
+                                 C::APP, GM.basis, C::NC, (float*)nullptr);
 }
 
 }  // namespace jt
@@ -950,9 +991,9 @@ static const int kWgradBlocks = 512;
 template <class C>
 struct WsLayout {
   typedef BwdCfg<C> B;
-  static constexpr int NT3 = (C::IN3 + 31) / 32, NT1 = 5, NTB = (C::NC + 31) / 32;
-  static constexpr size_t P3 = 1 * NT3 * 1024 + 32, P2 = (size_t)C::MT * C::MT * 1024 + C::MT * 32,
-                          P1 = (size_t)C::MT * NT1 * 1024 + C::MT * 32, PB = 1 * NTB * 1024 + 32;
+  typedef WgradDims<C> WD;
+  static constexpr int NT3 = WD::NT3, NT1 = WD::NT1, NTB = WD::NTB;
+  static constexpr size_t P3 = WD::P3, P2 = WD::P2, P1 = WD::P1, PB = WD::PB;
   static size_t rec_floats_per_chunk() { return (size_t)B::REC_FLOATS * kChunkEntries; }
   static size_t slab_floats_per_chunk() { return (P3 + P2 + P1 + PB) * kWgradBlocks; }
   // records of all chunks are one contiguous tile-blocked array (a chunk is a whole number of 32-sample tiles), so
@@ -1164,21 +1205,10 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   }
   {
     const int ry = det ? 1 : 32;  // slab groups that add into dW atomically; ONE group = a fixed summation order
-    float* s3 = slabs;
-    float* s2 = s3 + W::P3 * nb;
-    float* s1 = s2 + W::P2 * nb;
-    float* sb = s1 + W::P1 * nb;
-    hipLaunchKernelGGL((k_wgrad_reduce<1, NT3, 0>), dim3((W::P3 + 255) / 256, ry), dim3(256), 0, ws_st, s3, nb, cstride,
-                       chunk, offset, R, cap, 3, C::IN3, C::APP, GM.w3, C::IN3, GM.b3);
-    JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad_reduce<C::MT, C::MT, 0>), dim3((W::P2 + 255) / 256, ry), dim3(256), 0, ws_st, s2, nb,
-                       cstride, chunk, offset, R, cap, C::HID, C::HID, C::APP, GM.w2, C::HID, GM.b2);
-    JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad_reduce<C::MT, NT1, XF1>), dim3((W::P1 + 255) / 256, ry), dim3(256), 0, ws_st, s1, nb,
-                       cstride, chunk, offset, R, cap, C::HID, C::IN1, C::APP, GM.w1, C::IN1, GM.b1);
-    JT_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_wgrad_reduce<1, NTB, 0>), dim3((W::PB + 255) / 256, ry), dim3(256), 0, ws_st, sb, nb, cstride,
-                       chunk, offset, R, cap, C::APP, C::NC, C::APP, GM.basis, C::NC, (float*)nullptr);
+    const int nblk = (int)((W::P3 + 255) / 256 + (W::P2 + 255) / 256 + (W::P1 + 255) / 256 + (W::PB + 255) / 256);
+    const MlpGrad gm = {GM.basis, GM.w1, GM.b1, GM.w2, GM.b2, GM.w3, GM.b3};
+    hipLaunchKernelGGL((k_wgrad_reduce4<C>), dim3(nblk, ry), dim3(256), 0, ws_st, slabs, nb, cstride, chunk, offset, R, cap,
+                       gm);
     JT_LAUNCH_CHECK();
   }
   if (ws_st != st) {
