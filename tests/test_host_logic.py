@@ -173,3 +173,33 @@ def test_bench_gpus_n_without_n_gpus_refuses():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "--gpus 8" in r.stderr and not r.stdout.strip()
+
+
+def test_flat_gradient_buffer_zeroes_only_what_nobody_overwrites():
+    """ops._zeros_flat carves the gradient tensors of a backward out of one buffer; groups the regularisers' backward is
+    about to overwrite completely (RenderRays.backward: density factors, appearance planes under TV) are left unfilled, every
+    other group -- and the padding between its tensors -- is zero, and the spans are what the data-parallel reducer slices."""
+    from joint_tensorf_amd import ops
+    g = torch.Generator().manual_seed(1)
+    groups = [[torch.randn(5, 4, generator=g), torch.randn(3, generator=g)], [torch.randn(8, generator=g)],
+              [torch.randn(2, 3, generator=g)], [torch.randn(7, generator=g), torch.randn(1, generator=g)]]
+    views, flat, spans = ops._zeros_flat(groups, with_flat=True)
+    assert float(flat.abs().sum()) == 0.0 and spans == [(0, 24), (24, 32), (32, 40), (40, 52)]
+    for grp, vs in zip(groups, views):
+        assert [tuple(v.shape) for v in vs] == [tuple(t.shape) for t in grp]
+    # views alias the flat buffer, 16-byte aligned
+    views[3][1].fill_(2.0)
+    assert float(flat[48]) == 2.0 and all(v.data_ptr() % 16 == 0 for vs in views for v in vs)
+    # poison the allocator's next block, then ask for groups 0 and 2 unzeroed
+    junk = torch.full((52,), float("nan"))
+    del junk
+    views, flat, spans = ops._zeros_flat(groups, with_flat=True, unzeroed=(0, 2))
+    assert float(flat[24:32].abs().sum()) == 0.0 and float(flat[40:52].abs().sum()) == 0.0
+    assert spans == [(0, 24), (24, 32), (32, 40), (40, 52)]
+    # the caller overwrites every ELEMENT of the unzeroed groups (their padding words, if any, belong to nobody: the factor
+    # tensors this is used for have none, and the data-parallel path, which ships whole spans, never skips a fill)
+    for vs in (views[0], views[2]):
+        for v in vs:
+            v.fill_(1.0)
+    assert float(flat[24:32].abs().sum()) == 0.0 and float(flat[40:52].abs().sum()) == 0.0
+    assert float(sum(v.sum() for vs in (views[0], views[2]) for v in vs)) == 5 * 4 + 3 + 2 * 3
