@@ -108,4 +108,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as e:  # the failure belongs in the run's record (stdout), not only on stderr
+        print(json.dumps({"failed": type(e).__name__, "message": str(e)[:500]}), flush=True)
+        raise
