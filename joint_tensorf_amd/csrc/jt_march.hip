@@ -446,6 +446,10 @@ __device__ inline float sel3f(int i, float a, float b, float c) { return i == 0 
 // cannot return before the flush atomics of step q - 1 have retired, ~3 000 cycles with every CU issuing; what hides
 // that is more independent chains per CU.  Per-plane items are three times as many chains of a third of the length, and
 // one walker instead of three fits 6 waves per SIMD instead of 4 (and nothing spills).
+#ifndef JT_WALK_PF
+#define JT_WALK_PF 2  // tap prefetch distance of the density walk in steps (4 at five waves per SIMD, 5 at four: the same time on
+                      // both grids -- 0.43 ms Blender, 0.82-0.84 ms LLFF -- the walk does not wait for its taps)
+#endif
 #ifndef JT_WALK_WAVES
 #define JT_WALK_WAVES 6  // waves per SIMD the walk is compiled for: 80 registers, nothing spills (7: 72 registers, 9 spilled)
 #endif
@@ -521,7 +525,6 @@ __global__ __launch_bounds__(256, JT_WALK_WAVES) void k_march_bwd_walk(Dev D, Jt
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-      TapBuf<NCH> bufA, bufB, bufC;
       auto step = [&](TapBuf<NCH>& tv, int q) {
         const float* rq = rec + q * kWalkRecW;
         const float gc = rq[18], zc = rq[19];
@@ -538,17 +541,19 @@ __global__ __launch_bounds__(256, JT_WALK_WAVES) void k_march_bwd_walk(Dev D, Jt
         gol += ail;
         gdl += ail * zc;
       };
-      // taps two steps ahead of the step that consumes them (three buffers in rotation)
-      wk.load(bufA, P, L, rec);
-      wk.load(bufB, P, L, rec + kWalkRecW);
+      // taps JT_WALK_PF steps ahead of the step that consumes them (JT_WALK_PF + 1 buffers in rotation)
+      constexpr int PF = JT_WALK_PF;
+      TapBuf<NCH> buf[PF + 1];
+#pragma unroll
+      for (int u = 0; u < PF; ++u) wk.load(buf[u], P, L, rec + u * kWalkRecW);
 #pragma unroll 1
-      for (int q = 0; q < kWalkSub; q += 3) {
-        if (q + 2 < kWalkSub) wk.load(bufC, P, L, rec + (q + 2) * kWalkRecW);
-        step(bufA, q);
-        if (q + 3 < kWalkSub) wk.load(bufA, P, L, rec + (q + 3) * kWalkRecW);
-        if (q + 1 < kWalkSub) step(bufB, q + 1);
-        if (q + 4 < kWalkSub) wk.load(bufB, P, L, rec + (q + 4) * kWalkRecW);
-        if (q + 2 < kWalkSub) step(bufC, q + 2);
+      for (int q0 = 0; q0 < kWalkSub; q0 += PF + 1) {
+#pragma unroll
+        for (int u = 0; u <= PF; ++u) {
+          const int q = q0 + u;
+          if (q + PF < kWalkSub) wk.load(buf[(u + PF) % (PF + 1)], P, L, rec + (q + PF) * kWalkRecW);
+          if (q < kWalkSub) step(buf[u], q);
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
