@@ -232,6 +232,14 @@ struct RecWalker {
   // out-of-range taps count as zeros).
   __device__ inline void add(TapBuf<NCH>& tv, const float* rec, const float g[NCH], float& aix, float& aiy,
                              float& ail) {
+#if JT_ABL_WALK_PAD  // profiling knob: N extra vector instructions per step -- is a walker bound by instruction issue?
+    {
+      float pad = aix;
+#pragma unroll
+      for (int i = 0; i < JT_ABL_WALK_PAD; ++i) asm volatile("v_add_f32 %0, %0, %0" : "+v"(pad));
+      asm volatile("" ::"v"(pad));
+    }
+#endif
     const float4 w = *reinterpret_cast<const float4*>(rec + 8);
     const float4 x = *reinterpret_cast<const float4*>(rec + 12);  // lw0, lw1, cxA, cxB
     const float2 y = *reinterpret_cast<const float2*>(rec + 16);  // cyA, cyB
