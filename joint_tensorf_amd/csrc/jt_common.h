@@ -243,6 +243,43 @@ __device__ inline float4 ld4q(const float* base, unsigned byte_off, int q) {
   return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off)[q];
 }
 
+// XCD-aware work placement (cdna_hip_programming.md T1): consecutive workgroup ids are dealt round-robin to the eight XCDs, each
+// with its own 4 MB L2, so "blockIdx % 8" labels the workgroups that share an L2.  xcd_swizzle gives every label a CONTIGUOUS
+// range of the n work items (bijective for any n): neighbouring rays / tiles -- which gather neighbouring texels -- then meet
+// in one L2 instead of being spread over all eight.  A speed choice only: any placement computes the same thing.
+#ifndef JT_XCD_SWIZZLE
+#define JT_XCD_SWIZZLE 1
+#endif
+__device__ inline int xcd_swizzle(int id, int n) {
+#if JT_XCD_SWIZZLE
+  const int q = n >> 3, r = n & 7, x = id & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+#else
+  return id;
+#endif
+}
+// the same for a persistent kernel: this workgroup's label, its rank among the workgroups of that label, how many of them there
+// are, and the [lo, hi) range of the n items the label owns
+struct XcdShare {
+  int lo, hi, rank, peers;
+};
+// `blocks`: the workgroups that take part (ids 0 .. blocks - 1; a kernel whose grid was sized for a worst case lets the rest
+// return before they load anything)
+__device__ inline XcdShare xcd_share(int n, int blocks) {
+  XcdShare s;
+#if JT_XCD_SWIZZLE
+  const int g = min(blocks, 8), x = (int)blockIdx.x % g;
+  const int q = n / g, r = n - q * g;
+  s.lo = x * q + min(x, r);
+  s.hi = s.lo + q + (x < r ? 1 : 0);
+  s.rank = (int)blockIdx.x / g;
+  s.peers = (blocks - x + g - 1) / g;
+#else
+  s.lo = 0, s.hi = n, s.rank = blockIdx.x, s.peers = blocks;
+#endif
+  return s;
+}
+
 // order-independent accumulation: v as 2^48 fixed point into a 64-bit word
 __device__ inline void fixed_add(long long* p, float v) {
   const long long w = (fabsf(v) < 8192.f) ? __double2ll_rn((double)v * kFixedScale) : kFixedPoison;  // NaN fails the test

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void k_march_fwd(Dev D, const float* __restric
                                                    uint16_t* __restrict__ sidx, float* __restrict__ opacity,
                                                    float* __restrict__ depth) {
   const int lane = threadIdx.x & 63;
-  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // (workgroups that share an XCD take neighbouring rays: in a full-image render those are neighbouring pixels)
+  const int ray = xcd_swizzle(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
   if (ray >= R) return;
   Ray r;
   load_ray(D, rays_o, rays_d, jitter, nullptr, ray, r);

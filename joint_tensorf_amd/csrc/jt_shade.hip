@@ -44,14 +44,16 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
   extern __shared__ __align__(16) float smem[];
   const int total = min(offset[R], cap);
   const int ntiles = (total + 31) >> 5;
-  if ((int)blockIdx.x * 4 >= ntiles) return;
+  const int nblk = min((int)gridDim.x, (ntiles + 3) / 4);  // the grid is sized for the worst case
+  if ((int)blockIdx.x >= nblk) return;
   load_weights_lds<C>(smem, M);
   __syncthreads();
   // (the wave index as a scalar: everything derived from it -- tile, record block -- stays in scalar registers)
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j_ = lane & 31, h_ = lane >> 5;
   constexpr int HOFF = (C::KIND == JT_MLP_FEA) ? 0 : 12;
-  for (int tile = blockIdx.x * 4 + wv; tile < ntiles; tile += gridDim.x * 4) {
+  const XcdShare xs = xcd_share(ntiles, nblk);  // tiles of neighbouring samples meet in one XCD's L2
+  for (int tile = xs.lo + xs.rank * 4 + wv; tile < xs.hi; tile += xs.peers * 4) {
     int j = j_, h = h_;  // see k_shade_bwd: keeps per-lane address math from being hoisted out of the loop
     asm volatile("" : "+v"(j), "+v"(h));
     const int e = tile * 32 + j;
@@ -130,14 +132,16 @@ __global__ __launch_bounds__(JT_B16_THREADS) void k_shade_fwd_b16(Dev D, MlpDev 
   const int total = min(offset[R], cap);
   const int ntiles = (total + 31) >> 5;
   constexpr int NW = JT_B16_THREADS / 64;
-  if ((int)blockIdx.x * NW >= ntiles) return;
+  const int nblk = min((int)gridDim.x, (ntiles + NW - 1) / NW);  // the grid is sized for the worst case
+  if ((int)blockIdx.x >= nblk) return;
   load_weights_lds_b16<C>(smem_raw, M);
   __syncthreads();
   // (the wave index as a scalar: everything derived from it -- tile, record block -- stays in scalar registers)
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j_ = lane & 31, h_ = lane >> 5;
   constexpr int HOFF = (C::KIND == JT_MLP_FEA) ? 0 : 12;
-  for (int tile = blockIdx.x * NW + wv; tile < ntiles; tile += gridDim.x * NW) {
+  const XcdShare xs = xcd_share(ntiles, nblk);  // tiles of neighbouring samples meet in one XCD's L2
+  for (int tile = xs.lo + xs.rank * NW + wv; tile < xs.hi; tile += xs.peers * NW) {
     int j = j_, h = h_;  // see k_shade_bwd: keeps per-lane address math from being hoisted out of the loop
     asm volatile("" : "+v"(j), "+v"(h));
     const int e = tile * 32 + j;
@@ -293,7 +297,8 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
   const int total = min(offset[R], cap);
   const int n_chunk = min(total - chunk_start, chunk_cap);
   const int ntiles = (n_chunk + 31) >> 5;
-  if ((int)blockIdx.x * B::NWAVE >= ntiles) return;  // chunk beyond the shaded samples: nothing to do
+  const int nblk = min((int)gridDim.x, (ntiles + B::NWAVE - 1) / B::NWAVE);  // the grid is sized for the worst case
+  if ((int)blockIdx.x >= nblk) return;  // chunk beyond the shaded samples: nothing to do
   load_weights_lds<C>(smem, M);
   __syncthreads();
   // (the wave index as a scalar: everything derived from it -- tile, record block -- stays in scalar registers)
@@ -304,7 +309,8 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
   float* gxyz = geo + 32 * 4;
   const size_t RC = B::REC_FLOATS;
   constexpr int HOFF = (C::KIND == JT_MLP_FEA) ? 0 : 12;
-  for (int tile = blockIdx.x * B::NWAVE + wv; tile < ntiles; tile += gridDim.x * B::NWAVE) {
+  const XcdShare xs = xcd_share(ntiles, nblk);  // tiles of neighbouring samples meet in one XCD's L2
+  for (int tile = xs.lo + xs.rank * B::NWAVE + wv; tile < xs.hi; tile += xs.peers * B::NWAVE) {
     // re-materialise the lane indices per tile: otherwise every per-lane LDS address / select that depends
     // on them is hoisted out of the tile loop as a loop invariant and the kernel spills hundreds of VGPRs
     int j = j_, h = h_;
