@@ -447,6 +447,9 @@ __device__ inline float sel3f(int i, float a, float b, float c) { return i == 0 
 // cannot return before the flush atomics of step q - 1 have retired, ~3 000 cycles with every CU issuing; what hides
 // that is more independent chains per CU.  Per-plane items are three times as many chains of a third of the length, and
 // one walker instead of three fits 6 waves per SIMD instead of 4 (and nothing spills).
+#ifndef JT_WALK_PLANE_MAJOR
+#define JT_WALK_PLANE_MAJOR 0  // measured: 0.444 ms against 0.434 ray-major (Blender), 0.869 against 0.834 (LLFF)
+#endif
 #ifndef JT_WALK_PF
 #define JT_WALK_PF 2  // tap prefetch distance of the density walk in steps (4 at five waves per SIMD, 5 at four: the same time on
                       // both grids -- 0.43 ms Blender, 0.82-0.84 ms LLFF -- the walk does not wait for its taps)
@@ -472,11 +475,23 @@ __global__ __launch_bounds__(256, JT_WALK_WAVES) void k_march_bwd_walk(Dev D, Jt
   const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
   // (ray, plane) of the wave: scalar
   const long witem = (long)blockIdx.x * 16 + (grp & ~3);
+#if JT_WALK_PLANE_MAJOR
+  // plane-major item order (an experiment, off): the whole grid walks plane 0, then plane 1, then plane 2, so that the taps
+  // in flight chip-wide come out of ONE 10 MB plane (400^2 x 16 channels) instead of all three.  It is 2-4 % slower than
+  // keeping a ray's three planes together
+  const long per_plane = (long)R * runs_per_ray;
+  const int pl = __builtin_amdgcn_readfirstlane((int)(witem / per_plane));
+  if (pl >= 3) return;
+  const long wi = witem - (long)pl * per_plane;
+  const int ray = __builtin_amdgcn_readfirstlane((int)(wi / runs_per_ray));
+  const int rem = __builtin_amdgcn_readfirstlane(pl * runs_per_ray + (int)(wi - (long)ray * runs_per_ray));
+#else
   const int per_ray = 3 * runs_per_ray;
   const int ray = __builtin_amdgcn_readfirstlane((int)(witem / per_ray));
   if (ray >= R) return;
   const int rem = __builtin_amdgcn_readfirstlane((int)(witem - (long)ray * per_ray));
   const int pl = __builtin_amdgcn_readfirstlane(rem / runs_per_ray);
+#endif
   const int run = rem - pl * runs_per_ray + (grp & 3);
   const int nv = nvalid[ray];
   const int k0 = run * kWalkRun;
