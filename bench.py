@@ -436,6 +436,20 @@ def run_extras():
                     out[name]["density_backward_listed_samples"] = db["samples_per_launch"]
         except Exception as ex:  # a secondary number must never cost the headline line
             out[name] = {"error": repr(ex)[:200]}
+    # BASELINE.json configs[4]: the full 800 x 800 novel-view render at 1 024 depth samples (32 768-ray slices captured as
+    # hipGraphs) and a test-time pose-optimisation iteration, dense random-init scene and the sparse blob scene
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "eval_bench.py")
+    for name, flags in (("eval_800x800_S1024_hipgraph", ["--graph"]),
+                        ("eval_800x800_S1024_blob_scene_hipgraph", ["--graph", "--scene", "blobs"])):
+        try:
+            r = subprocess.run([sys.executable, tool] + flags, capture_output=True, text=True, timeout=300)
+            j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            out[name] = {"ms_per_image": j["eval_render"]["ms_per_image"], "rays_per_s": j["eval_render"]["rays_per_s"],
+                         "Msamples_per_s": j["eval_render"]["Msamples_per_s"], "launch": j["eval_render"]["launch"],
+                         "test_time_pose_optim_ms_per_iter": j["test_time_optim"]["ms_per_iter"],
+                         "test_time_pose_optim_rays_per_iter": j["test_time_optim"]["rays_per_iter"]}
+        except Exception as ex:
+            out[name] = {"error": repr(ex)[:200]}
     return out
 
 
