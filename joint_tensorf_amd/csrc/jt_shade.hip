@@ -537,7 +537,7 @@ __device__ inline void mask_tail(float v[16], int h, int nl) {
 // Work split of a weight-gradient GEMM over `blocks` workgroups of four waves: every wave takes `per` consecutive 32-sample
 // tiles, at least kWgradMinTiles of them, so a chunk with few shaded samples (a trained scene shades a few per cent of what
 // the random-init scene does) occupies only as many workgroups as it can feed -- the others return at once, write no slab,
-// and k_wgrad_reduce, which recomputes the same split, does not read theirs.  Measured on the converged synthetic scene
+// and k_wgrad_reduce4, which recomputes the same split, does not read theirs.  Measured on the converged synthetic scene
 // (1.9 k tiles, replayed step): 1 tile per wave 0.963 ms, 2: 0.960, 4: 0.951, 8: 0.988 -- a wave's tiles are a chain of
 // dependent row loads (~12 us each for dBasis), so few workgroups with long chains lose what the smaller epilogue wins.
 #ifndef JT_WGRAD_MIN_TILES
@@ -556,7 +556,7 @@ __device__ inline int wgrad_active_blocks(int n, int blocks) {
 
 // epilogue of the weight-gradient GEMMs: sum the four waves' tiles through LDS and park the block's partial result in its
 // slab (plain 256-byte stores).  Many blocks atomically adding into the same few-KB weight matrix would run at a fraction of
-// the float-atomic rate, so the cross-block sum is a second, deterministic pass (k_wgrad_reduce).
+// the float-atomic rate, so the cross-block sum is a second, deterministic pass (k_wgrad_reduce4).
 template <int MT, int NT>
 __device__ inline void wgrad_epilogue(f32x16 (*acc)[NT], const float* asum, float (*s_red)[16][64], float* slab, int lane,
                                       int wv, int m, int h) {
