@@ -128,13 +128,23 @@ __global__ __launch_bounds__(256) void k_reg_batch_fwd(RegBatch B, float* __rest
     factor_reg_fwd_body<false>(T.x, T.H, T.W, T.C, scratch36 + T.slot * 3, bid, T.nblocks);
 }
 
-__global__ __launch_bounds__(256) void k_reg_batch_bwd(RegBatch B, const float* __restrict__ coef36, int accumulate) {
+// (the coefficient triple of the block's tensor from the upstream gradients g3 = dL/d{L1, TV_density, TV_color} is three
+//  divisions: every block works it out for itself instead of a launch of its own in front of this one)
+__global__ __launch_bounds__(256) void k_reg_batch_bwd(RegBatch B, const float* __restrict__ g3, int accumulate) {
   int it = 0;
 #pragma unroll 1
   for (int i = 1; i < B.n; ++i)
     if ((int)blockIdx.x >= B.t[i].block0) it = i;
   const RegBatchItem& T = B.t[it];
-  factor_reg_bwd_body(T.x, T.H, T.W, T.C, coef36 + T.slot * 3, T.g, accumulate, blockIdx.x - T.block0, T.nblocks);
+  const int i = T.slot;  // 0-2 density planes, 3-5 density lines, 6-8 appearance planes
+  float coef[3] = {0.f, 0.f, 0.f};
+  if (i < 6) coef[0] = g3[0] / ((float)T.H * T.W * T.C);
+  if (i < 3 || i >= 6) {
+    const float gt = i < 3 ? g3[1] : g3[2];
+    if (T.H > 1) coef[1] = gt * 2e-2f / ((float)T.C * (T.H - 1) * T.W);
+    if (T.W > 1) coef[2] = gt * 2e-2f / ((float)T.C * T.H * (T.W - 1));
+  }
+  factor_reg_bwd_body(T.x, T.H, T.W, T.C, coef, T.g, accumulate, blockIdx.x - T.block0, T.nblocks);
 }
 
 __global__ void k_reg_zero(float* __restrict__ p, int n) {
@@ -204,24 +214,6 @@ __global__ void k_reg_combine(const float* __restrict__ sums, RegSet S, float* _
   out3[2] = tva;
 }
 
-// coefficient triple of tensor i from the upstream gradients g3 = dL/d{L1, TV_density, TV_color}
-__global__ void k_reg_coefs(const float* __restrict__ g3, RegSet S, float* __restrict__ coef) {
-  const int i = threadIdx.x;
-  if (i >= 12) return;
-  const RegTensor& a = S.t[i];
-  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-  if (i < 6) c0 = g3[0] / ((float)a.H * a.W * a.C);
-  const bool dplane = i < 3, aplane = (i >= 6 && i < 9);
-  if (dplane || aplane) {
-    const float gt = dplane ? g3[1] : g3[2];
-    if (a.H > 1) c1 = gt * 2e-2f / ((float)a.C * (a.H - 1) * a.W);
-    if (a.W > 1) c2 = gt * 2e-2f / ((float)a.C * a.H * (a.W - 1));
-  }
-  coef[i * 3] = c0;
-  coef[i * 3 + 1] = c1;
-  coef[i * 3 + 2] = c2;
-}
-
 }  // namespace jt
 
 static int reg_set(const JtFactors* f, const JtFactors* g, const int32_t* hw, int Cd, int Ca, RegSet* S) {
@@ -278,8 +270,6 @@ extern "C" int jt_reg_losses_backward(const JtFactors* factors, const int32_t* p
   if (rc) return rc;
   if (!g3 || !scratch36 || !g_factors) return JT_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_reg_coefs, dim3(1), dim3(64), 0, st, g3, S, scratch36);
-  JT_LAUNCH_CHECK();
   RegBatch B;
   B.n = 0;
   int nblk = 0;
@@ -295,7 +285,7 @@ extern "C" int jt_reg_losses_backward(const JtFactors* factors, const int32_t* p
     B.t[B.n++] = {t.x, t.g, t.H, t.W, t.C, 0, i, nblk, blocks};
     nblk += blocks;
   }
-  hipLaunchKernelGGL(k_reg_batch_bwd, dim3(nblk), dim3(256), 0, st, B, (const float*)scratch36, accumulate ? 1 : 0);
+  hipLaunchKernelGGL(k_reg_batch_bwd, dim3(nblk), dim3(256), 0, st, B, g3, accumulate ? 1 : 0);
   JT_LAUNCH_CHECK();
   return JT_OK;
 }
