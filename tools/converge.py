@@ -27,6 +27,10 @@ def build(args, device="cuda:0"):
         over["data"]["llff_baseline"] = args.llff_baseline
     if getattr(args, "llff_focus", 0):
         over["data"]["llff_focus"] = args.llff_focus
+    if getattr(args, "gt_z_range", None):
+        over["data"]["gt_z_range"] = [float(v) for v in args.gt_z_range.split(",")]
+    if getattr(args, "gt_wall", 0):
+        over["data"]["gt_wall"] = args.gt_wall
     opt = make_options(args.config, device=device, **over)
     if args.image_size:
         h, w = opt.data.image_size
@@ -81,6 +85,8 @@ def main():
     ap.add_argument("--report-every", type=int, default=0)
     ap.add_argument("--llff-baseline", type=float, default=0.0)
     ap.add_argument("--llff-focus", type=float, default=0.0)
+    ap.add_argument("--gt-z-range", default=None, help="LLFF scene: fraction range of the box's z the blobs sit in, e.g. 0.6,0.9")
+    ap.add_argument("--gt-wall", type=float, default=0.0, help="LLFF scene: z fraction of the back wall")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     opt, model = build(args)
