@@ -2,7 +2,7 @@
 # usage: tools/pmc_sq.sh <tag> [bench args...]  -- SQ counters per kernel (own pass, kernel-trace only)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && export JT_NO_AUX=1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_SALU --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/sq_$tag -o k -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline "$@" > $GRAFT_REPO_ROOT/gpurun_out/sq_$tag.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_SALU --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/sq_$tag -o k -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-probe --no-torch-baseline --no-extras "$@" > $GRAFT_REPO_ROOT/gpurun_out/sq_$tag.log 2>&1
 cd $GRAFT_REPO_ROOT
 python - <<'PY' gpurun_out/sq_$tag/k_counter_collection.csv
 import csv, sys

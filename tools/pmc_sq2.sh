@@ -2,7 +2,7 @@
 # usage: tools/pmc_sq2.sh <tag> [bench args...]  -- second set of SQ counters per kernel (LDS / VMEM pressure)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && export JT_NO_AUX=1
-rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_INSTS_BRANCH --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/sq2_$tag -o k -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline "$@" > $GRAFT_REPO_ROOT/gpurun_out/sq2_$tag.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_INSTS_BRANCH --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/sq2_$tag -o k -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-probe --no-torch-baseline --no-extras "$@" > $GRAFT_REPO_ROOT/gpurun_out/sq2_$tag.log 2>&1
 cd $GRAFT_REPO_ROOT
 python - <<'PY' gpurun_out/sq2_$tag/k_counter_collection.csv
 import csv, sys
