@@ -141,6 +141,9 @@ __global__ __launch_bounds__(JT_B16_THREADS) void k_shade_fwd_b16(Dev D, MlpDev 
   const int j_ = lane & 31, h_ = lane >> 5;
   constexpr int HOFF = (C::KIND == JT_MLP_FEA) ? 0 : 12;
   const XcdShare xs = xcd_share(ntiles, nblk);  // tiles of neighbouring samples meet in one XCD's L2
+#if JT_SETPRIO
+  if (wv >= NW / 2) __builtin_amdgcn_s_setprio(1);  // static priority for the later-dispatched wave of every SIMD: measured, no effect
+#endif
   for (int tile = xs.lo + xs.rank * NW + wv; tile < xs.hi; tile += xs.peers * NW) {
     int j = j_, h = h_;  // see k_shade_bwd: keeps per-lane address math from being hoisted out of the loop
     asm volatile("" : "+v"(j), "+v"(h));
@@ -310,6 +313,9 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
   const size_t RC = B::REC_FLOATS;
   constexpr int HOFF = (C::KIND == JT_MLP_FEA) ? 0 : 12;
   const XcdShare xs = xcd_share(ntiles, nblk);  // tiles of neighbouring samples meet in one XCD's L2
+#if JT_SETPRIO
+  if (wv >= B::NWAVE / 2) __builtin_amdgcn_s_setprio(1);
+#endif
   for (int tile = xs.lo + xs.rank * B::NWAVE + wv; tile < xs.hi; tile += xs.peers * B::NWAVE) {
     // re-materialise the lane indices per tile: otherwise every per-lane LDS address / select that depends
     // on them is hoisted out of the tile loop as a loop invariant and the kernel spills hundreds of VGPRs
