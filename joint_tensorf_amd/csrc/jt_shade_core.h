@@ -580,6 +580,9 @@ struct BwdCfg;
 #ifndef JT_B16_PIPE
 #define JT_B16_PIPE 1
 #endif
+#ifndef JT_B16_PF_INFER
+#define JT_B16_PF_INFER 1  // (2 pairs ahead measured the same 174 ms per 800 x 800 image)
+#endif
 #ifndef JT_B16_THREADS
 #define JT_B16_THREADS 512
 #endif
@@ -634,23 +637,21 @@ __device__ inline f32x16 gather_basis_b16(const Dev& D, const uint4* img, const 
     }
   };
   constexpr int NP = 3 * Q::SPP;   // pairs of quad slots = K steps
-  TapSlot buf[2][2];
-  if (JT_B16_PIPE) {
-    load_slot(0, 0, buf[0][0]);
-    if (1 < C::NSLOT) load_slot(0, 1, buf[0][1]);
-  }
+  // taps PF pairs ahead of the pair that is multiplied (PF + 1 buffers in rotation; 0 = fetched where they are used).  The
+  // training forward has registers for one pair ahead; the inference / pose-only forwards could afford two, which measures the same.
+  constexpr int PF = !JT_B16_PIPE ? 0 : (REC ? 1 : JT_B16_PF_INFER);
+  TapSlot buf[PF + 1][2];
+  auto load_pair = [&](int p, TapSlot* b) {
+    const int ip = p / Q::SPP, s2 = p - ip * Q::SPP;
+    load_slot(ip, 2 * s2, b[0]);
+    if (2 * s2 + 1 < C::NSLOT) load_slot(ip, 2 * s2 + 1, b[1]);
+  };
+#pragma unroll
+  for (int p = 0; p < PF && p < NP; ++p) load_pair(p, buf[p]);
 #pragma unroll
   for (int pp = 0; pp < NP; ++pp) {
     const int i = pp / Q::SPP, sp = pp - i * Q::SPP;
-    if (JT_B16_PIPE && pp + 1 < NP) {  // the next pair's taps go out before this pair is touched
-      const int i1 = (pp + 1) / Q::SPP, sp1 = (pp + 1) - i1 * Q::SPP;
-      load_slot(i1, 2 * sp1, buf[(pp + 1) & 1][0]);
-      if (2 * sp1 + 1 < C::NSLOT) load_slot(i1, 2 * sp1 + 1, buf[(pp + 1) & 1][1]);
-    }
-    if (!JT_B16_PIPE) {
-      load_slot(i, 2 * sp, buf[pp & 1][0]);
-      if (2 * sp + 1 < C::NSLOT) load_slot(i, 2 * sp + 1, buf[pp & 1][1]);
-    }
+    if (pp + PF < NP) load_pair(pp + PF, buf[(pp + PF) % (PF + 1)]);
     __builtin_amdgcn_sched_barrier(0);
     const TapGeo& g = geo[i];
     float bv8[8];
@@ -658,7 +659,7 @@ __device__ inline f32x16 gather_basis_b16(const Dev& D, const uint4* img, const 
     for (int half = 0; half < 2; ++half) {
       const int m = 2 * sp + half;
       if (m < C::NSLOT) {
-        const TapSlot& s = buf[pp & 1][half];
+        const TapSlot& s = buf[pp % (PF + 1)][half];
         const bool live = C::CA % 8 == 0 || (2 * m + h) * 4 < C::CA;
         float pr[4];
         pr[0] = (g.w00 * s.a.x + g.w10 * s.b.x + g.w01 * s.c.x + g.w11 * s.d.x) * (g.lw0 * s.u.x + g.lw1 * s.v.x);
