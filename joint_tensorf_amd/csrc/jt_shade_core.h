@@ -628,6 +628,15 @@ __device__ inline f32x16 gather_basis_b16(const Dev& D, const uint4* img, const 
     s.a = s.b = s.c = s.d = make_float4(g.w00, g.w10, g.w01, g.w11), s.u = s.v = make_float4(g.lw0, g.lw1, g.w00, g.w11);
     return;
 #endif
+#if JT_ABL_SAMETEX  // profiling knob: every tap of every sample reads texel 0 (same instructions, all L1 hits)
+    {
+      const unsigned z = hb & 16u;
+      s.a = ld4q(P, z, 2 * m), s.b = ld4q(P, z, 2 * m), s.c = ld4q(P, z, 2 * m), s.d = ld4q(P, z, 2 * m);
+      s.u = ld4q(L, z, 2 * m), s.v = ld4q(L, z, 2 * m);
+      asm volatile("" : "+v"(s.a.x), "+v"(s.b.x), "+v"(s.c.x), "+v"(s.d.x), "+v"(s.u.x), "+v"(s.v.x));
+      return;
+    }
+#endif
     if (C::CA % 8 == 0 || m + 1 < C::NSLOT) {
       s.a = ld4q(P, g.b00, 2 * m), s.b = ld4q(P, g.b10, 2 * m), s.c = ld4q(P, g.b01, 2 * m), s.d = ld4q(P, g.b11, 2 * m);
       s.u = ld4q(L, g.bl0, 2 * m), s.v = ld4q(L, g.bl1, 2 * m);
