@@ -111,6 +111,13 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
 }
 
 
+#if JT_STAMP
+// profiling build only (tools/build_variant.py -DJT_STAMP=1): cycles a wave of k_shade_fwd_b16 spends per phase of a tile,
+// summed over all waves and tiles; read and cleared by jt_debug_read_stamps (tools/stamp_fwd.py)
+__device__ unsigned long long g_stamps[8];
+#define JT_STAMP_T() (__builtin_readcyclecounter())
+#endif
+
 // The same forward with the three matrix stages on the bf16 matrix cores at fp32-level accuracy (jt_shade_core.h, "bf16x3"):
 // one workgroup of eight waves per CU around a 114 KB pre-split weight image.  Selected by JT_BF16X3 (launch_shade_fwd_t).
 template <class C, int REC>
@@ -141,6 +148,9 @@ __global__ __launch_bounds__(JT_B16_THREADS) void k_shade_fwd_b16(Dev D, MlpDev 
   const int j_ = lane & 31, h_ = lane >> 5;
   constexpr int HOFF = (C::KIND == JT_MLP_FEA) ? 0 : 12;
   const XcdShare xs = xcd_share(ntiles, nblk);  // tiles of neighbouring samples meet in one XCD's L2
+#if JT_STAMP
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
 #if JT_SETPRIO
   if (wv >= NW / 2) __builtin_amdgcn_s_setprio(1);  // static priority for the later-dispatched wave of every SIMD: measured, no effect
 #endif
@@ -160,10 +170,19 @@ __global__ __launch_bounds__(JT_B16_THREADS) void k_shade_fwd_b16(Dev D, MlpDev 
         rec_st(rec_at(rt, B::R_GEO + c, 4u * (unsigned)j), g.n[c]);
       }
     }
+#if JT_STAMP
+    const unsigned long long ts0 = JT_STAMP_T();
+#endif
     f32x16 facc = gather_basis_b16<C, REC == 1>(D, img, g.n, j, h, lane, rt, on);
     if (REC) rec_store<1>(rt, B::R_F, &facc, j, h, on);
+#if JT_STAMP
+    const unsigned long long ts1 = JT_STAMP_T();
+#endif
     Hidden<C> h1 = layer1_b16<C>(img, tail, facc, vd, pm, h, lane);
     relu_<C>(h1);
+#if JT_STAMP
+    const unsigned long long ts2 = JT_STAMP_T();
+#endif
     if (REC) {
       unsigned mask1 = 0u;
 #pragma unroll
@@ -173,8 +192,14 @@ __global__ __launch_bounds__(JT_B16_THREADS) void k_shade_fwd_b16(Dev D, MlpDev 
       if (on) rec_st(rec_at(rt, B::R_MASK, 4u * (unsigned)j + 128u * (unsigned)h), __uint_as_float(mask1));
       if (REC == 1) rec_store<C::MT>(rt, B::R_H1, h1.v, j, h, on);
     }
+#if JT_STAMP
+    const unsigned long long ts3 = JT_STAMP_T();
+#endif
     Hidden<C> h2 = layer2_b16<C>(img, tail, h1, h, lane);
     relu_<C>(h2);
+#if JT_STAMP
+    const unsigned long long ts4 = JT_STAMP_T();
+#endif
     if (REC) {
       unsigned mask2 = 0u;
 #pragma unroll
@@ -198,7 +223,22 @@ __global__ __launch_bounds__(JT_B16_THREADS) void k_shade_fwd_b16(Dev D, MlpDev 
 #pragma unroll
       for (int c = 0; c < 3; ++c) rgb_s[(size_t)e * 3 + c] = 1.f / (1.f + expf(-o[c]));
     }
+#if JT_STAMP
+    const unsigned long long ts5 = JT_STAMP_T();
+    st_acc[0] += ts1 - ts0;   // gather + products + basis product (+ F records)
+    st_acc[1] += ts2 - ts1;   // encodings + layer 1
+    st_acc[2] += ts3 - ts2;   // ReLU words + H1 records
+    st_acc[3] += ts4 - ts3;   // layer 2
+    st_acc[4] += ts5 - ts4;   // ReLU words + MID records + layer 3 + colours
+    st_acc[5] += 1ull;        // tiles
+#endif
   }
+#if JT_STAMP
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_stamps[i], st_acc[i]);
+  }
+#endif
 }
 
 
@@ -981,6 +1021,14 @@ static int chunk_entries() {
   }
   return 1 << g_chunk_log2;
 }
+#if JT_STAMP
+extern "C" int jt_debug_read_stamps(unsigned long long* out8) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return JT_ERR_ARG;
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return JT_ERR_ARG;
+  return JT_OK;
+}
+#endif
 extern "C" int jt_shade_chunk_entries(void) { return chunk_entries(); }
 extern "C" int jt_shade_matrix_mode(void) { return bf16x3_mode(); }
 extern "C" int jt_shade_set_matrix_mode(int mode) {
