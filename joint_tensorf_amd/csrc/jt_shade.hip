@@ -21,6 +21,9 @@
 
 #include "jt_shade_core.h"
 
+#ifndef JT_B16_PINGPONG
+#define JT_B16_PINGPONG 1
+#endif
 #ifndef JT_BF16X3_DEFAULT
 #define JT_BF16X3_DEFAULT 3
 #endif
@@ -148,21 +151,32 @@ __global__ __launch_bounds__(JT_B16_THREADS) void k_shade_fwd_b16(Dev D, MlpDev 
   const int j_ = lane & 31, h_ = lane >> 5;
   constexpr int HOFF = (C::KIND == JT_MLP_FEA) ? 0 : 12;
   const XcdShare xs = xcd_share(ntiles, nblk);  // tiles of neighbouring samples meet in one XCD's L2
-#if JT_STAMP
-  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
-#endif
 #if JT_SETPRIO
   if (wv >= NW / 2) __builtin_amdgcn_s_setprio(1);  // static priority for the later-dispatched wave of every SIMD: measured, no effect
 #endif
-  for (int tile = xs.lo + xs.rank * NW + wv; tile < xs.hi; tile += xs.peers * NW) {
+  // A tile is a GATHER step (taps, products, basis product: half of a wave's time, most of it waiting for the texture path)
+  // and a COMPUTE step (encodings, layers, records: vector and matrix instructions).  JT_B16_PINGPONG: the two waves of a
+  // SIMD (w and w + NW / 2) take the steps in opposite order with a workgroup barrier between steps, so that one of them
+  // computes while the other gathers instead of both queueing for the same unit.
+  const int stride = xs.peers * NW;
+  const int first = xs.lo + xs.rank * NW;
+  const int iters0 = first < xs.hi ? (xs.hi - first + stride - 1) / stride : 0;  // tiles of the workgroup's wave 0: uniform
+  f32x16 facc;
+  float vd[3] = {0.f, 0.f, 0.f};
+  int e = 0;
+  bool on = false, have = false;
+  float* rt = nullptr;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) facc[r] = 0.f;
+  auto gather_step = [&](int tile) {
     int j = j_, h = h_;  // see k_shade_bwd: keeps per-lane address math from being hoisted out of the loop
     asm volatile("" : "+v"(j), "+v"(h));
-    const int e = tile * 32 + j;
-    const bool on = e < total;
+    e = tile * 32 + j;
+    on = e < total;
     const int ee = on ? e : total - 1;
-    float* rt = REC ? rec + (size_t)tile * B::REC_FLOATS * 32 : nullptr;
+    rt = REC ? rec + (size_t)tile * B::REC_FLOATS * 32 : nullptr;
     EntryGeom g = entry_geom(D, rays_o, rays_d, jitter, zvals, tmin, eray, esmp, ee);
-    float vd[3] = {vdir[(size_t)ee * 3], vdir[(size_t)ee * 3 + 1], vdir[(size_t)ee * 3 + 2]};
+    vd[0] = vdir[(size_t)ee * 3], vd[1] = vdir[(size_t)ee * 3 + 1], vd[2] = vdir[(size_t)ee * 3 + 2];
     if (REC && on && h == 0) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -170,19 +184,14 @@ __global__ __launch_bounds__(JT_B16_THREADS) void k_shade_fwd_b16(Dev D, MlpDev 
         rec_st(rec_at(rt, B::R_GEO + c, 4u * (unsigned)j), g.n[c]);
       }
     }
-#if JT_STAMP
-    const unsigned long long ts0 = JT_STAMP_T();
-#endif
-    f32x16 facc = gather_basis_b16<C, REC == 1>(D, img, g.n, j, h, lane, rt, on);
+    facc = gather_basis_b16<C, REC == 1>(D, img, g.n, j, h, lane, rt, on);
     if (REC) rec_store<1>(rt, B::R_F, &facc, j, h, on);
-#if JT_STAMP
-    const unsigned long long ts1 = JT_STAMP_T();
-#endif
+  };
+  auto compute_step = [&]() {
+    int j = j_, h = h_;
+    asm volatile("" : "+v"(j), "+v"(h));
     Hidden<C> h1 = layer1_b16<C>(img, tail, facc, vd, pm, h, lane);
     relu_<C>(h1);
-#if JT_STAMP
-    const unsigned long long ts2 = JT_STAMP_T();
-#endif
     if (REC) {
       unsigned mask1 = 0u;
 #pragma unroll
@@ -192,14 +201,8 @@ __global__ __launch_bounds__(JT_B16_THREADS) void k_shade_fwd_b16(Dev D, MlpDev 
       if (on) rec_st(rec_at(rt, B::R_MASK, 4u * (unsigned)j + 128u * (unsigned)h), __uint_as_float(mask1));
       if (REC == 1) rec_store<C::MT>(rt, B::R_H1, h1.v, j, h, on);
     }
-#if JT_STAMP
-    const unsigned long long ts3 = JT_STAMP_T();
-#endif
     Hidden<C> h2 = layer2_b16<C>(img, tail, h1, h, lane);
     relu_<C>(h2);
-#if JT_STAMP
-    const unsigned long long ts4 = JT_STAMP_T();
-#endif
     if (REC) {
       unsigned mask2 = 0u;
 #pragma unroll
@@ -223,20 +226,24 @@ __global__ __launch_bounds__(JT_B16_THREADS) void k_shade_fwd_b16(Dev D, MlpDev 
 #pragma unroll
       for (int c = 0; c < 3; ++c) rgb_s[(size_t)e * 3 + c] = 1.f / (1.f + expf(-o[c]));
     }
-#if JT_STAMP
-    const unsigned long long ts5 = JT_STAMP_T();
-    st_acc[0] += ts1 - ts0;   // gather + products + basis product (+ F records)
-    st_acc[1] += ts2 - ts1;   // encodings + layer 1
-    st_acc[2] += ts3 - ts2;   // ReLU words + H1 records
-    st_acc[3] += ts4 - ts3;   // layer 2
-    st_acc[4] += ts5 - ts4;   // ReLU words + MID records + layer 3 + colours
-    st_acc[5] += 1ull;        // tiles
-#endif
+  };
+#if JT_B16_PINGPONG
+  const int half = (wv >= NW / 2) ? 1 : 0;
+  for (int step = 0; step < 2 * iters0 + 1; ++step) {
+    if ((step & 1) == half) {
+      const int tile = first + wv + ((step - half) >> 1) * stride;
+      have = tile < xs.hi;
+      if (have) gather_step(tile);
+    } else if (have) {
+      compute_step();
+      have = false;
+    }
+    __syncthreads();
   }
-#if JT_STAMP
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) atomicAdd(&g_stamps[i], st_acc[i]);
+#else
+  for (int tile = first + wv; tile < xs.hi; tile += stride) {
+    gather_step(tile);
+    compute_step();
   }
 #endif
 }

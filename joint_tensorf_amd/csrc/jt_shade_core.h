@@ -580,6 +580,9 @@ struct BwdCfg;
 #ifndef JT_B16_PIPE
 #define JT_B16_PIPE 1
 #endif
+#ifndef JT_B16_PIN_TAPS
+#define JT_B16_PIN_TAPS 0
+#endif
 #ifndef JT_B16_PF_INFER
 #define JT_B16_PF_INFER 1  // (2 pairs ahead measured the same 174 ms per 800 x 800 image)
 #endif
@@ -662,6 +665,26 @@ __device__ inline f32x16 gather_basis_b16(const Dev& D, const uint4* img, const 
     const int i = pp / Q::SPP, sp = pp - i * Q::SPP;
     if (pp + PF < NP) load_pair(pp + PF, buf[(pp + PF) % (PF + 1)]);
     __builtin_amdgcn_sched_barrier(0);
+    // JT_B16_PIN_TAPS: pin the consumption of this pair's taps BEHIND the loads just issued for the next pair.  Without it
+    // the instruction selector, which orders pure arithmetic by data dependence only, places the products of a pair directly
+    // behind that pair's own loads -- one region earlier -- and the "prefetch" waits for every load right after issuing it
+    // (s_waitcnt vmcnt(11) ... vmcnt(0) behind twelve loads; with the pins: vmcnt(23) ... vmcnt(12)).  Measured with the
+    // pins: training forward 0.502 ms against 0.485 without, eval render 155 against 157 ms -- the gather phase is not
+    // waiting for the latency of its own loads (profiles/round3_forward_phase_stamps.txt), so the pins stay off.
+    if (JT_B16_PIN_TAPS && PF > 0) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (2 * sp + half < C::NSLOT) {
+          TapSlot& t = buf[pp % (PF + 1)][half];
+          asm volatile("" : "+v"(t.a.x), "+v"(t.a.y), "+v"(t.a.z), "+v"(t.a.w));
+          asm volatile("" : "+v"(t.b.x), "+v"(t.b.y), "+v"(t.b.z), "+v"(t.b.w));
+          asm volatile("" : "+v"(t.c.x), "+v"(t.c.y), "+v"(t.c.z), "+v"(t.c.w));
+          asm volatile("" : "+v"(t.d.x), "+v"(t.d.y), "+v"(t.d.z), "+v"(t.d.w));
+          asm volatile("" : "+v"(t.u.x), "+v"(t.u.y), "+v"(t.u.z), "+v"(t.u.w));
+          asm volatile("" : "+v"(t.v.x), "+v"(t.v.y), "+v"(t.v.z), "+v"(t.v.w));
+        }
+      }
+    }
     const TapGeo& g = geo[i];
     float bv8[8];
 #pragma unroll
