@@ -155,97 +155,108 @@ __global__ __launch_bounds__(JT_B16_THREADS) void k_shade_fwd_b16(Dev D, MlpDev 
   if (wv >= NW / 2) __builtin_amdgcn_s_setprio(1);  // static priority for the later-dispatched wave of every SIMD: measured, no effect
 #endif
   // A tile is a GATHER step (taps, products, basis product: half of a wave's time, most of it waiting for the texture path)
-  // and a COMPUTE step (encodings, layers, records: vector and matrix instructions).  JT_B16_PINGPONG: the two waves of a
-  // SIMD (w and w + NW / 2) take the steps in opposite order with a workgroup barrier between steps, so that one of them
-  // computes while the other gathers instead of both queueing for the same unit.
+  // and a COMPUTE step (encodings, layers, records: vector and matrix instructions).  JT_B16_PINGPONG (inference only, below):
+  // the two waves of a SIMD (w and w + NW / 2) take the steps in opposite order with a workgroup barrier between steps, so
+  // that one of them computes while the other gathers instead of both queueing for the same unit.
   const int stride = xs.peers * NW;
   const int first = xs.lo + xs.rank * NW;
   const int iters0 = first < xs.hi ? (xs.hi - first + stride - 1) / stride : 0;  // tiles of the workgroup's wave 0: uniform
   f32x16 facc;
-  float vd[3] = {0.f, 0.f, 0.f};
+  float vd0 = 0.f, vd1 = 0.f, vd2 = 0.f;  // (scalars: an array captured by reference below ends up in scratch memory)
   int e = 0;
   bool on = false, have = false;
   float* rt = nullptr;
 #pragma unroll
   for (int r = 0; r < 16; ++r) facc[r] = 0.f;
-  auto gather_step = [&](int tile) {
-    int j = j_, h = h_;  // see k_shade_bwd: keeps per-lane address math from being hoisted out of the loop
-    asm volatile("" : "+v"(j), "+v"(h));
-    e = tile * 32 + j;
-    on = e < total;
-    const int ee = on ? e : total - 1;
-    rt = REC ? rec + (size_t)tile * B::REC_FLOATS * 32 : nullptr;
-    EntryGeom g = entry_geom(D, rays_o, rays_d, jitter, zvals, tmin, eray, esmp, ee);
-    vd[0] = vdir[(size_t)ee * 3], vd[1] = vdir[(size_t)ee * 3 + 1], vd[2] = vdir[(size_t)ee * 3 + 2];
-    if (REC && on && h == 0) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        if (REC == 1) rec_st(rec_at(rt, B::R_VD + c, 4u * (unsigned)j), vd[c]);
-        rec_st(rec_at(rt, B::R_GEO + c, 4u * (unsigned)j), g.n[c]);
-      }
-    }
-    facc = gather_basis_b16<C, REC == 1>(D, img, g.n, j, h, lane, rt, on);
-    if (REC) rec_store<1>(rt, B::R_F, &facc, j, h, on);
-  };
-  auto compute_step = [&]() {
-    int j = j_, h = h_;
-    asm volatile("" : "+v"(j), "+v"(h));
-    Hidden<C> h1 = layer1_b16<C>(img, tail, facc, vd, pm, h, lane);
-    relu_<C>(h1);
-    if (REC) {
-      unsigned mask1 = 0u;
-#pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mask1 |= (h1.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
-      if (on) rec_st(rec_at(rt, B::R_MASK, 4u * (unsigned)j + 128u * (unsigned)h), __uint_as_float(mask1));
-      if (REC == 1) rec_store<C::MT>(rt, B::R_H1, h1.v, j, h, on);
-    }
-    Hidden<C> h2 = layer2_b16<C>(img, tail, h1, h, lane);
-    relu_<C>(h2);
-    if (REC) {
-      unsigned mask2 = 0u;
-#pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mask2 |= (h2.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
-      if (on) rec_st(rec_at(rt, B::R_MASK + 2, 4u * (unsigned)j + 128u * (unsigned)h), __uint_as_float(mask2));
-      if (REC == 1) rec_store<C::MT>(rt, B::R_MID + HOFF, h2.v, j, h, on);
-      if (REC == 1 && C::KIND != JT_MLP_FEA) {
-        float pe[12];
-        view_pe(vd, pm, pe);
-        if (on && h == 0) {
-#pragma unroll
-          for (int k = 0; k < 12; ++k) rec_st(rec_at(rt, B::R_MID + k, 4u * (unsigned)j), pe[k]);
-        }
-      }
-    }
-    float o[3];
-    layer3<C>(smem, h2, vd, pm, h, o);
-    if (on && h == 0) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) rgb_s[(size_t)e * 3 + c] = 1.f / (1.f + expf(-o[c]));
-    }
-  };
-#if JT_B16_PINGPONG
-  const int half = (wv >= NW / 2) ? 1 : 0;
-  for (int step = 0; step < 2 * iters0 + 1; ++step) {
-    if ((step & 1) == half) {
-      const int tile = first + wv + ((step - half) >> 1) * stride;
-      have = tile < xs.hi;
-      if (have) gather_step(tile);
-    } else if (have) {
-      compute_step();
-      have = false;
-    }
-    __syncthreads();
+  // (the two steps as macros, not lambdas: captured by reference, the 20-channel instantiation kept 192 bytes of its state in
+  //  scratch memory and its forward went from 0.117 to 0.144 ms)
+#define JT_FWD_GATHER_STEP \
+  {                                                                                                                    \
+    int j = j_, h = h_; \
+    asm volatile("" : "+v"(j), "+v"(h)); \
+    e = tile * 32 + j; \
+    on = e < total; \
+    const int ee = on ? e : total - 1; \
+    rt = REC ? rec + (size_t)tile * B::REC_FLOATS * 32 : nullptr; \
+    EntryGeom g = entry_geom(D, rays_o, rays_d, jitter, zvals, tmin, eray, esmp, ee); \
+    vd0 = vdir[(size_t)ee * 3], vd1 = vdir[(size_t)ee * 3 + 1], vd2 = vdir[(size_t)ee * 3 + 2]; \
+    const float vd[3] = {vd0, vd1, vd2}; \
+    if (REC && on && h == 0) { \
+_Pragma("unroll") \
+      for (int c = 0; c < 3; ++c) { \
+        if (REC == 1) rec_st(rec_at(rt, B::R_VD + c, 4u * (unsigned)j), vd[c]); \
+        rec_st(rec_at(rt, B::R_GEO + c, 4u * (unsigned)j), g.n[c]); \
+      } \
+    } \
+    facc = gather_basis_b16<C, REC == 1>(D, img, g.n, j, h, lane, rt, on); \
+    if (REC) rec_store<1>(rt, B::R_F, &facc, j, h, on); \
   }
-#else
-  for (int tile = first + wv; tile < xs.hi; tile += stride) {
-    gather_step(tile);
-    compute_step();
+#define JT_FWD_COMPUTE_STEP \
+  {                                                                                                                    \
+    int j = j_, h = h_; \
+    asm volatile("" : "+v"(j), "+v"(h)); \
+    const float vd[3] = {vd0, vd1, vd2}; \
+    Hidden<C> h1 = layer1_b16<C>(img, tail, facc, vd, pm, h, lane); \
+    relu_<C>(h1); \
+    if (REC) { \
+      unsigned mask1 = 0u; \
+_Pragma("unroll") \
+      for (int mt = 0; mt < C::MT; ++mt) \
+_Pragma("unroll") \
+        for (int r = 0; r < 16; ++r) mask1 |= (h1.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u; \
+      if (on) rec_st(rec_at(rt, B::R_MASK, 4u * (unsigned)j + 128u * (unsigned)h), __uint_as_float(mask1)); \
+      if (REC == 1) rec_store<C::MT>(rt, B::R_H1, h1.v, j, h, on); \
+    } \
+    Hidden<C> h2 = layer2_b16<C>(img, tail, h1, h, lane); \
+    relu_<C>(h2); \
+    if (REC) { \
+      unsigned mask2 = 0u; \
+_Pragma("unroll") \
+      for (int mt = 0; mt < C::MT; ++mt) \
+_Pragma("unroll") \
+        for (int r = 0; r < 16; ++r) mask2 |= (h2.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u; \
+      if (on) rec_st(rec_at(rt, B::R_MASK + 2, 4u * (unsigned)j + 128u * (unsigned)h), __uint_as_float(mask2)); \
+      if (REC == 1) rec_store<C::MT>(rt, B::R_MID + HOFF, h2.v, j, h, on); \
+      if (REC == 1 && C::KIND != JT_MLP_FEA) { \
+        float pe[12]; \
+        view_pe(vd, pm, pe); \
+        if (on && h == 0) { \
+_Pragma("unroll") \
+          for (int k = 0; k < 12; ++k) rec_st(rec_at(rt, B::R_MID + k, 4u * (unsigned)j), pe[k]); \
+        } \
+      } \
+    } \
+    float o[3]; \
+    layer3<C>(smem, h2, vd, pm, h, o); \
+    if (on && h == 0) { \
+_Pragma("unroll") \
+      for (int c = 0; c < 3; ++c) rgb_s[(size_t)e * 3 + c] = 1.f / (1.f + expf(-o[c])); \
+    } \
   }
-#endif
+  // in lock step only where it pays: the inference forward of the 48-channel scene (800 x 800 eval render 168 -> 157 ms); the
+  // training forward is unchanged by it (0.485 / 0.479 ms) and the 20-channel one, whose gather step is short, loses
+  // (0.117 -> 0.153 ms)
+  if (JT_B16_PINGPONG && REC == 0 && C::CA >= 48) {
+    const int half = (wv >= NW / 2) ? 1 : 0;
+    for (int step = 0; step < 2 * iters0 + 1; ++step) {
+      if ((step & 1) == half) {
+        const int tile = first + wv + ((step - half) >> 1) * stride;
+        have = tile < xs.hi;
+        if (have) JT_FWD_GATHER_STEP
+      } else if (have) {
+        JT_FWD_COMPUTE_STEP
+        have = false;
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int tile = first + wv; tile < xs.hi; tile += stride) {
+      JT_FWD_GATHER_STEP
+      JT_FWD_COMPUTE_STEP
+    }
+  }
+#undef JT_FWD_GATHER_STEP
+#undef JT_FWD_COMPUTE_STEP
 }
 
 
@@ -360,6 +371,8 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
   const size_t RC = B::REC_FLOATS;
   constexpr int HOFF = (C::KIND == JT_MLP_FEA) ? 0 : 12;
   const XcdShare xs = xcd_share(ntiles, nblk);  // tiles of neighbouring samples meet in one XCD's L2
+  // (the two waves of a SIMD taking the chain and the scatter of their tiles in opposite order, in lock step by a workgroup
+  //  barrier as in the inference forward, was measured here as well: 1.51 ms against 1.33 free-running, LLFF 0.68 / 0.65)
 #if JT_SETPRIO
   if (wv >= B::NWAVE / 2) __builtin_amdgcn_s_setprio(1);
 #endif
