@@ -585,12 +585,14 @@ __device__ inline float pe_pick(int b, float x, float sn, float cs, float m0, fl
 // the 16 samples [16 h, 16 h + 16) of one record row (zeros for a dead row): four 16-byte loads
 __device__ inline void load_row_half(const float* __restrict__ row, bool live, int h, float out[16]) {
 #pragma unroll
+  // (the load itself is unconditional -- callers clamp the row -- and a dead row is zeroed by selects: a load under a per-lane
+  //  condition is a branch around it, and with loads under control flow the wait-count pass waits for everything)
   for (int q = 0; q < 4; ++q) {
-    const float4 v = live ? ld4(row + 16 * h + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-    out[4 * q] = v.x;
-    out[4 * q + 1] = v.y;
-    out[4 * q + 2] = v.z;
-    out[4 * q + 3] = v.w;
+    const float4 v = ld4(row + 16 * h + 4 * q);
+    out[4 * q] = live ? v.x : 0.f;
+    out[4 * q + 1] = live ? v.y : 0.f;
+    out[4 * q + 2] = live ? v.z : 0.f;
+    out[4 * q + 3] = live ? v.w : 0.f;
   }
 }
 
@@ -783,6 +785,20 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ rec, in
   wgrad_epilogue<MT, NT>(acc, asum, s_red, slab, lane, wv, m, h);
 }
 
+// Keep the use of sixteen prefetched values BEHIND whatever loads were issued in front of this point.  The instruction selector
+// orders pure arithmetic by data dependence only: without a pin it places the consumer of a row directly behind that row's own
+// loads, i.e. in front of the NEXT row's prefetch, and the "one step ahead" of the loops below turns into a full wait
+// (s_waitcnt vmcnt(0)) behind every load (JT_WGRAD_PIN = 0 shows it in the listing).
+#ifndef JT_WGRAD_PIN
+#define JT_WGRAD_PIN 1
+#endif
+__device__ inline void pin16(float v[16]) {
+#if JT_WGRAD_PIN
+#pragma unroll
+  for (int q = 0; q < 16; q += 4) asm volatile("" : "+v"(v[q]), "+v"(v[q + 1]), "+v"(v[q + 2]), "+v"(v[q + 3]));
+#endif
+}
+
 // The same skinny GEMM on the bf16 matrix cores at fp32-level accuracy (jt_shade_core.h, "bf16x3"): both operands are
 // per-sample data here, so both are split in registers -- (MT + NT) x 16 values per lane and tile -- and a tile's 32 samples
 // are two 16-deep K steps (lane half h feeds samples 16 h + 8 s .. + 7 to step s: the contraction order is free as long as
@@ -848,13 +864,21 @@ __global__ __launch_bounds__(256) void k_wgrad_b16(const float* __restrict__ rec
       const int nl = min(32, n - t * 32);
 #pragma unroll
       for (int b = 0; b < NT; ++b) {
+        // (unconditionally -- the last step of the last tile fetches its own rows again: with the loads under control flow the
+        //  wait-count pass gives up and waits for everything)
         if (b + 1 < NT) {
           loadB(t, b + 1, bn);
-        } else if (t + 1 < t_end) {
-          loadA(t + 1, an);
-          loadB(t + 1, 0, bn);
+        } else {
+          const int tn = min(t + 1, t_end - 1);
+          loadA(tn, an);
+          loadB(tn, 0, bn);
         }
-        if (b == 0) prepA(av, nl, a3);
+        if (b == 0) {
+#pragma unroll
+          for (int a = 0; a < MT; ++a) pin16(av[a]);
+          prepA(av, nl, a3);
+        }
+        pin16(bv);
         if (nl < 32) mask_tail(bv, h, nl);  // never-written record slots may hold anything, 0 * NaN is NaN
         const B3 b0 = split8(bv), b1 = split8(bv + 8);
 #pragma unroll
@@ -882,10 +906,14 @@ __global__ __launch_bounds__(256) void k_wgrad_b16(const float* __restrict__ rec
     }
     for (int t = t_begin; t < t_end; ++t) {
       const int nl = min(32, n - t * 32);
-      if (t + 1 < t_end) {
-        loadA(t + 1, an);
-        load_row_half(rec + (size_t)(t + 1) * tstride + (size_t)srow * 32, live, h, xn);
+      {
+        const int tn = min(t + 1, t_end - 1);  // (unconditionally, see above)
+        loadA(tn, an);
+        load_row_half(rec + (size_t)tn * tstride + (size_t)srow * 32, live, h, xn);
       }
+      pin16(x);
+#pragma unroll
+      for (int a = 0; a < MT; ++a) pin16(av[a]);
       if (nl < 32) mask_tail(x, h, nl);  // never-written record slots may hold anything, 0 * NaN is NaN
       prepA(av, nl, a3);
       float sn[16], cs[16];
