@@ -325,6 +325,14 @@ def pmc_traffic_instep(roof, hidden=None):
             return {"traffic": None}  # another workload than the one the counters were collected on
         out = {"traffic": k["hbm_bytes_per_sample"] * n, "traffic_unit": "bytes/launch",
                "traffic_source": "profiles/round3_default_pmc_traffic.json", "traffic_detail": rec}
+        try:
+            # matrix-pipe / vector-instruction / texture-path busy fractions of the big kernels and the launches of a step,
+            # from the committed SQ / TA counter passes and kernel trace of this same command (profiles/round3_sq_counters.txt)
+            busy = json.load(open(os.path.join(ROOT, "profiles", "round3_default_pipe_busy.json")))
+            out["pipe_busy"] = dict(busy["kernels"], source="profiles/round3_default_pipe_busy.json")
+            out["launches_per_step_profiled"] = busy["launches_per_step_profiled"]
+        except Exception:
+            pass
         if hidden:
             # the second bound of a scatter kernel: the chip retires ~20.9 G float-atomic 64-byte segments per second
             # whatever the access pattern (tools/atomic_rate.hip, profiles/round2_atomic_rate.txt).  Segments of a launch =
