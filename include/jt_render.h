@@ -251,6 +251,15 @@ int jt_shade_record_layout(const JtScene* scene, int32_t* out);
  * a fixed order, and the ray gradients of jt_march_backward are combined in fixed point inside its workspace.  Returns
  * the previous setting; any argument other than 0 / 1 only queries.  A debugging aid (race detection), slower. */
 int jt_set_deterministic(int on);
+/* Device-side failure reporting of the gradient scatters (the reference's NaN checks, model/tensorf.py:43-44,147-151).  The
+ * ray (pose) gradients of jt_march_backward, and in JT_DETERMINISTIC mode the factor gradients, are summed in 2^48 fixed
+ * point; an addend that is NaN, infinite or >= 8 192 in magnitude is dropped and raises a sticky flag inside the library.
+ * While the flag is up jt_march_backward writes NaN into g_rays_o / g_rays_d (as the float sums it replaces would have
+ * carried it) and ORs JT_STATUS_FINITE_GRAD into the int32 status word bound with jt_status_bind (device memory, may be
+ * NULL: nothing is reported then).  jt_status_clear zeroes the flag and the bound word on `stream`. */
+#define JT_STATUS_FINITE_GRAD 8
+int jt_status_bind(int32_t* status_word);
+int jt_status_clear(void* stream);
 int jt_shade_chunk_entries(void);
 /* Which matrix stages of the appearance path run on the bf16 matrix cores with every fp32 operand split into three bf16
  * pieces and six products accumulated per K step (fp32-level accuracy; the reference's fp32 torch.nn.Linear chain,
@@ -262,6 +271,14 @@ int jt_shade_chunk_entries(void);
 int jt_shade_matrix_mode(void);
 int jt_shade_set_matrix_mode(int mode);
 int jt_shade_set_chunk_log2(int log2_entries);
+/* How jt_shade_backward runs the per-sample part of the appearance backward (the autograd of bateRF.py:97-130 +
+ * tensorBase.py:116-126): 0 = one kernel (MLP backward chain and the factor-gradient scatter of a 32-sample tile in the same
+ * wave); 8 / 16 = two launches, the chain (which leaves the feature gradients in the record rows) and a scatter kernel at
+ * its own occupancy whose 16-lane groups walk runs of that many consecutive samples.  Same gradients up to the order of the
+ * float sums.  The environment variable JT_BWD_SPLIT (read once) overrides the build default; the setter returns the previous
+ * value (any other argument only queries). */
+int jt_shade_bwd_split(void);
+int jt_shade_set_bwd_split(int run);
 int jt_shade_forward(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp, const float* rays_o,
                      const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
                      const int32_t* shade_offset, int n_rays, const int32_t* entry_ray,

@@ -92,10 +92,14 @@ SIGNATURES = {
     "jt_shade_record_layout": (I, [SP, P]),
     "jt_finite_check": (I, [P, I, P, P]),
     "jt_set_deterministic": (I, [I]),
+    "jt_status_bind": (I, [P]),
+    "jt_status_clear": (I, [P]),
     "jt_shade_chunk_entries": (I, []),
     "jt_shade_matrix_mode": (I, []),
     "jt_shade_set_matrix_mode": (I, [I]),
     "jt_shade_set_chunk_log2": (I, [I]),
+    "jt_shade_bwd_split": (I, []),
+    "jt_shade_set_bwd_split": (I, [I]),
     "jt_render_loss_forward": (I, [P, P, P, P, I, I, I, F, F, P, P, P]),
     "jt_render_loss_backward": (I, [P, P, P, P, I, I, I, F, F, P, P, P, P]),
     "jt_render_loss_forward_ind": (I, [P, P, P, I, I, I, I, F, F, P, P, P]),

@@ -75,11 +75,15 @@ inline int make_dev(const JtScene* s, const JtFactors* f, Dev* d) {
 // slower, and the callers hand int64 shadow buffers where the header says so.
 int jt_deterministic();                      // defined in jt_march.hip
 // 2^48: 3.6e-15 resolution, +-32 768 range (a gradient element of this path is far below 1; round 2 used 2^56, whose
-// +-128 wrapped silently).  A non-finite addend is replaced by kFixedPoison = 2^61 (value 8 192): sums at or above 2^60
-// in magnitude are what the caller's conversion flags (ops.py: FINITE_GRAD bit of the status word), so an overflow or a
-// NaN can no longer pass as a wrong-but-plausible gradient.
+// +-128 wrapped silently).  An addend that is non-finite or out of range adds NOTHING and raises the library's sticky
+// "bad fixed-point addend" flag instead (round 3 added a poison magnitude of 2^61 to the sum, which wrapped: eight poisoned
+// addends are 0 mod 2^64); a sum that leaves the safe range through in-range addends is caught by its magnitude (>= 2^60,
+// value 4 096).  Whoever converts a sum back (k_rays_fixed_add, ops.py's deterministic path) writes NaN / sets the
+// FINITE_GRAD bit of the bound status word when either is seen, so neither can pass as a wrong-but-plausible gradient.
 constexpr double kFixedScale = 281474976710656.0;
-constexpr long long kFixedPoison = 1ll << 61;
+constexpr long long kFixedLimit = 1ll << 60;
+// device address of the sticky flag (one word per process, owned by jt_march.hip; cleared by jt_status_clear)
+unsigned* fixed_bad_flag();
 
 #define JT_LAUNCH_CHECK()                      \
   do {                                         \
@@ -281,9 +285,11 @@ __device__ inline XcdShare xcd_share(int n, int blocks) {
 }
 
 // order-independent accumulation: v as 2^48 fixed point into a 64-bit word
-__device__ inline void fixed_add(long long* p, float v) {
-  const long long w = (fabsf(v) < 8192.f) ? __double2ll_rn((double)v * kFixedScale) : kFixedPoison;  // NaN fails the test
-  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)w);
+__device__ inline void fixed_add(long long* p, float v, unsigned* bad) {
+  if (fabsf(v) < 8192.f)  // NaN fails the test
+    atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn((double)v * kFixedScale));
+  else
+    atomicOr(bad, 1u);
 }
 
 __device__ inline float wave_sum(float v) {

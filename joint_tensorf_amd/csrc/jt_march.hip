@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, JT_WALK_WAVES) void k_march_bwd_walk(Dev D, Jt
                                                         const uint16_t* __restrict__ vlist,
                                                         const int* __restrict__ nvalid, int runs_per_ray,
                                                         float* __restrict__ g_rays_o, float* __restrict__ g_rays_d,
-                                                        long long* __restrict__ rays_fixed) {
+                                                        long long* __restrict__ rays_fixed, unsigned* __restrict__ bad) {
   constexpr int NCH = (CD + 15) / 16;
   // + 16 words per group: the four groups of a wave read their own records in the same instruction, and a group
   // stride that is a multiple of the 64 LDS banks would put all four on the same banks
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256, JT_WALK_WAVES) void k_march_bwd_walk(Dev D, Jt
   const int a0 = pl == 2 ? 1 : 0, a1 = pl == 0 ? 1 : 2, a2 = 2 - pl;
   RecWalker<NCH, CD, DET ? 1 : 0> wk;
   wk.init(pl == 0 ? G.density_plane[0] : (pl == 1 ? G.density_plane[1] : G.density_plane[2]),
-          pl == 0 ? G.density_line[0] : (pl == 1 ? G.density_line[1] : G.density_line[2]), cl, DET);
+          pl == 0 ? G.density_line[0] : (pl == 1 ? G.density_line[1] : G.density_line[2]), cl, DET, bad);
   const float sx = 0.5f * (float)(W - 1) * sel3f(a0, D.inv[0], D.inv[1], D.inv[2]),
               sy = 0.5f * (float)(H - 1) * sel3f(a1, D.inv[0], D.inv[1], D.inv[2]),
               sl = 0.5f * (float)(LL - 1) * sel3f(a2, D.inv[0], D.inv[1], D.inv[2]);
@@ -593,19 +593,33 @@ __global__ __launch_bounds__(256, JT_WALK_WAVES) void k_march_bwd_walk(Dev D, Jt
     // ALWAYS in fixed point (integer atomics commute): the pose gradient does not depend on the order in which the runs of
     // a ray arrive -- test-time pose optimisation and the camera trajectory of a training run are reproducible bit for bit
     // in their density part, for one extra 5 us launch (k_rays_fixed_add)
-    fixed_add(rays_fixed + (size_t)ray * 6 + (c < 3 ? 0 : 3) + ax, v);
+    fixed_add(rays_fixed + (size_t)ray * 6 + (c < 3 ? 0 : 3) + ax, v, bad);
   }
 }
 
-// g_rays_o/d [R][3] += fixed-point sums [R][6]
+// g_rays_o/d [R][3] += fixed-point sums [R][6].  A sum out of the format's safe range becomes NaN, and so does EVERY ray
+// gradient while the sticky bad-addend flag is up (a NaN / infinite / huge addend was dropped somewhere in this process's
+// fixed-point sums since the flag was last cleared: what float atomics would have carried into the pose as a NaN must not
+// turn into a finite number); either way the FINITE_GRAD bit goes into the bound status word (jt_status_bind).
 __global__ void k_rays_fixed_add(const long long* __restrict__ f, int R, float* __restrict__ g_rays_o,
-                                 float* __restrict__ g_rays_d) {
+                                 float* __restrict__ g_rays_d, const unsigned* __restrict__ bad,
+                                 int32_t* __restrict__ status) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= R * 6) return;
   const int ray = i / 6, c = i - ray * 6;
-  const float v = (float)((double)f[i] / kFixedScale);
+  const long long w = f[i];
+  const bool poisoned = (*bad != 0u) || w >= kFixedLimit || w <= -kFixedLimit;
+  const float v = poisoned ? __builtin_nanf("") : (float)((double)w / kFixedScale);
   if (c < 3) g_rays_o[ray * 3 + c] += v;
   else g_rays_d[ray * 3 + (c - 3)] += v;
+  if (poisoned && status) atomicOr(status, JT_STATUS_FINITE_GRAD);
+}
+
+// the sticky flag of fixed_add (jt_common.h) and the status word the library reports into
+__device__ unsigned g_fixed_bad;
+__global__ void k_status_clear(int32_t* status) {
+  g_fixed_bad = 0u;
+  if (status) *status = 0;
 }
 
 // opacity of one step of `length` at arbitrary points (BatBase.compute_alpha, batBase.py:27-41): the dense
@@ -634,6 +648,23 @@ static int check_density_shape(const Dev& D) {
 }
 
 extern "C" int jt_version(void) { return JT_VERSION; }
+
+unsigned* jt::fixed_bad_flag() {
+  static unsigned* p = nullptr;  // (one GPU per process: SURVEY 8(e))
+  if (!p && hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(g_fixed_bad)) != hipSuccess) p = nullptr;
+  return p;
+}
+static std::atomic<int32_t*> g_status_word{nullptr};
+extern "C" int jt_status_bind(int32_t* status_word) {
+  g_status_word.store(status_word, std::memory_order_relaxed);
+  return JT_OK;
+}
+extern "C" int jt_status_clear(void* stream) {
+  if (!jt::fixed_bad_flag()) return JT_ERR_ARG;
+  hipLaunchKernelGGL(k_status_clear, dim3(1), dim3(1), 0, (hipStream_t)stream, g_status_word.load(std::memory_order_relaxed));
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
 
 static std::atomic<int> g_deterministic{-1};  // -1: not yet read from the environment
 int jt::jt_deterministic() {
@@ -795,6 +826,8 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
                      n_rays, sigma_feat, weight, tmin, shade_offset, shade_idx, rgb_s, clamp_mask, g_rgb, g_opacity,
                      g_xyz_app, gfeat, vlist, nvalid, g_rays_o, g_rays_d, rays_fixed, Spad);
   JT_LAUNCH_CHECK();
+  unsigned* bad = jt::fixed_bad_flag();
+  if (!bad) return JT_ERR_ARG;
   const int runs = ((D.S + kWalkRun - 1) / kWalkRun + 3) & ~3;  // a wave's four groups: four runs of ONE (ray, plane)
   const long items = (long)n_rays * runs * 3;
   const int blocks = (int)((items + 15) / 16);
@@ -802,10 +835,10 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
   do {                                                                                                           \
     if (det)                                                                                                     \
       hipLaunchKernelGGL((k_march_bwd_walk<CD_, true>), dim3(blocks), dim3(256), 0, st, D, GF, rays_o, rays_d,   \
-                         jitter, zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d, rays_fixed); \
+                         jitter, zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d, rays_fixed, bad); \
     else                                                                                                         \
       hipLaunchKernelGGL((k_march_bwd_walk<CD_, false>), dim3(blocks), dim3(256), 0, st, D, GF, rays_o, rays_d,  \
-                         jitter, zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d, rays_fixed); \
+                         jitter, zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d, rays_fixed, bad); \
   } while (0)
   if (D.Cd == 16) JT_WALK(16);
   else if (D.Cd == 8) JT_WALK(8);
@@ -814,7 +847,7 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
 #undef JT_WALK
   JT_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_rays_fixed_add, dim3((n_rays * 6 + 255) / 256), dim3(256), 0, st, rays_fixed, n_rays, g_rays_o,
-                     g_rays_d);
+                     g_rays_d, bad, g_status_word.load(std::memory_order_relaxed));
   JT_LAUNCH_CHECK();
   return JT_OK;
 }

@@ -291,13 +291,13 @@ __device__ inline int walk_slot(int j) { return j ^ (((j >> 3) & 1) * 7); }
 
 template <class C, bool DET>
 __device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, const float* tp, const float* recs,
-                                     float* gxyz, int lane) {
+                                     float* gxyz, int lane, unsigned* bad) {
   constexpr int NCH = (C::CA + 15) / 16;
   const int grp = lane >> 4, cl = lane & 15;
   const float* P = D.aP[pl];
   const float* Ln = D.aL[pl];
   RecWalker<NCH, C::CA, DET ? 1 : 0> wk;  // (instantiated per accumulation mode: float atomics / 2^56 fixed point)
-  wk.init(G.app_plane[pl], G.app_line[pl], cl, DET);
+  wk.init(G.app_plane[pl], G.app_line[pl], cl, DET, bad);
   const int m0 = kM0(pl), m1 = kM1(pl), mv = kV(pl);
   // lanes 0..2 of a group add the x / y / line coordinate gradient of the step to gxyz[sample][axis]
   const int my_axis = (cl == 0) ? m0 : (cl == 1) ? m1 : mv;
@@ -346,13 +346,15 @@ __device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, c
   wk.finish_pair(grp);
 }
 
-template <class C, bool DET>
+// SPLIT: the chain only -- the feature gradients leave through the GF record rows (always written then) and the scatter runs
+// as its own launch (k_shade_scatter below); the wave's LDS is then just the 8 KB sin / cos stash.
+template <class C, bool DET, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm, JtFactors G,
                                                       const int* __restrict__ offset, int R,
                                                       const float* __restrict__ rgb_s,
                                                       const float* __restrict__ g_rgb_s, float* __restrict__ g_xyz,
                                                       float* __restrict__ rec, int chunk_start, int chunk_cap,
-                                                      int cap, int ablate) {
+                                                      int cap, int ablate, unsigned* __restrict__ bad) {
   typedef BwdCfg<C> B;
   extern __shared__ __align__(16) float smem[];
   const int total = min(offset[R], cap);
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
   // (the wave index as a scalar: everything derived from it -- tile, record block -- stays in scalar registers)
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j_ = lane & 31, h_ = lane >> 5;
-  float* tp = smem + C::LDS_FLOATS + wv * B::WAVE_FLOATS;
+  float* tp = smem + C::LDS_FLOATS + wv * (SPLIT ? B::STASH_FLOATS : B::WAVE_FLOATS);
   float* geo = tp + B::TP_ROWS * B::TP_LD;
   float* gxyz = geo + 32 * 4;
   const size_t RC = B::REC_FLOATS;
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
     const bool onrec = on && !(ablate & 2);
     float* rt = rec + (size_t)tile * RC * 32;  // this tile's record block (layer inputs left by the forward)
     const int jj = on ? j : nlive - 1;         // padding lanes mirror the last live sample
-    if (h == 0) {
+    if (!SPLIT && h == 0) {
       geo[j * 4 + 0] = rec_ld(rec_at(rt, B::R_GEO + 0, 4u * (unsigned)jj));
       geo[j * 4 + 1] = rec_ld(rec_at(rt, B::R_GEO + 1, 4u * (unsigned)jj));
       geo[j * 4 + 2] = rec_ld(rec_at(rt, B::R_GEO + 2, 4u * (unsigned)jj));
@@ -504,10 +506,10 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       if (rowmap(r, 0) + 4 * h >= C::APP) gf[r] = 0.f;
-    rec_store<1>(rt, B::R_GF, &gf, j, h, onrec);
+    rec_store<1>(rt, B::R_GF, &gf, j, h, SPLIT ? on : onrec);
     // ---- basis_mat^T and the scatter, plane by plane ----
 #pragma unroll 1
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < (SPLIT ? 0 : 3); ++pl) {
       f32x16 gp[B::PT];
 #pragma unroll
       for (int T = 0; T < B::PT; ++T) {
@@ -543,14 +545,215 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
                       recs + pj * kRecWords);
       }
       wave_lds_sync();
-      if (!(ablate & 1)) scatter_plane<C, DET>(D, G, pl, tp, recs, gxyz, lane);
+      if (!(ablate & 1)) scatter_plane<C, DET>(D, G, pl, tp, recs, gxyz, lane, bad);
       wave_lds_sync();
     }
-    if (on && h == 0) {
+    if (!SPLIT && on && h == 0) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) g_xyz[(size_t)e * 3 + a] = gxyz[pj * 4 + a];
     }
     wave_lds_sync();
+  }
+}
+
+// ---- split backward: the scatter as its own launch -------------------------------------------------------------------
+// k_shade_bwd<SPLIT> leaves the feature gradients GF [APP][32 samples] of every tile in the records; this kernel turns them
+// into the factor gradients.  A wave takes a BATCH of 4 RUN consecutive shaded samples (RUN = 8: one 32-sample tile, as the
+// fused kernel; 16 / 32: two / four tiles); its four 16-lane groups (lane = channel) each walk one run of RUN samples in
+// order (jt_walk.h), odd groups downwards so that runs 0 | 1 and 2 | 3 end on neighbouring samples (finish_pair): the longer
+// the run, the fewer texels are flushed twice.  The product gradients of a step are not staged anywhere: basis^T GF comes out
+// of v_mfma_f32_16x16x4_f32 (A = GF of sixteen samples, four per group; B = basis^T of the plane's channels; D: lane (group,
+// channel), register r = the group's step 4 b + r) directly in the registers of the lane that scatters them.  Nothing of the
+// MLP chain lives here: 16 KB of basis operands + 3.5 / 7 / 14 KB per wave of step records in LDS, ~130 registers -- the
+// latency-bound walk runs at its own occupancy instead of the chain's two waves per SIMD.
+template <int RUN>
+__device__ inline int slot_sample(int t) {  // walk slot t = group * RUN + step  ->  sample of the batch
+  const int g = t / RUN, q = t - g * RUN;
+  return g * RUN + ((g & 1) ? RUN - 1 - q : q);
+}
+
+template <class C>
+struct ScatCfg {
+  static constexpr int NCH = (C::CA + 15) / 16;
+  static constexpr int KS = (C::APP + 3) / 4;             // K steps of the 16x16x4 product over basis_mat's rows
+  static constexpr int BT_FLOATS = 3 * NCH * KS * 64;     // basis^T operand image [plane][channel group][K step][lane]
+  static constexpr int wave_floats(int run) { return 4 * run * (4 + 4 + kRecWords); }  // geo, gxyz, step records
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// FLAGS bit 0 (not with DET): the line gradients of the pass's plane are summed in a workgroup-private LDS copy of the line
+// (line_floats = the longest line x channels; LDS float atomics) and added to the real gradient once per workgroup and plane --
+// a fifth of the scatter's global atomic segments.  (Forming dBasis here as well -- the walker has the plane x line products in
+// registers -- was measured at + 0.6 ms and removed: profiles/round4_bwd_split_ablation.txt.)
+// The plane loop is OUTSIDE the batch loop (one LDS line at a time): the coordinate gradients of a sample go to g_xyz as
+// store (plane 0) / load-add-store (planes 1, 2) by the same lane.
+template <class C, bool DET, int RUN, int WAVES, int FLAGS>
+__global__ __launch_bounds__(WAVES * 64) void k_shade_scatter(Dev D, MlpDev M, JtFactors G, const int* __restrict__ offset,
+                                                              int R, float* __restrict__ g_xyz,
+                                                              const float* __restrict__ rec, int chunk_start,
+                                                              int chunk_cap, int cap, unsigned* __restrict__ bad,
+                                                              int line_floats) {
+  typedef BwdCfg<C> B;
+  typedef ScatCfg<C> Q;
+  constexpr bool LLINE = (FLAGS & 1) && !DET;
+  constexpr int NS = 4 * RUN, NB = RUN / 4, NCH = Q::NCH, KS = Q::KS;
+  extern __shared__ __align__(16) float smem[];
+  const int total = min(offset[R], cap);
+  const int n_chunk = min(total - chunk_start, chunk_cap);
+  const int nbatch = (n_chunk + NS - 1) / NS;
+  const int nblk = min((int)gridDim.x, (nbatch + WAVES - 1) / WAVES);  // the grid is sized for the worst case
+  if ((int)blockIdx.x >= nblk) return;
+  for (int it = threadIdx.x; it < Q::BT_FLOATS; it += WAVES * 64) {
+    const int ln = it & 63, blk = it >> 6, k = blk % KS, c = (blk / KS) % NCH, pl = blk / (KS * NCH);
+    const int a = 4 * k + (ln >> 4), ch = 16 * c + (ln & 15);
+    smem[it] = (a < C::APP && ch < C::CA) ? M.basis[a * C::NC + pl * C::CA + ch] : 0.f;
+  }
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* sline = smem + Q::BT_FLOATS;                                    // [line cell][channel] of the pass's plane
+  float* geo = sline + (LLINE ? line_floats : 0) + wv * Q::wave_floats(RUN);
+  float* gxyz = geo + NS * 4;
+  float* recs = gxyz + NS * 4;
+  const size_t RC = B::REC_FLOATS;
+  const XcdShare xs = xcd_share(nbatch, nblk);
+#pragma unroll 1
+  for (int pl = 0; pl < 3; ++pl) {
+    if (LLINE)
+      for (int i = threadIdx.x; i < D.ll[pl] * C::CA; i += WAVES * 64) sline[i] = 0.f;
+    __syncthreads();
+    for (int batch = xs.lo + xs.rank * WAVES + wv; batch < xs.hi; batch += xs.peers * WAVES) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));  // (keeps per-lane address math inside the loop, see k_shade_bwd)
+      const int grp = ln >> 4, cl = ln & 15;
+      const int L0 = batch * NS;                  // first sample of the batch (chunk-local)
+      const int nlive = min(NS, n_chunk - L0);
+      // normalised coordinates of the batch's samples, in WALK order (padding slots mirror the last live sample)
+#pragma unroll
+      for (int ti = 0; ti < (NS + 63) / 64; ++ti) {
+        const int t = ln + 64 * ti;
+        if (NS % 64 != 0 && t >= NS) continue;
+        const int L = L0 + min(slot_sample<RUN>(t), nlive - 1);
+        const float* rt = rec + (size_t)(L >> 5) * RC * 32 + (L & 31);
+        geo[t * 4 + 0] = rec_ld(rt + (B::R_GEO + 0) * 32);
+        geo[t * 4 + 1] = rec_ld(rt + (B::R_GEO + 1) * 32);
+        geo[t * 4 + 2] = rec_ld(rt + (B::R_GEO + 2) * 32);
+        gxyz[t * 4 + 0] = gxyz[t * 4 + 1] = gxyz[t * 4 + 2] = 0.f;
+      }
+      // A operand of block b (steps 4 b .. 4 b + 3 of every group): row i = cl is step 4 b + (cl & 3) of group cl >> 2, the
+      // lane's K slice is basis row 4 k + grp
+      auto loadA = [&](int b, float* av) {
+        const int s = slot_sample<RUN>((cl >> 2) * RUN + 4 * b + (cl & 3));
+        const bool live = s < nlive;
+        const int L = L0 + (live ? s : nlive - 1);
+        const float* rt = rec + (size_t)(L >> 5) * RC * 32 + (size_t)(B::R_GF + grp) * 32 + (L & 31);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const float v = rec_ld(rt + 4 * k * 32);
+          av[k] = live ? v : 0.f;
+        }
+      };
+      wave_lds_sync();
+      // step records of the batch's samples for this plane, one lane per walk slot
+#pragma unroll
+      for (int ti = 0; ti < (NS + 63) / 64; ++ti) {
+        const int t = ln + 64 * ti;
+        if (NS % 64 != 0 && t >= NS) continue;
+        const bool has_prev = (t % RUN) != 0;
+        const int tq = has_prev ? t - 1 : t;
+        make_step_rec(geo[t * 4 + kM0(pl)], geo[t * 4 + kM1(pl)], geo[t * 4 + kV(pl)], geo[tq * 4 + kM0(pl)],
+                      geo[tq * 4 + kM1(pl)], geo[tq * 4 + kV(pl)], has_prev, D.ph[pl], D.pw[pl], D.ll[pl], C::CA,
+                      recs + t * kRecWords);
+      }
+      float bop[NCH][KS];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int k = 0; k < KS; ++k) bop[c][k] = smem[((pl * NCH + c) * KS + k) * 64 + ln];
+      wave_lds_sync();
+      const float* P = D.aP[pl];
+      const float* Ln = D.aL[pl];
+      RecWalker<NCH, C::CA, DET ? 1 : 0, LLINE> wk;
+      wk.init(G.app_plane[pl], LLINE ? sline : G.app_line[pl], cl, DET, bad);
+      const int m0 = kM0(pl), m1 = kM1(pl), mv = kV(pl);
+      const int my_axis = (cl == 0) ? m0 : (cl == 1) ? m1 : mv;
+      const float my_scale = ((cl == 0) ? 0.5f * (float)(D.pw[pl] - 1) : (cl == 1) ? 0.5f * (float)(D.ph[pl] - 1)
+                                                                                    : 0.5f * (float)(D.ll[pl] - 1)) *
+                             D.inv[my_axis];
+      const float* rec0 = recs + (grp * RUN) * kRecWords;
+      float* gx0 = gxyz + (grp * RUN) * 4 + my_axis;
+      auto step = [&](TapBuf<NCH>& tv, int q, const float* g) {
+        const float* sr = rec0 + q * kRecWords;
+        wk.advance(sr);
+        float aix = 0.f, aiy = 0.f, ail = 0.f;
+        wk.add(tv, sr, g, aix, aiy, ail);
+        aix = row16_sum(aix);
+        aiy = row16_sum(aiy);
+        ail = row16_sum(ail);
+        if (cl < 3) atomicAdd(gx0 + q * 4, ((cl == 0) ? aix : (cl == 1) ? aiy : ail) * my_scale);
+      };
+      TapBuf<NCH> bufA, bufB;
+      float av[KS];
+      loadA(0, av);
+      wk.load(bufA, P, Ln, rec0);
+      auto block = [&](int b) {
+        f32x4 dv[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          dv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int k = 0; k < KS; ++k) dv[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bop[c][k], dv[c], 0, 0, 0);
+        }
+        if (b + 1 < NB) loadA(b + 1, av);  // the next block's rows are in flight while this block is walked
+        float g[4][NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          g[0][c] = dv[c].x, g[1][c] = dv[c].y, g[2][c] = dv[c].z, g[3][c] = dv[c].w;
+        }
+        const int q = 4 * b;
+        wk.load(bufB, P, Ln, rec0 + (q + 1) * kRecWords);
+        step(bufA, q, g[0]);
+        wk.load(bufA, P, Ln, rec0 + (q + 2) * kRecWords);
+        step(bufB, q + 1, g[1]);
+        wk.load(bufB, P, Ln, rec0 + (q + 3) * kRecWords);
+        step(bufA, q + 2, g[2]);
+        if (b + 1 < NB) wk.load(bufA, P, Ln, rec0 + (q + 4) * kRecWords);
+        step(bufB, q + 3, g[3]);
+      };
+      if (NB <= 2) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) block(b);
+      } else {
+#pragma unroll 1
+        for (int b = 0; b < NB; ++b) block(b);
+      }
+      wk.finish_pair(grp);
+      wave_lds_sync();
+#pragma unroll
+      for (int ti = 0; ti < (NS + 63) / 64; ++ti) {
+        const int t = ln + 64 * ti;
+        if (NS % 64 != 0 && t >= NS) continue;
+        const int s = slot_sample<RUN>(t);
+        if (s < nlive) {
+          float* o = g_xyz + (size_t)(chunk_start + L0 + s) * 3;
+          if (pl == 0) {
+            o[0] = gxyz[t * 4 + 0], o[1] = gxyz[t * 4 + 1], o[2] = gxyz[t * 4 + 2];
+          } else {
+            o[0] += gxyz[t * 4 + 0], o[1] += gxyz[t * 4 + 1], o[2] += gxyz[t * 4 + 2];
+          }
+        }
+      }
+      wave_lds_sync();
+    }
+    if (LLINE) __syncthreads();
+    if (LLINE) {
+      float* gl = G.app_line[pl];
+      if (gl != nullptr)
+        for (int i = threadIdx.x; i < D.ll[pl] * C::CA; i += WAVES * 64) {
+          const float v = sline[i];
+          if (v != 0.f) atomicAdd(gl + i, v);
+        }
+    }
+    if (LLINE) __syncthreads();
   }
 }
 
@@ -1077,6 +1280,28 @@ extern "C" int jt_debug_read_stamps(unsigned long long* out8) {
   return JT_OK;
 }
 #endif
+// Split appearance backward: 0 = one kernel (chain + scatter in k_shade_bwd), 8 / 16 = k_shade_bwd<SPLIT> + k_shade_scatter
+// with runs of that many samples per 16-lane group.  JT_BWD_SPLIT (read once) overrides the build default.
+#ifndef JT_BWD_SPLIT_DEFAULT
+#define JT_BWD_SPLIT_DEFAULT 0
+#endif
+static std::atomic<int> g_bwd_split{-1};
+static int bwd_split_mode() {
+  int m = g_bwd_split.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = getenv("JT_BWD_SPLIT");
+    m = e ? atoi(e) : JT_BWD_SPLIT_DEFAULT;
+    if (m != 8 && m != 16) m = 0;
+    g_bwd_split.store(m, std::memory_order_relaxed);
+  }
+  return m;
+}
+extern "C" int jt_shade_bwd_split(void) { return bwd_split_mode(); }
+extern "C" int jt_shade_set_bwd_split(int run) {
+  const int prev = bwd_split_mode();
+  if (run == 0 || run == 8 || run == 16) g_bwd_split.store(run, std::memory_order_relaxed);
+  return prev;
+}
 extern "C" int jt_shade_chunk_entries(void) { return chunk_entries(); }
 extern "C" int jt_shade_matrix_mode(void) { return bf16x3_mode(); }
 extern "C" int jt_shade_set_matrix_mode(int mode) {
@@ -1246,16 +1471,74 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   static const bool pipe = [] { const char* e = getenv("JT_WGRAD_PIPE"); return !e || atoi(e) != 0; }();
   hipStream_t ws_st = use_aux ? aux : st;
   const int RR = B::REC_FLOATS;
+  const int split = bwd_split_mode();
+  unsigned* bad = jt::fixed_bad_flag();
+  if (!bad) return JT_ERR_ARG;
+  // fused: one kernel per chunk.  Split: the chain (launch_bwd) and the scatter (launch_scatter) -- the weight-gradient GEMMs only
+  // need the chain's records, so they are forked BEHIND THE CHAIN and run next to the atomic-bound scatter.
   auto launch_bwd = [&](int ci) -> int {
     const int start = ci * chunk, ccap = std::min(chunk, cap - start);
     long tiles = ((long)ccap + 31) / 32;
     int blocks = (int)std::min<long>((tiles + B::NWAVE - 1) / B::NWAVE, 256);
-    if (det)
+    float* rc = recs + W::rec_floats_per_chunk() * ci;
+    if (split) {
+      const size_t lds_c = B::LDS_FLOATS_SPLIT * sizeof(float);
+      static bool attr_done = false;
+      if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_bwd<C, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+        attr_done = true;
+      }
+      hipLaunchKernelGGL((k_shade_bwd<C, false, true>), dim3(blocks), dim3(512), lds_c, st, D, M, pm, G, offset, R, rgb_s,
+                         g_rgb_s, g_xyz, rc, start, ccap, cap, ablate, bad);
+    } else if (det) {
       hipLaunchKernelGGL((k_shade_bwd<C, true>), dim3(blocks), dim3(512), lds, st, D, M, pm, G, offset, R, rgb_s,
-                         g_rgb_s, g_xyz, recs + W::rec_floats_per_chunk() * ci, start, ccap, cap, ablate);
-    else
+                         g_rgb_s, g_xyz, rc, start, ccap, cap, ablate, bad);
+    } else {
       hipLaunchKernelGGL((k_shade_bwd<C, false>), dim3(blocks), dim3(512), lds, st, D, M, pm, G, offset, R, rgb_s,
-                         g_rgb_s, g_xyz, recs + W::rec_floats_per_chunk() * ci, start, ccap, cap, ablate);
+                         g_rgb_s, g_xyz, rc, start, ccap, cap, ablate, bad);
+    }
+    JT_LAUNCH_CHECK();
+    return JT_OK;
+  };
+  // JT_SCATTER_FLAGS (read once): bit 0 line gradients through LDS (k_shade_scatter)
+  static const int sflags_env = [] { const char* e = getenv("JT_SCATTER_FLAGS"); return e ? atoi(e) & 1 : 1; }();
+  constexpr int SW = 8;  // waves per scatter workgroup, ONE workgroup per CU (two waves per SIMD reach the atomic unit's rate)
+  int line_floats = 0;
+  for (int a = 0; a < 3; ++a) line_floats = std::max(line_floats, D.ll[a] * C::CA);
+  int sflags = split ? sflags_env : 0;
+  if (det) sflags &= ~1;
+  auto scatter_lds = [&](int run, int fl) {
+    return (size_t)(ScatCfg<C>::BT_FLOATS + ((fl & 1) ? line_floats : 0) + SW * ScatCfg<C>::wave_floats(run)) * sizeof(float);
+  };
+  if (split && scatter_lds(split, sflags) > 160 * 1024) sflags &= ~1;  // a line too long for the LDS: global atomics as before
+  auto launch_scatter = [&](int ci) -> int {
+    if (!split || (ablate & 1)) return JT_OK;
+    const int start = ci * chunk, ccap = std::min(chunk, cap - start);
+    const float* rc = recs + W::rec_floats_per_chunk() * ci;
+    const size_t lds_s = scatter_lds(split, sflags);
+#define JT_SCATTER_LAUNCH(RUN_, DET_, FL_)                                                                              \
+  {                                                                                                                     \
+    static bool attr = false;                                                                                           \
+    if (!attr) {                                                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_scatter<C, DET_, RUN_, SW, FL_>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                \
+      attr = true;                                                                                                      \
+    }                                                                                                                   \
+    const long nbatch = ((long)ccap + 4 * RUN_ - 1) / (4 * RUN_);                                                       \
+    const int sblocks = (int)std::min<long>((nbatch + SW - 1) / SW, 256L);                                              \
+    hipLaunchKernelGGL((k_shade_scatter<C, DET_, RUN_, SW, FL_>), dim3(sblocks), dim3(SW * 64), lds_s, st, D, M, G,     \
+                       offset, R, g_xyz, rc, start, ccap, cap, bad, line_floats);                                       \
+  }
+#define JT_SCATTER_RUN(RUN_)                                                                    \
+  {                                                                                             \
+    if (det) JT_SCATTER_LAUNCH(RUN_, true, 0)                                                   \
+    else if (sflags == 1) JT_SCATTER_LAUNCH(RUN_, false, 1)                                     \
+    else JT_SCATTER_LAUNCH(RUN_, false, 0)                                                      \
+  }
+    if (split == 8) JT_SCATTER_RUN(8) else JT_SCATTER_RUN(16)
+#undef JT_SCATTER_RUN
+#undef JT_SCATTER_LAUNCH
     JT_LAUNCH_CHECK();
     return JT_OK;
   };
@@ -1288,14 +1571,18 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
 #undef JT_WGRAD_LAUNCH
     return JT_OK;
   };
+  // (JT_SCATTER_FIRST=1: the scatter in front of the fork, as in the fused kernel's order)
+  static const bool scatter_first = [] { const char* e = getenv("JT_SCATTER_FIRST"); return e && atoi(e) != 0; }();
   for (int ci = 0; ci < nchunks; ++ci) {
     int rc = launch_bwd(ci);
     if (rc) return rc;
+    if (scatter_first && (rc = launch_scatter(ci))) return rc;
     if (use_aux && pipe) {
       if (hipEventRecord(ev_fork, st) != hipSuccess) return JT_ERR_ARG;
       if (hipStreamWaitEvent(aux, ev_fork, 0) != hipSuccess) return JT_ERR_ARG;
       if ((rc = launch_wgrad(ci))) return rc;
     }
+    if (!scatter_first && (rc = launch_scatter(ci))) return rc;
   }
   if (ablate & 4) return JT_OK;
   if (use_aux && !pipe) {

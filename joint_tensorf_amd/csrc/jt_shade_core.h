@@ -827,6 +827,8 @@ struct BwdCfg {
   static constexpr int WAVE_FLOATS = TP_ROWS * TP_LD + 32 * 4 + 32 * 4;
   static constexpr int NWAVE = 8;
   static constexpr int LDS_FLOATS = C::LDS_FLOATS + NWAVE * WAVE_FLOATS;
+  static constexpr int STASH_FLOATS = 2 * 16 * 64;                               // split backward: the chain's sin / cos stash only
+  static constexpr int LDS_FLOATS_SPLIT = C::LDS_FLOATS + NWAVE * STASH_FLOATS;
   static constexpr int PT = (C::CA + 31) / 32;  // M tiles of one plane's channels in the basis backward
   // TILE-BLOCKED records: rec[tile][row][32 samples]; every accumulator register goes out as one coalesced
   // 128-byte-per-half store, no transposition (k_wgrad reads rows, one per lane).  The training forward

@@ -122,7 +122,9 @@ __device__ inline float row16_sum(float v) {
 // Run-length accumulator of one plane + its line, driven by step records.
 // FX: 0 = float atomics, 1 = JT_DETERMINISTIC fixed point, 2 = chosen at run time by init()'s flag (a kernel that is
 // instantiated once; the density walk, short of registers, is instantiated per mode)
-template <int NCH, int CA, int FX = 2>
+// LDSL: the LINE gradients are added into a workgroup-private copy of the line in LDS (gL points there; LDS float atomics,
+// the owner adds the copy into the real gradient once) instead of going out as global atomics
+template <int NCH, int CA, int FX = 2, bool LDSL = false>
 struct RecWalker {
   float acc[4][NCH];   // plane accumulators, parity slots
   float accl[2][NCH];  // line accumulators, parity slots
@@ -131,12 +133,14 @@ struct RecWalker {
   bool live[NCH];
   float* gP;
   float* gL;
-  bool fixed;  // JT_DETERMINISTIC: gP / gL are int64 shadow buffers (same element indexing), sums in 2^56 fixed point
+  bool fixed;  // JT_DETERMINISTIC: gP / gL are int64 shadow buffers (same element indexing), sums in 2^48 fixed point
+  unsigned* bad;  // the library's sticky flag for fixed-point addends out of range (jt_common.h: fixed_add)
 
-  __device__ inline void init(float* gP_, float* gL_, int cl, bool fixed_ = false) {
+  __device__ inline void init(float* gP_, float* gL_, int cl, bool fixed_ = false, unsigned* bad_ = nullptr) {
     gP = gP_;
     gL = gL_;
     fixed = fixed_;
+    bad = bad_;
 #pragma unroll
     for (int c = 0; c < 4; ++c) o[c] = 0u;
     lo[0] = lo[1] = 0u;
@@ -181,6 +185,22 @@ struct RecWalker {
   }
   // out-of-range texels never receive anything (their weights are zero), so a clamped address is fine.
   // base == nullptr: the caller does not want factor gradients (pose-only backward), nothing is written.
+  __device__ inline void flush_lds(float* base, unsigned off, float* a) {
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) any = any || JT_FLUSH_COND(a[k]);
+    if (any) {
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+        if (live[k]) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (off + ck[k])), a[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) a[k] = 0.f;
+  }
+  __device__ inline void flush_line(unsigned off, float* a) {
+    if (LDSL) flush_lds(gL, off, a);
+    else flush(gL, off, a);
+  }
   __device__ inline void flush(float* base, unsigned off, float* a) {
     // (full channel groups, k < CA / 16: the texel's byte offset plus the lane's first channel once, the 64-byte group
     //  step as an immediate offset of the atomic)
@@ -196,7 +216,7 @@ struct RecWalker {
       for (int k = 0; k < NCH; ++k) {
         if (!live[k]) continue;
         if (FX == 1 || (FX == 2 && fixed))  // byte offset of a float element -> the same element of the 64-bit shadow buffer
-          fixed_add(reinterpret_cast<long long*>(reinterpret_cast<char*>(base) + 2 * (size_t)(off + ck[k])), a[k]);
+          fixed_add(reinterpret_cast<long long*>(reinterpret_cast<char*>(base) + 2 * (size_t)(off + ck[k])), a[k], bad);
         else if (k < CA / 16)
           JT_WALK_ATOMIC(t0 + 16 * k, a[k]);
         else
@@ -216,8 +236,8 @@ struct RecWalker {
       if (bits & 0x200u) flush(gP, o[1], acc[1]);
       if (bits & 0x400u) flush(gP, o[2], acc[2]);
       if (bits & 0x800u) flush(gP, o[3], acc[3]);
-      if (bits & 0x1000u) flush(gL, lo[0], accl[0]);
-      if (bits & 0x2000u) flush(gL, lo[1], accl[1]);
+      if (bits & 0x1000u) flush_line(lo[0], accl[0]);
+      if (bits & 0x2000u) flush_line(lo[1], accl[1]);
     }
     const uint4 ro = *reinterpret_cast<const uint4*>(rec);
     o[0] = ro.x;
@@ -308,8 +328,8 @@ struct RecWalker {
     flush(gP, o[1], acc[1]);
     flush(gP, o[2], acc[2]);
     flush(gP, o[3], acc[3]);
-    flush(gL, lo[0], accl[0]);
-    flush(gL, lo[1], accl[1]);
+    flush_line(lo[0], accl[0]);
+    flush_line(lo[1], accl[1]);
   }
 };
 

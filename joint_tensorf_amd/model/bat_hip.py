@@ -834,7 +834,9 @@ class Model(torch.nn.Module):
         bits = ops.read_status(opt.device)
         if bits:
             what = [n for b, n in ((ops.FINITE_POSE, "camera pose (se3_refine / pose composition)"),
-                                   (ops.FINITE_RENDER, "rendered colours"), (ops.FINITE_LOSS, "loss")) if bits & b]
+                                   (ops.FINITE_RENDER, "rendered colours"), (ops.FINITE_LOSS, "loss"),
+                                   (ops.FINITE_GRAD, "gradient scatter (a non-finite / out-of-range addend or an overflowed "
+                                                     "fixed-point sum in the pose or factor gradients)")) if bits & b]
             raise FloatingPointError("non-finite values since the last check in: %s (iteration %d)" % ("; ".join(what), self.it))
 
     def generate_videos_synthesis(self, opt, eps=1e-10, it=None):

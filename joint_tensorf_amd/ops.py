@@ -46,6 +46,8 @@ def status_word(dev):
     key = d.index if d.index is not None else torch.cuda.current_device()  # "cuda" and "cuda:0" are one device
     if key not in _STATUS:
         _STATUS[key] = torch.zeros(1, device=torch.device("cuda", key), dtype=torch.int32)
+        # the library reports dropped fixed-point addends / out-of-range sums of its gradient scatters here (FINITE_GRAD)
+        check(lib.jt_status_bind(ptr(_STATUS[key])), "jt_status_bind")
     return _STATUS[key]
 
 
@@ -66,7 +68,7 @@ def read_status(dev, clear=True):
     w = status_word(dev)
     v = int(w.item())
     if v and clear:
-        w.zero_()
+        check(lib.jt_status_clear(_stream()), "jt_status_clear")  # the word and the library's sticky bad-addend flag
     return v
 
 
@@ -360,6 +362,7 @@ class RenderRays(torch.autograd.Function):
         basis, w1, b1, w2, b2, w3, b3 = params[12:19]
         dev = rays_o.device
         assert dev.type == "cuda", "joint_tensorf_amd renders on the GPU only (no CPU fallback)"
+        status_word(dev)  # bound to the library before any backward can want to report into it
         R, S = rays_o.shape[0], cfg.n_samples
         rays_o = rays_o.detach().contiguous().float()
         rays_d = rays_d.detach().contiguous().float()
@@ -600,8 +603,9 @@ class RenderRays(torch.autograd.Function):
             reducer.wait()  # stream-level: whoever consumes the gradients next runs behind the collectives
         if det and want_fac:
             # fixed point -> float (value = word / 2^48), in place of the zero-filled float buffers; a sum at or beyond
-            # 2^60 (value 4 096: out of the format's safe range, or a poisoned non-finite addend, jt_common.h) leaves the
-            # FINITE_GRAD bit in the device's status word -- read with the other non-finite checks (read_status)
+            # 2^60 (value 4 096: out of the format's safe range) leaves the FINITE_GRAD bit in the device's status word --
+            # read with the other non-finite checks (read_status); a non-finite ADDEND was dropped by the kernels and
+            # raised the library's sticky flag, which jt_march_backward (above) has already turned into the same bit
             gflat.copy_((gflat64.double() * (1.0 / 281474976710656.0)).float())
             bad = (gflat64.abs() >= (1 << 60)).any()
             status_word(dev).bitwise_or_(bad.to(torch.int32) * FINITE_GRAD)

@@ -149,11 +149,15 @@ def test_blender_middle_stages_blurred(stage, grid, S):
     _train_case("blender_stage%d_blurred_%dcube" % (stage, grid), opt, model, var, it0, blur_scale=0.6)
 
 
-def test_blender_stage4_sharp_400cube():
+@pytest.mark.parametrize("variant", ["mfma", "mfma-fp32", "mfma-split16"])
+def test_blender_stage4_sharp_400cube(variant):
     """(i) the bench workload: 400^3, S = 1000, ~2 000 rays, blur off; semi-transparent field (density planes x 25:
-    every in-box sample is shaded and the transmittance decays over the whole ray)."""
+    every in-box sample is shaded and the transmittance decays over the whole ray).  Under the default kernels, the
+    fp32-matrix-core kernels (jt_shade_set_matrix_mode(0)) and the split backward (jt_shade_set_bwd_split(16))."""
+    from tests.test_gpu_parity import kernel_variant
     opt, model, var, it0 = U.build("bat_blender_VM", stage=-1, density_scale=25.0)
-    _train_case("blender_stage4_sharp", opt, model, var, it0)
+    with kernel_variant(variant):
+        _train_case("blender_stage4_sharp" + variant[4:], opt, model, var, it0)
 
 
 def test_blender_stage4_sharp_random_init():
@@ -181,10 +185,14 @@ def test_llff_stage0_20480rays():
     _train_case("llff_stage0_20480rays", opt, model, var, it0, offsets=(2, 3), blur_scale=0.8)
 
 
-def test_llff_final_grid():
-    """(iii) the final LLFF grid 771 x 859 x 771 (planes of 2.7 M texels x 20 / 16 channels), 4 096 nominal rays."""
+@pytest.mark.parametrize("variant", ["mfma", "mfma-fp32", "mfma-split16"])
+def test_llff_final_grid(variant):
+    """(iii) the final LLFF grid 771 x 859 x 771 (planes of 2.7 M texels x 20 / 16 channels), 4 096 nominal rays; under the
+    default kernels, the fp32-matrix-core kernels and the split backward."""
+    from tests.test_gpu_parity import kernel_variant
     opt, model, var, it0 = U.build("bat_llff_VM_MLP", stage=-1)
-    _train_case("llff_final_grid", opt, model, var, it0, offsets=(2, 3), coin=0.7)
+    with kernel_variant(variant):
+        _train_case("llff_final_grid" + variant[4:], opt, model, var, it0, offsets=(2, 3), coin=0.7)
 
 
 def test_configs3_62500rays_and_shard():

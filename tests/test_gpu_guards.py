@@ -51,6 +51,40 @@ def test_nan_pose_and_infinite_loss_are_flagged_on_the_device():
     assert "loss" in str(e.value) and "camera pose" not in str(e.value)
 
 
+def test_non_finite_pose_gradient_addends_cannot_pass_as_a_finite_gradient():
+    """the ray (pose) gradients of the density walk are ALWAYS summed in 2^48 fixed point.  Round 3 replaced a
+    non-finite addend by a poison magnitude inside the sum, which wraps (eight poisoned waves on one ray sum to 0 mod 2^64: a
+    NaN gradient became exactly 0).  Now a bad addend is dropped and raises the library's sticky flag: while it is up every
+    ray gradient jt_march_backward writes is NaN and the FINITE_GRAD bit goes into the bound status word."""
+    from joint_tensorf_amd import ops
+    from tests.test_gpu_edge import _batch
+    from tests.test_gpu_fuzz import _scene
+    tf, cfg, params, rs = _scene(41, "blender")
+    o, d = _batch([("hit", 64)], seed=7)
+    S = 512   # 16 runs of 32 samples per (ray, plane): more than eight poisoned waves per sum
+    ops.read_status(DEV)
+
+    def pose_grads(poison):
+        og, dg = o.to(DEV).requires_grad_(True), d.to(DEV).requires_grad_(True)
+        out = tf(None, og, dg, white_bg=True, is_train=False, ndc_ray=False, N_samples=S)
+        w = torch.ones_like(out[2])
+        if poison:
+            w[3] = float("nan")     # d loss / d opacity of ray 3 is NaN: every density-gradient addend of that ray's walk is
+        (out[2] * w).sum().backward()  # (opacity only: the appearance path, whose float sums carry a NaN by themselves, is idle)
+        return og.grad.clone(), dg.grad.clone()
+
+    go, gd = pose_grads(False)
+    assert torch.isfinite(go).all() and torch.isfinite(gd).all() and float(go.abs().max()) > 0
+    assert ops.read_status(DEV) == 0
+    go, gd = pose_grads(True)
+    assert torch.isnan(go[3]).all() and torch.isnan(gd[3]).all(), "a poisoned ray came back finite: %s" % (go[3],)
+    bits = ops.read_status(DEV)          # (clears the word and the sticky flag)
+    assert bits & ops.FINITE_GRAD, bits
+    go, gd = pose_grads(False)           # after the clear the same batch is clean again
+    assert torch.isfinite(go).all() and torch.isfinite(gd).all()
+    assert ops.read_status(DEV) == 0
+
+
 def test_float_atomic_scatters_reproduce_within_rounding():
     """Two backward passes from the same state and draws: the factor / pose gradients come out of float atomics whose
     order differs from run to run; the difference must stay at summation-rounding level (a lost or doubled update --
