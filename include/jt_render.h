@@ -273,10 +273,11 @@ int jt_shade_set_matrix_mode(int mode);
 int jt_shade_set_chunk_log2(int log2_entries);
 /* How jt_shade_backward runs the per-sample part of the appearance backward (the autograd of bateRF.py:97-130 +
  * tensorBase.py:116-126): 0 = one kernel (MLP backward chain and the factor-gradient scatter of a 32-sample tile in the same
- * wave); 8 / 16 = two launches, the chain (which leaves the feature gradients in the record rows) and a scatter kernel at
- * its own occupancy whose 16-lane groups walk runs of that many consecutive samples.  Same gradients up to the order of the
- * float sums.  The environment variable JT_BWD_SPLIT (read once) overrides the build default; the setter returns the previous
- * value (any other argument only queries). */
+ * wave); 8 / 16 = two launches, the chain (which leaves the feature gradients in the record rows) and a scatter kernel whose
+ * 16-lane groups walk runs of that many consecutive samples and which sums the LINE gradients in a workgroup-private LDS copy;
+ * -1 (the default) = chosen per scene kind (split 16 for the 20-channel WeakView scene, one kernel for VM-48).  Same gradients
+ * up to the order of the float sums.  The environment variable JT_BWD_SPLIT (read once) overrides the default; the setter
+ * returns the previous value (any other argument only queries). */
 int jt_shade_bwd_split(void);
 int jt_shade_set_bwd_split(int run);
 int jt_shade_forward(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp, const float* rays_o,
@@ -363,6 +364,11 @@ typedef struct JtFiniteItem {
   int32_t pad_;
 } JtFiniteItem;
 int jt_finite_check(const JtFiniteItem* items, int n_items, int32_t* status_word, void* stream);
+
+/* TV of the rendered depth over the pixel lattice (model/tensorf.py:126-135, `TV_depth`), VALUE only: out[0] = sum over views of
+ * sum_h (d[h+1][w] - d[h][w])^2 / grid_h + sum_w (d[h][w+1] - d[h][w])^2 / grid_w for depth [n_views][grid_h][grid_w].  The BAT
+ * yamls weight the term 0.0 and only log it; a non-zero weight goes through the host mirror's differentiable ops. */
+int jt_tv_depth_forward(const float* depth, int n_views, int grid_h, int grid_w, float* out, void* stream);
 
 /* The weighted sum of Model.summarize_loss (model/tensorf.py:31-47) over the photometric term and the three
  * regularisers, one launch each way:  total = w_render render[0] + w_l1 reg3[0] + w_tv_density reg3[1] +

@@ -104,6 +104,7 @@ SIGNATURES = {
     "jt_render_loss_backward": (I, [P, P, P, P, I, I, I, F, F, P, P, P, P]),
     "jt_render_loss_forward_ind": (I, [P, P, P, I, I, I, I, F, F, P, P, P]),
     "jt_render_loss_backward_ind": (I, [P, P, P, I, I, I, I, F, F, P, P, P, P]),
+    "jt_tv_depth_forward": (I, [P, I, I, I, P, P]),
     "jt_loss_sum_forward": (I, [P, P, F, F, F, F, P, P]),
     "jt_loss_sum_backward": (I, [P, F, F, F, F, P, P, P]),
     "jt_loss_sum_forward_dyn": (I, [P, P, P, P, P]),

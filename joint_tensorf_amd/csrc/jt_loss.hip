@@ -202,9 +202,39 @@ __global__ void k_loss_sum_bwd_dyn(const float* __restrict__ g, const float* __r
   }
 }
 
+// TV of a depth lattice [B][H][W] (model/tensorf.py:126-135): sum_h (d[h+1] - d[h])^2 / H + sum_w (d[w+1] - d[w])^2 / W, value only
+// (the BAT yamls weight the term 0.0: the reference still evaluates it for its logs with a dozen elementwise launches)
+__global__ __launch_bounds__(1024) void k_tv_depth(const float* __restrict__ d, int B, int H, int W, float* __restrict__ out) {
+  __shared__ float s_h[16], s_w[16];
+  float sh = 0.f, sw = 0.f;
+  const long n = (long)B * H * W;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const int w = (int)(i % W), h = (int)((i / W) % H);
+    const float v = d[i];
+    if (h + 1 < H) { const float t = d[i + W] - v; sh += t * t; }
+    if (w + 1 < W) { const float t = d[i + 1] - v; sw += t * t; }
+  }
+  sh = wave_sum(sh);
+  sw = wave_sum(sw);
+  if ((threadIdx.x & 63) == 0) s_h[threadIdx.x >> 6] = sh, s_w[threadIdx.x >> 6] = sw;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) a += s_h[k], b += s_w[k];
+    out[0] = a / (float)H + b / (float)W;
+  }
+}
+
 }  // namespace jt
 
 using namespace jt;
+
+extern "C" int jt_tv_depth_forward(const float* depth, int n_views, int grid_h, int grid_w, float* out, void* stream) {
+  if (!depth || !out || n_views < 1 || grid_h < 1 || grid_w < 1) return JT_ERR_ARG;
+  hipLaunchKernelGGL(k_tv_depth, dim3(1), dim3(1024), 0, (hipStream_t)stream, depth, n_views, grid_h, grid_w, out);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
 
 extern "C" int jt_loss_sum_forward_dyn(const float* render, const float* reg3, const float* w4, float* total,
                                        void* stream) {

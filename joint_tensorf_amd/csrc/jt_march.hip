@@ -447,18 +447,21 @@ __device__ inline float sel3f(int i, float a, float b, float c) { return i == 0 
 // cannot return before the flush atomics of step q - 1 have retired, ~3 000 cycles with every CU issuing; what hides
 // that is more independent chains per CU.  Per-plane items are three times as many chains of a third of the length, and
 // one walker instead of three fits 6 waves per SIMD instead of 4 (and nothing spills).
-#ifndef JT_WALK_PLANE_MAJOR
-#define JT_WALK_PLANE_MAJOR 0  // measured: 0.444 ms against 0.434 ray-major (Blender), 0.869 against 0.834 (LLFF)
-#endif
 #ifndef JT_WALK_PF
 #define JT_WALK_PF 2  // tap prefetch distance of the density walk in steps (4 at five waves per SIMD, 5 at four: the same time on
                       // both grids -- 0.43 ms Blender, 0.82-0.84 ms LLFF -- the walk does not wait for its taps)
 #endif
-#ifndef JT_WALK_WAVES
-#define JT_WALK_WAVES 6  // waves per SIMD the walk is compiled for: 80 registers, nothing spills (7: 72 registers, 9 spilled)
-#endif
-template <int CD, bool DET>
-__global__ __launch_bounds__(256, JT_WALK_WAVES) void k_march_bwd_walk(Dev D, JtFactors G, const float* __restrict__ rays_o,
+// Round 4: PERSISTENT and PLANE-MAJOR, with the LINE gradients of the pass's plane summed in a workgroup-private LDS copy of
+// the line.  Measured with the line flushes compiled out (profiles/round4_line_flush_cost.txt): they are 18 % of the walk's
+// time on the Blender grid and 32 % on LLFF's, where the rays march along the line axis and leave a line cell every step or
+// two.  One workgroup of sixteen waves per CU (four per SIMD) loops over the (ray, four runs) wave items of plane 0, adds its
+// LDS line to the real gradient with 64-byte-contiguous float atomics, then plane 1, plane 2.  LLINE = false (deterministic
+// mode, or a line that does not fit the LDS): the line goes out through global atomics / fixed point as before.
+constexpr int kWalkPrefixRays = 16384;
+// kWalkWaves = 16: one workgroup per CU (a long line: LLFF's 55 KB); 8: two per CU when their LDS fits twice (finer grains for
+// whatever runs beside the walk: the weight-gradient GEMMs on the auxiliary stream)
+template <int CD, bool DET, bool LLINE, int kWalkWaves>
+__global__ __launch_bounds__(kWalkWaves * 64) void k_march_bwd_walk(Dev D, JtFactors G, const float* __restrict__ rays_o,
                                                         const float* __restrict__ rays_d,
                                                         const float* __restrict__ jitter,
                                                         const float* __restrict__ zvals,
@@ -467,50 +470,93 @@ __global__ __launch_bounds__(256, JT_WALK_WAVES) void k_march_bwd_walk(Dev D, Jt
                                                         const uint16_t* __restrict__ vlist,
                                                         const int* __restrict__ nvalid, int runs_per_ray,
                                                         float* __restrict__ g_rays_o, float* __restrict__ g_rays_d,
-                                                        long long* __restrict__ rays_fixed, unsigned* __restrict__ bad) {
+                                                        long long* __restrict__ rays_fixed, unsigned* __restrict__ bad,
+                                                        int line_floats, int prefix) {
   constexpr int NCH = (CD + 15) / 16;
   // + 16 words per group: the four groups of a wave read their own records in the same instruction, and a group
   // stride that is a multiple of the 64 LDS banks would put all four on the same banks
-  __shared__ __align__(16) float s_rec[16][kWalkSub * kWalkRecW + 16];
+  constexpr int kGroupWords = kWalkSub * kWalkRecW + 16;
+  extern __shared__ __align__(16) float s_dyn[];
+  float* sline = s_dyn + kWalkWaves * 4 * kGroupWords;  // [line cell][channel] of the pass's plane (LLINE)
   const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  // (ray, plane) of the wave: scalar
-  const long witem = (long)blockIdx.x * 16 + (grp & ~3);
-#if JT_WALK_PLANE_MAJOR
-  // plane-major item order (an experiment, off): the whole grid walks plane 0, then plane 1, then plane 2, so that the taps
-  // in flight chip-wide come out of ONE 10 MB plane (400^2 x 16 channels) instead of all three.  It is 2-4 % slower than
-  // keeping a ray's three planes together
-  const long per_plane = (long)R * runs_per_ray;
-  const int pl = __builtin_amdgcn_readfirstlane((int)(witem / per_plane));
-  if (pl >= 3) return;
-  const long wi = witem - (long)pl * per_plane;
-  const int ray = __builtin_amdgcn_readfirstlane((int)(wi / runs_per_ray));
-  const int rem = __builtin_amdgcn_readfirstlane(pl * runs_per_ray + (int)(wi - (long)ray * runs_per_ray));
-#else
-  const int per_ray = 3 * runs_per_ray;
-  const int ray = __builtin_amdgcn_readfirstlane((int)(witem / per_ray));
-  if (ray >= R) return;
-  const int rem = __builtin_amdgcn_readfirstlane((int)(witem - (long)ray * per_ray));
-  const int pl = __builtin_amdgcn_readfirstlane(rem / runs_per_ray);
-#endif
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int qpr = runs_per_ray >> 2;               // wave items (four runs) per (ray, plane)
+  const int witems = R * qpr;
+  // every workgroup owns ONE plane (blockIdx % 3): one LDS line, one pass, one flush, no barrier between planes (a pass per
+  // plane in every workgroup cost three tails: +15 %).  Rays differ in length and half of the padded wave items are empty: the
+  // workgroups of a plane stride over the NON-EMPTY items only -- every workgroup builds the inclusive prefix of the rays' item
+  // counts in LDS (PREFIX: R <= kWalkPrefixRays) and finds an item's ray by bisection.  (Drawing items from a global counter
+  // instead was twice as slow: one word serves ~88 returning atomics per microsecond, MI355X_MICROARCH.md "dequeue".)
+  const int nblk = (int)gridDim.x;
+  const int pl = (int)blockIdx.x % 3, pb = (int)blockIdx.x / 3, npeers = (nblk - pl + 2) / 3;
+  int* s_pre = reinterpret_cast<int*>(sline + (LLINE ? line_floats : 0));   // [R] inclusive prefix of ceil(nvalid / 128)
+  int n_items = witems;
+  if (prefix) {
+    __shared__ int s_wsum[kWalkWaves];
+    const int per = (R + kWalkWaves * 64 - 1) / (kWalkWaves * 64), r0 = (int)threadIdx.x * per;
+    int loc = 0;
+    for (int k = 0; k < per; ++k)
+      if (r0 + k < R) loc += (nvalid[r0 + k] + 4 * kWalkRun - 1) / (4 * kWalkRun);
+    int inc = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o);
+      if ((int)(threadIdx.x & 63) >= o) inc += t;
+    }
+    if ((threadIdx.x & 63) == 63) s_wsum[wv] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += s_wsum[w];
+    int run_sum = base + inc - loc;
+    for (int k = 0; k < per; ++k)
+      if (r0 + k < R) {
+        run_sum += (nvalid[r0 + k] + 4 * kWalkRun - 1) / (4 * kWalkRun);
+        s_pre[r0 + k] = run_sum;
+      }
+    __syncthreads();
+    n_items = s_pre[R - 1];
+  }
+  {
+  const int H = sel3(pl, D.ph[0], D.ph[1], D.ph[2]), W = sel3(pl, D.pw[0], D.pw[1], D.pw[2]),
+            LL = sel3(pl, D.ll[0], D.ll[1], D.ll[2]);
+  float* gline = pl == 0 ? G.density_line[0] : (pl == 1 ? G.density_line[1] : G.density_line[2]);
+  if (LLINE) {
+    for (int i = threadIdx.x; i < LL * CD; i += kWalkWaves * 64) sline[i] = 0.f;
+    __syncthreads();
+  }
+#pragma unroll 1
+  for (int it = pb * kWalkWaves + wv; it < n_items; it += npeers * kWalkWaves) {
+  int ray, quad;
+  if (prefix) {  // first ray whose inclusive prefix exceeds the item index (uniform over the wave)
+    int lo = 0, hi = R - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (s_pre[mid] > it) hi = mid; else lo = mid + 1;
+    }
+    ray = __builtin_amdgcn_readfirstlane(lo);
+    quad = it - (ray > 0 ? s_pre[ray - 1] : 0);
+  } else {
+    ray = __builtin_amdgcn_readfirstlane(it / qpr);
+    quad = it - ray * qpr;
+  }
+  const int rem = __builtin_amdgcn_readfirstlane(pl * runs_per_ray + 4 * quad);
   const int run = rem - pl * runs_per_ray + (grp & 3);
   const int nv = nvalid[ray];
   const int k0 = run * kWalkRun;
-  if ((rem - pl * runs_per_ray) * kWalkRun >= nv) return;  // the whole wave is past the ray's list
+  if ((rem - pl * runs_per_ray) * kWalkRun >= nv) continue;  // the whole wave is past the ray's list
   const bool has_run = k0 < nv;
   const int k1 = min(k0 + kWalkRun, nv);
   Ray r;
   load_ray(D, rays_o, rays_d, jitter, tmin_in, ray, r);
   const size_t row = (size_t)ray * D.S;
-  float* rec = s_rec[grp];
-  const int H = sel3(pl, D.ph[0], D.ph[1], D.ph[2]), W = sel3(pl, D.pw[0], D.pw[1], D.pw[2]),
-            LL = sel3(pl, D.ll[0], D.ll[1], D.ll[2]);
+  float* rec = s_dyn + grp * kGroupWords;
   const float* P = pl == 0 ? D.dP[0] : (pl == 1 ? D.dP[1] : D.dP[2]);
   const float* L = pl == 0 ? D.dL[0] : (pl == 1 ? D.dL[1] : D.dL[2]);
   // axes of the plane: x <-> kM0(pl), y <-> kM1(pl), line <-> kV(pl)
   const int a0 = pl == 2 ? 1 : 0, a1 = pl == 0 ? 1 : 2, a2 = 2 - pl;
-  RecWalker<NCH, CD, DET ? 1 : 0> wk;
-  wk.init(pl == 0 ? G.density_plane[0] : (pl == 1 ? G.density_plane[1] : G.density_plane[2]),
-          pl == 0 ? G.density_line[0] : (pl == 1 ? G.density_line[1] : G.density_line[2]), cl, DET, bad);
+  RecWalker<NCH, CD, DET ? 1 : 0, LLINE> wk;
+  wk.init(pl == 0 ? G.density_plane[0] : (pl == 1 ? G.density_plane[1] : G.density_plane[2]), LLINE ? sline : gline, cl, DET,
+          bad);
   const float sx = 0.5f * (float)(W - 1) * sel3f(a0, D.inv[0], D.inv[1], D.inv[2]),
               sy = 0.5f * (float)(H - 1) * sel3f(a1, D.inv[0], D.inv[1], D.inv[2]),
               sl = 0.5f * (float)(LL - 1) * sel3f(a2, D.inv[0], D.inv[1], D.inv[2]);
@@ -595,6 +641,17 @@ __global__ __launch_bounds__(256, JT_WALK_WAVES) void k_march_bwd_walk(Dev D, Jt
     // in their density part, for one extra 5 us launch (k_rays_fixed_add)
     fixed_add(rays_fixed + (size_t)ray * 6 + (c < 3 ? 0 : 3) + ax, v, bad);
   }
+  }  // wave items of the plane
+  if (LLINE) {
+    __syncthreads();
+    if (gline != nullptr)
+      for (int i = threadIdx.x; i < LL * CD; i += kWalkWaves * 64) {
+        const float v = sline[i];
+        if (v != 0.f) atomicAdd(gline + i, v);
+      }
+    __syncthreads();
+  }
+  }  // the workgroup's plane
 }
 
 // g_rays_o/d [R][3] += fixed-point sums [R][6].  A sum out of the format's safe range becomes NaN, and so does EVERY ray
@@ -779,7 +836,7 @@ static size_t march_bwd_ws_layout(int S, int R, size_t* o_vlist, size_t* o_nvali
   off += (size_t)R * sizeof(int);
   off = (off + 255) & ~(size_t)255;
   if (o_fixed) *o_fixed = off;
-  off += (size_t)R * 6 * sizeof(long long);             // ray-gradient sums in fixed point (JT_DETERMINISTIC only)
+  off += (size_t)R * 6 * sizeof(long long);             // ray-gradient sums in fixed point
   return (off + 255) & ~(size_t)255;
 }
 
@@ -829,22 +886,56 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
   unsigned* bad = jt::fixed_bad_flag();
   if (!bad) return JT_ERR_ARG;
   const int runs = ((D.S + kWalkRun - 1) / kWalkRun + 3) & ~3;  // a wave's four groups: four runs of ONE (ray, plane)
-  const long items = (long)n_rays * runs * 3;
-  const int blocks = (int)((items + 15) / 16);
-#define JT_WALK(CD_)                                                                                              \
-  do {                                                                                                           \
-    if (det)                                                                                                     \
-      hipLaunchKernelGGL((k_march_bwd_walk<CD_, true>), dim3(blocks), dim3(256), 0, st, D, GF, rays_o, rays_d,   \
-                         jitter, zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d, rays_fixed, bad); \
-    else                                                                                                         \
-      hipLaunchKernelGGL((k_march_bwd_walk<CD_, false>), dim3(blocks), dim3(256), 0, st, D, GF, rays_o, rays_d,  \
-                         jitter, zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d, rays_fixed, bad); \
+  const long witems = (long)n_rays * (runs / 4);
+  int line_floats = 0;
+  for (int a = 0; a < 3; ++a) line_floats = std::max(line_floats, D.ll[a] * D.Cd);
+  static const bool lline_env = [] { const char* e = getenv("JT_WALK_LDS_LINE"); return !e || atoi(e) != 0; }();
+  static const int waves_env = [] { const char* e = getenv("JT_WALK_WAVES"); return e ? atoi(e) : 0; }();
+  int nw = 8;
+  size_t wlds = 0;
+  bool lline = false;
+  int prefix = 0;
+  for (;;) {
+    const size_t rec_bytes = (size_t)nw * 4 * (kWalkSub * kWalkRecW + 16) * sizeof(float);
+    lline = lline_env && !det && rec_bytes + (size_t)line_floats * sizeof(float) <= 158 * 1024;
+    wlds = rec_bytes + (lline ? (size_t)line_floats * sizeof(float) : 0);
+    prefix = (n_rays <= kWalkPrefixRays && wlds + (size_t)n_rays * sizeof(int) <= 158 * 1024) ? 1 : 0;
+    if (prefix) wlds += (size_t)n_rays * sizeof(int);
+    // eight-wave workgroups only where two of them fit a CU (otherwise sixteen waves: four per SIMD either way)
+    if (nw == 16 || (waves_env != 16 && 2 * (wlds + 256) <= 160 * 1024)) break;
+    nw = 16;
+  }
+  const int blocks = (int)std::min<long>(3 * ((witems + nw - 1) / nw), 255L * (16 / nw));  // 85 / 170 workgroups per plane
+#define JT_WALK_ONE(CD_, DET_, LL_, NW_)                                                                                    \
+  do {                                                                                                                      \
+    static bool attr = false;                                                                                               \
+    if (!attr) {                                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_bwd_walk<CD_, DET_, LL_, NW_>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);  /* + 64 B static */               \
+      attr = true;                                                                                                          \
+    }                                                                                                                       \
+    hipLaunchKernelGGL((k_march_bwd_walk<CD_, DET_, LL_, NW_>), dim3(blocks), dim3(NW_ * 64), wlds, st, D, GF, rays_o,      \
+                       rays_d, jitter, zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d, rays_fixed,     \
+                       bad, lline ? line_floats : 0, prefix);                                                               \
+  } while (0)
+#define JT_WALK_NW(CD_, DET_, LL_)              \
+  do {                                          \
+    if (nw == 8) JT_WALK_ONE(CD_, DET_, LL_, 8); \
+    else JT_WALK_ONE(CD_, DET_, LL_, 16);       \
+  } while (0)
+#define JT_WALK(CD_)                               \
+  do {                                             \
+    if (det) JT_WALK_NW(CD_, true, false);         \
+    else if (lline) JT_WALK_NW(CD_, false, true);  \
+    else JT_WALK_NW(CD_, false, false);            \
   } while (0)
   if (D.Cd == 16) JT_WALK(16);
   else if (D.Cd == 8) JT_WALK(8);
   else if (D.Cd == 32) JT_WALK(32);
   else return JT_ERR_UNSUPPORTED;
 #undef JT_WALK
+#undef JT_WALK_NW
+#undef JT_WALK_ONE
   JT_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_rays_fixed_add, dim3((n_rays * 6 + 255) / 256), dim3(256), 0, st, rays_fixed, n_rays, g_rays_o,
                      g_rays_d, bad, g_status_word.load(std::memory_order_relaxed));

@@ -1281,17 +1281,16 @@ extern "C" int jt_debug_read_stamps(unsigned long long* out8) {
 }
 #endif
 // Split appearance backward: 0 = one kernel (chain + scatter in k_shade_bwd), 8 / 16 = k_shade_bwd<SPLIT> + k_shade_scatter
-// with runs of that many samples per 16-lane group.  JT_BWD_SPLIT (read once) overrides the build default.
-#ifndef JT_BWD_SPLIT_DEFAULT
-#define JT_BWD_SPLIT_DEFAULT 0
-#endif
-static std::atomic<int> g_bwd_split{-1};
+// with runs of that many samples per 16-lane group, -1 = per scene kind (the default): split 16 for the 20-channel WeakView
+// scene (bat_llff_VM_MLP: its line gradients, privatised in LDS by the scatter kernel, are 40 % of the fused kernel's time:
+// 0.49 -> 0.35 ms per launch), fused for VM-48 (profiles/round4_bwd_split_ablation.txt).  JT_BWD_SPLIT (read once) overrides.
+static std::atomic<int> g_bwd_split{-2};
 static int bwd_split_mode() {
   int m = g_bwd_split.load(std::memory_order_relaxed);
-  if (m < 0) {
+  if (m < -1) {
     const char* e = getenv("JT_BWD_SPLIT");
-    m = e ? atoi(e) : JT_BWD_SPLIT_DEFAULT;
-    if (m != 8 && m != 16) m = 0;
+    m = e ? atoi(e) : -1;
+    if (m != 0 && m != 8 && m != 16) m = -1;
     g_bwd_split.store(m, std::memory_order_relaxed);
   }
   return m;
@@ -1299,7 +1298,7 @@ static int bwd_split_mode() {
 extern "C" int jt_shade_bwd_split(void) { return bwd_split_mode(); }
 extern "C" int jt_shade_set_bwd_split(int run) {
   const int prev = bwd_split_mode();
-  if (run == 0 || run == 8 || run == 16) g_bwd_split.store(run, std::memory_order_relaxed);
+  if (run == -1 || run == 0 || run == 8 || run == 16) g_bwd_split.store(run, std::memory_order_relaxed);
   return prev;
 }
 extern "C" int jt_shade_chunk_entries(void) { return chunk_entries(); }
@@ -1471,7 +1470,7 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   static const bool pipe = [] { const char* e = getenv("JT_WGRAD_PIPE"); return !e || atoi(e) != 0; }();
   hipStream_t ws_st = use_aux ? aux : st;
   const int RR = B::REC_FLOATS;
-  const int split = bwd_split_mode();
+  const int split = bwd_split_mode() >= 0 ? bwd_split_mode() : (C::CA < 48 ? 16 : 0);
   unsigned* bad = jt::fixed_bad_flag();
   if (!bad) return JT_ERR_ARG;
   // fused: one kernel per chunk.  Split: the chain (launch_bwd) and the scatter (launch_scatter) -- the weight-gradient GEMMs only

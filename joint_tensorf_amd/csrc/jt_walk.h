@@ -198,6 +198,11 @@ struct RecWalker {
     for (int k = 0; k < NCH; ++k) a[k] = 0.f;
   }
   __device__ inline void flush_line(unsigned off, float* a) {
+#if JT_ABL_WALK_LINE  // profiling knob: the line gradients are dropped -- what the LINE flushes cost a walker
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) a[k] = 0.f;
+    return;
+#endif
     if (LDSL) flush_lds(gL, off, a);
     else flush(gL, off, a);
   }

@@ -473,9 +473,13 @@ class Graph(torch.nn.Module):
             if float(opt.loss_weight.TV_depth or 0.0) != 0.0:
                 raise NotImplementedError("TV_depth with a non-zero weight under pixel-sharded data parallelism")
         elif mode == "train" and opt.nerf.ray_sampling_strategy == "all_view_rand_grid" and "TV_depth" in opt.loss_weight:
-            d = var.depth.reshape(batch_size, var.grid_H, var.grid_W)
-            loss.TV_depth = torch.pow(d[:, 1:, :] - d[:, :-1, :], 2).sum() / var.grid_H + \
-                torch.pow(d[:, :, 1:] - d[:, :, :-1], 2).sum() / var.grid_W
+            if float(opt.loss_weight.TV_depth or 0.0) == 0.0 and var.depth.is_cuda:
+                # weighted 0.0 (both BAT yamls): the value is only logged -- one launch instead of a dozen elementwise ones
+                loss.TV_depth = ops.tv_depth_value(var.depth, batch_size, var.grid_H, var.grid_W)
+            else:
+                d = var.depth.reshape(batch_size, var.grid_H, var.grid_W)
+                loss.TV_depth = torch.pow(d[:, 1:, :] - d[:, :-1, :], 2).sum() / var.grid_H + \
+                    torch.pow(d[:, :, 1:] - d[:, :, :-1], 2).sum() / var.grid_W
             if self.it > opt.loss_weight.TV_depth_until_iters:
                 opt.loss_weight.TV_depth = 0.0
         return loss

@@ -150,9 +150,18 @@ def _workspace_owner(dev, name):
     return _WS_EPOCH.get((str(dev), name), 0)
 
 
-# weight-gradient GEMMs on an auxiliary stream (overlaps the MFMA-bound GEMMs with the atomics-bound density
-# backward); JT_NO_AUX=1 keeps everything on one stream, e.g. for clean per-kernel profiles
-USE_AUX_STREAM = os.environ.get("JT_NO_AUX", "0") != "1"
+# weight-gradient GEMMs on an auxiliary stream, next to the density backward.  JT_NO_AUX=1: never (clean per-kernel profiles);
+# JT_NO_AUX=0: always; unset: only for the 20-channel scene, whose small GEMMs (136-256 registers, 0.14 ms) fit beside the
+# persistent density walk (bat_llff_VM_MLP final grid 2.29 ms with, 2.39 without).  VM-48's GEMMs (160-368 registers) and the
+# walk's 8-wave workgroups keep each other off the CUs: 3.32-3.36 ms with the auxiliary stream, 3.26 without (round 4).
+_AUX_ENV = os.environ.get("JT_NO_AUX")
+USE_AUX_STREAM = _AUX_ENV != "1"
+
+
+def _use_aux(cfg):
+    if not USE_AUX_STREAM:
+        return False
+    return True if _AUX_ENV == "0" else cfg.n_comp_app < 48
 
 
 def _aux_stream(dev):
@@ -550,7 +559,7 @@ class RenderRays(torch.autograd.Function):
                                        ptr(torch.empty_like(rgb_s)), cap, ptr(ws), nbytes,
                                        _lib.JT_SHADE_POSE_ONLY if ctx.pose_only else 0, st),
                   "jt_shade_forward")
-        if USE_AUX_STREAM and want_mlp:
+        if _use_aux(cfg) and want_mlp:
             aux, ev_fork, ev_join = _aux_stream(dev)
             # the weight-gradient GEMMs read mlp_t / ws and write g_mlp on the auxiliary stream
             if not torch.cuda.is_current_stream_capturing():  # graph-pool memory is never recycled elsewhere
@@ -561,17 +570,25 @@ class RenderRays(torch.autograd.Function):
             join = ev_join
         else:
             h_aux = (None, None, None)
+        t_bwd_end = None
         if STEP_TIMERS is not None and not ctx.pose_only:
-            # the fork event doubles as the end mark of k_shade_bwd (jt_render.h); a fresh timing-enabled pair per call
             t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0.record()
-            t1.record()  # creates the handle; the library records it again behind k_shade_bwd
-            h_aux = (h_aux[0], ctypes.c_void_p(t1.cuda_event), h_aux[2])
+            if h_aux[0] is not None:
+                # the weight-gradient GEMMs go to the auxiliary stream: what this call leaves on the launch stream IS the
+                # per-sample backward (k_shade_bwd, or chain + scatter when split) -- its end mark is recorded behind the call
+                t_bwd_end = t1
+            else:
+                # one stream: the library records the mark between the per-sample kernels and the GEMMs (jt_render.h)
+                t1.record()  # creates the handle
+                h_aux = (h_aux[0], ctypes.c_void_p(t1.cuda_event), h_aux[2])
             STEP_TIMERS.append(("bwd", t0, t1, offset))
         check(lib.jt_shade_backward(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals),
                                     ptr(tmin), ptr(offset), R, ptr(eray), ptr(esmp), ptr(vdir), ptr(rgb_s),
                                     ptr(g_rgb_s), gfac, gm, ptr(g_xyz), cap, ptr(ws), nbytes, 0, st, *h_aux),
               "jt_shade_backward")
+        if t_bwd_end is not None:
+            t_bwd_end.record()
         if dp:
             reducer.reduce(2, 3)  # appearance planes + lines are final
         g_o = torch.empty(R, 3, **f32)
@@ -911,6 +928,16 @@ class LossSum(torch.autograd.Function):
         g_reg = torch.empty(3, device=gc.device, dtype=torch.float32)
         check(lib.jt_loss_sum_backward(ptr(gc), *ctx.w, ptr(g_render), ptr(g_reg), _stream()), "jt_loss_sum_backward")
         return g_render.reshape(ctx.render_shape), g_reg, None, None, None, None
+
+
+def tv_depth_value(depth, n_views, grid_h, grid_w):
+    """TV of the depth lattice (model/tensorf.py:126-135) as ONE launch, value only (no gradient): what the BAT yamls, which
+    weight the term 0.0, need of it."""
+    d = depth.detach().contiguous().float()
+    assert d.numel() == n_views * grid_h * grid_w
+    out = torch.empty(1, device=d.device, dtype=torch.float32)
+    check(lib.jt_tv_depth_forward(ptr(d), int(n_views), int(grid_h), int(grid_w), ptr(out), _stream()), "jt_tv_depth_forward")
+    return out[0]
 
 
 class LossSumDyn(torch.autograd.Function):

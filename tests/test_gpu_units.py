@@ -237,6 +237,17 @@ def test_render_loss_vs_oracle(masked):
     assert _rel(b.grad.cpu().numpy(), a.grad.numpy()) < 1e-5
 
 
+def test_tv_depth_value_vs_oracle():
+    """jt_tv_depth_forward (model/tensorf.py:126-135, value only) against the oracle's restatement, ragged lattice shapes"""
+    from joint_tensorf_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for B, H, W in ((18, 15, 15), (3, 1, 7), (2, 9, 1), (100, 5, 4)):
+        d = torch.rand(B, H * W, 1, generator=g) * 7.0
+        got = float(ops.tv_depth_value(d.to(DEV), B, H, W))
+        ref = float(O.tv_depth(d, B, H, W))
+        assert abs(got - ref) <= 2e-6 * max(1.0, abs(ref)), (B, H, W, got, ref)
+
+
 def test_reg_losses_vs_oracle():
     """one-call L1 / TV_density / TV_color and their gradients against the oracle's formulas."""
     from joint_tensorf_amd import ops
