@@ -272,6 +272,18 @@ class Graph(torch.nn.Module):
             memo[key] = (sx[None, :] + sy[:, None] * opt.W).reshape(-1)
         return memo[key]
 
+    def _lattice_at(self, opt, step, ny, nx, ox, oy):
+        """pixel indices of the lattice at offset (ox, oy): base + ox + oy W, remembered per offset (step^2 of them, a few
+        thousand entries of a few KB: the add is one launch of an iteration's ~40)."""
+        key = (int(step), int(ny), int(nx), int(ox), int(oy), int(opt.W), str(opt.device))
+        memo = self.__dict__.setdefault("_lattice_at_memo", {})
+        t = memo.get(key)
+        if t is None:
+            if len(memo) >= 8192:
+                memo.clear()
+            t = memo[key] = self._lattice_base(opt, step, ny, nx) + (ox + oy * opt.W)
+        return t
+
     @staticmethod
     def lattice_step(opt, batch_size):
         """pixel stride of the all_view_rand_grid lattice (model/nerf.py:660-662)."""
@@ -301,7 +313,7 @@ class Graph(torch.nn.Module):
                     from ..dist import rank_lattice_offsets
                     ox, oy = rank_lattice_offsets(ox, oy, step, opt.W, opt.H, shard[1], shard[2])
                 nx, ny = len(range(ox, opt.W, step)), len(range(oy, opt.H, step))
-                var.ray_idx = self._lattice_base(opt, step, ny, nx) + (ox + oy * opt.W)
+                var.ray_idx = self._lattice_at(opt, step, ny, nx, ox, oy)
                 var.ray_grid_step, var.grid_H, var.grid_W = step, ny, nx
                 if shard is not None and shard[0] == "pixel":
                     var.ray_idx = var.ray_idx[shard[1]::shard[2]]
@@ -580,7 +592,7 @@ class Model(torch.nn.Module):
     def reduce_pose_gradients(self):
         """what left the renderer through the rays: the se(3) refinements' gradient, summed over the ranks (2.4 KB)"""
         dp = getattr(self, "dp", None)
-        if dp is not None and (dp.world > 1 or dp.force):
+        if dp is not None and (dp.world > 1 or dp.force) and not ops._DP.get("no_collectives"):
             from ..dist import allreduce_gradients
             allreduce_gradients([self.graph.se3_refine.weight], dp.world, group=dp.group, force=dp.force)
 
@@ -657,7 +669,7 @@ class Model(torch.nn.Module):
         with ops.prof_range("summarize_loss"):
             loss = self.summarize_loss(opt, var, loss)
         with ops.prof_range("loss.all.backward()"):
-            loss.all.backward()
+            loss.all.backward(gradient=self._backward_seed(loss.all))  # (a cached ones tensor: no fill launch per iteration)
         self.reduce_pose_gradients()
         if (not _has(opt.optim, "grad_accum_iter")) or (self.it % opt.optim.grad_accum_iter) == 0:
             with ops.prof_range("optim.step"):
@@ -673,6 +685,13 @@ class Model(torch.nn.Module):
             self.sched_pose.step()
         g.nerf.set_progress(self.it / opt.max_iter)
         return loss
+
+    def _backward_seed(self, t):
+        key = (t.shape, t.dtype, str(t.device))
+        memo = self.__dict__.setdefault("_seed_memo", {})
+        if key not in memo:
+            memo[key] = torch.ones_like(t)
+        return memo[key]
 
     def after_iteration(self, opt, it=None):
         """The part of nerf.Model.train's loop body that follows train_iteration (model/nerf.py:258-260).  The

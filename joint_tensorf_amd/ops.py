@@ -216,7 +216,7 @@ def _zeros_flat(groups, with_flat=False, unzeroed=()):
 # the kernels that are still running.  Callers scale the RENDER loss by 1 / world; the regularisers are the
 # same on every rank and are neither scaled nor reduced.  Gradients that leave through the rays (poses) are the
 # caller's to reduce (dist.allreduce_gradients).
-_DP = {"world": 1, "group": None, "force": False}
+_DP = {"world": 1, "group": None, "force": False, "no_collectives": os.environ.get("JT_DP_NO_COLLECTIVES") == "1"}
 
 
 class DpReducer:
@@ -234,6 +234,8 @@ class DpReducer:
         import torch.distributed as dist
         lo, hi = self.spans[first][0], self.spans[last][1]
         _DP.setdefault("span_elems", {})[(lo, hi)] = hi - lo  # sizes of the collectives (bench.py times them alone)
+        if _DP.get("no_collectives"):  # timing aid (JT_DP_NO_COLLECTIVES=1 / bench.py's allreduce_overlap_ms): the ranks' step
+            return                     # WITHOUT its gradient exchange -- the parameters of the ranks drift apart
         self.works.append(dist.all_reduce(self.gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):

@@ -160,3 +160,160 @@ def test_pose_error_curve_matches_the_oracle_loop():
         assert abs(rh - ro) <= 0.1 * ro + 0.05, (curve_h, curve_o)
         assert abs(th - to) <= 0.1 * to + 0.002, (curve_h, curve_o)
     assert curve_o[-1][0] < 0.8 * curve_o[0][0] or curve_o[-1][0] < 12.0  # and the oracle's own run is converging too
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bat_llff_VM_MLP (BASELINE.json configs[2]): the forward-facing configuration
+# ---------------------------------------------------------------------------------------------------------------------
+# The forward-facing synthetic scene (synthetic.make_gt_scene, NDC): eighteen cameras on a 0.5-wide patch looking along +z,
+# twelve textured blobs at depth 1.3 - 5 near-plane distances, a textured wall behind them at depth 6.7.
+LLFF_SCENE = dict(config="bat_llff_VM_MLP", views=18, image_size=240, llff_baseline=0.5, llff_focus=0.0, gt_z_range="0.4,0.8",
+                  gt_wall=0.9)
+
+
+def _llff_oracle_loop(cv, opt, model, K, EVERY):
+    """K iterations of bat_llff_VM_MLP's training loop (model/nerf.py:150-278 around model/bat.py:96-116) written with the
+    oracle's stock torch ops + torch.optim on the GPU, from `model`'s CURRENT state and the process's CURRENT random
+    streams: NDC rays from identity-initialised poses, the shared jittered z row, relu density, WeakView MLP, the near-plane
+    schedule, the white-background coin, factor blur with the random density scale, 2-D blurred supervision, edge-weighted
+    loss on even iterations, L1 + TV with decaying weights, Adam with per-iteration lr decay, pose Adam stepping every
+    n_AccumPoseGrad-th iteration on accumulated gradients with warm-up and ExponentialLR, and the pose reset of
+    train_schedule.reset_pose_on_iter.  Returns the pose-error curve [(rotation deg, translation)] every EVERY iterations."""
+    g, tf = model.graph, model.graph.nerf.tensorf
+    data = model.train_data.all
+    B, H, W = len(data.idx), opt.H, opt.W
+    sd = {k: v.detach().clone().contiguous() for k, v in tf.state_dict().items()}
+    params = O.params_from_state_dict(sd, prefix="")
+    for _, v in O.flat_params(params):
+        v.requires_grad_(True)
+    cfg = O.SceneCfg(opt.data.scene_bbox, tf.gridSize.tolist(), list(opt.nerf.depth.range), step_ratio=opt.nerf.step_ratio,
+                     density_shift=float(opt.arch.density_shift), distance_scale=float(opt.arch.distance_scale),
+                     fea2denseAct="relu", rayMarch_weight_thres=float(opt.arch.tensorf.rayMarch_weight_thres),
+                     shadingMode="MLP_Fea_WeakView", view_pe=2, fea_pe=2, ndc_near_plane=float(opt.arch.ndc_near_plane)).to(DEV)
+    se3_o = g.se3_refine.weight.detach().clone().requires_grad_(True)
+    eye = torch.eye(3, 4, device=DEV)
+    lr_i, lr_b = g.nerf.lr_index, g.nerf.lr_basis
+    groups = [dict(params=params["density_line"], lr=lr_i), dict(params=params["density_plane"], lr=lr_i),
+              dict(params=params["app_line"], lr=lr_i), dict(params=params["app_plane"], lr=lr_i),
+              dict(params=[params["basis"]], lr=lr_b), dict(params=list(params["mlp"].values()), lr=lr_b)]
+    optim_o = torch.optim.Adam(groups, betas=(0.9, 0.99))
+    optim_pose_o = torch.optim.Adam([dict(params=[se3_o], lr=opt.optim.lr_pose)])
+    gamma = (opt.optim.lr_pose_end / opt.optim.lr_pose) ** (1.0 / opt.max_iter)
+    sched_o = torch.optim.lr_scheduler.ExponentialLR(optim_pose_o, gamma=gamma)
+    decay = g.nerf.lr_decay_factor
+    S = g.nerf.n_samples
+    ts = opt.train_schedule
+    w_tvd, w_tvc = float(opt.loss_weight.TV_density), float(opt.loss_weight.TV_color)
+    pool2d = list(opt.c2f_alternate_2D_scale_pool)
+
+    def err_o():
+        with torch.no_grad():
+            pose = O.train_pose(se3_o, None, eye)
+            al, _ = O.prealign_cameras(pose.cpu(), data.pose.cpu())
+            r, t = O.camera_alignment_error(al, data.pose.cpu())
+        return float(np.rad2deg(r.mean())), float(t.mean())
+
+    curve, cache, masks = [], None, None
+    for it in range(K):
+        n_rays = int(ts.n_rays_init if it < ts.change_n_rays_after_n_iters else ts.n_rays_rest)          # before_iteration
+        accum = int(ts.n_AccumPoseGrad_init if it < ts.change_n_AccumPoseGrad_after_n_iters else ts.n_AccumPoseGrad_rest)
+        if it == ts.reset_pose_on_iter:
+            with torch.no_grad():
+                se3_o.mul_(0.0)
+        if it % 500 == 0:                                                                               # select_supervision
+            cache = O.process_gt_images(data.image.cpu(), it / opt.max_iter, opt.blur_2d_c2f_schedule, pool2d,
+                                        opt.blur_2d_c2f_kernel_size)
+            masks = {k: v.to(DEV) for k, v in O.edge_masks(cache).items()}
+            cache = {k: v.to(DEV) for k, v in cache.items()}
+        sc = np.random.choice(pool2d)
+        image = cache[sc].view(B, 3, -1).permute(0, 2, 1)
+        mask = masks[opt.edge_mask_use_scale]
+        for pg in optim_pose_o.param_groups:                                                            # train_iteration
+            pg["lr_orig"] = pg["lr"]
+            pg["lr"] *= min(1, it / opt.optim.warmup_pose)
+        optim_o.zero_grad()
+        pose = O.train_pose(se3_o, None, eye)
+        step = int(np.ceil((H * W // (n_rays // B)) ** 0.5))
+        ox, oy = np.random.randint(step), np.random.randint(step)
+        ray_idx, _, gh, gw = O.rand_grid_ray_idx(H, W, n_rays, B, ox, oy)
+        ray_idx = ray_idx.to(DEV)
+        center, ray = O.rays_for_pixels(pose, data.intr_inv, ray_idx, W)
+        center, ray = O.convert_ndc(center, ray, data.intr, near=float(opt.arch.ndc_near_plane))
+        scale = np.random.choice(opt.c2f_random_density_scale_pool)
+        progress = it / opt.max_iter
+        cfg.near_far[0] = O.interp_schedule(progress, opt.tensorf_near_plane_schedule)
+        pd = O.interp_schedule(progress, opt.c2f_schedule_density) * scale
+        pc = O.interp_schedule(progress, opt.c2f_schedule_color)
+        kd = kc = None
+        if max(pd, pc) >= 0.001:
+            kd, kc = O.get_kernel(cfg, pd, opt.c2f_kernel_size).to(DEV), O.get_kernel(cfg, pc, opt.c2f_kernel_size).to(DEV)
+        jit = torch.rand(1, S, device=DEV)                      # the draws BAT_VMSplit.forward takes: z row, then the coin
+        coin = float(torch.rand((1,)))
+        rgb, _, _ = O.render(cfg, params, center.reshape(-1, 3), ray.reshape(-1, 3), S, white_bg=coin < 0.5, jitter=jit,
+                             ndc_ray=True, kernel_density=kd, kernel_color=kc)
+        rgb = rgb.view(B, -1, 3)
+        if it % 2 == 0 and it < opt.edge_mask_before_iter:
+            render = O.render_loss(rgb, image[:, ray_idx], mask[:, ray_idx], opt.edge_loss_factor, opt.non_edge_loss_factor)
+        else:
+            render = O.render_loss(rgb, image[:, ray_idx])
+        w_l1 = float(opt.loss_weight.L1.rest if it > ts.update_alphamask_iters[0] else opt.loss_weight.L1.init)
+        total = float(opt.loss_weight.render) * render + w_l1 * O.density_L1(params) \
+            + w_tvd * O.tv_planes(params["density_plane"]) + w_tvc * O.tv_planes(params["app_plane"])
+        total.backward()
+        optim_o.step()
+        if (it + 1) % accum == 0:                               # pose gradients accumulate over `accum` iterations
+            optim_pose_o.step()
+            optim_pose_o.zero_grad()
+        for pg in optim_pose_o.param_groups:
+            pg["lr"] = pg["lr_orig"]
+        sched_o.step()
+        for grp in optim_o.param_groups:
+            grp["lr"] *= decay
+        w_tvd *= decay
+        w_tvc *= decay
+        if (it + 1) % EVERY == 0:
+            curve.append(err_o())
+    return curve
+
+
+def _hip_curve(cv, opt, model, K, EVERY):
+    curve = []
+    orig_after = model.after_iteration
+
+    def after(o, it=None):
+        orig_after(o, it)
+        if model.it % EVERY == 0:
+            curve.append(cv.pose_errors(opt, model))
+    model.after_iteration = after
+    model.train(opt)
+    model.after_iteration = orig_after
+    assert model.it == K and len(curve) == K // EVERY
+    return curve
+
+
+def test_llff_pose_error_curve_matches_the_oracle_loop():
+    """bat_llff_VM_MLP's joint optimisation through the HIP path against the SAME loop written with the
+    oracle, 400 iterations of the schedule compressed ten times (the whole first grid stage: 20 480-nominal-ray lattices,
+    factor blur, the near-plane schedule, pose steps every 8th iteration, warm-up, the pose reset at iteration 250) from the
+    same state and the same host / device draws: whatever the forward-facing run does to its cameras, the reference
+    algorithm in stock torch ops does the same."""
+    cv = _converge()
+    K, EVERY = 400, 50
+    opt, model = cv.build(_args(max_iter=K, **LLFF_SCENE), device=DEV)
+    assert bool(opt.camera.ndc) and opt.train_schedule.reset_pose_on_iter == 250 and opt.optim.warmup_pose == 50
+    torch.manual_seed(321)
+    np.random.seed(321)
+    rng_state = (torch.get_rng_state(), torch.cuda.get_rng_state(), np.random.get_state())
+    # the oracle loop first (it starts from the model's initial state and does not touch it), then the HIP run on the same streams
+    curve_o = _llff_oracle_loop(cv, opt, model, K, EVERY)
+    torch.set_rng_state(rng_state[0])
+    torch.cuda.set_rng_state(rng_state[1])
+    np.random.set_state(rng_state[2])
+    curve_h = _hip_curve(cv, opt, model, K, EVERY)
+    print("rotation error [deg]    hip   ", [round(r, 3) for r, _ in curve_h])
+    print("                        oracle", [round(r, 3) for r, _ in curve_o])
+    print("translation error       hip   ", [round(t, 4) for _, t in curve_h])
+    print("                        oracle", [round(t, 4) for _, t in curve_o])
+    for (rh, th), (ro, to) in zip(curve_h, curve_o):
+        assert abs(rh - ro) <= 0.15 * ro + 0.05, (curve_h, curve_o)
+        assert abs(th - to) <= 0.15 * to + 0.003, (curve_h, curve_o)

@@ -114,6 +114,11 @@ def test_bench_gpus2_starts_its_own_ranks():
     # 8192 nominal rays over 100 views: 81 per view -> stride ceil(sqrt(160000 // 81)) = 45 -> 8 or 9 points per axis
     assert len(per) == 2 and abs(per[0] - per[1]) <= 100 and 6400 <= per[0] + per[1] <= 8100
     assert "allreduce_ms" in line and len(line["allreduce_ms"]) == 3
+    # the record says which single-GPU figure it scales from, and how much of the exchange the backward did not hide
+    n1 = line["strong_scaling_n1"]
+    assert "--gpus 1 --total-rays 8192" in n1["workload"] and "configs3_single_gpu" in n1["key"]
+    assert line["ms_per_step_no_collectives"] > 0
+    assert abs(line["allreduce_overlap_ms"] - (line["ms_per_step"] - line["ms_per_step_no_collectives"])) < 1e-6
 
 
 def test_bench_gpus_mismatch_is_an_error():
