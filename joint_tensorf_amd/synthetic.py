@@ -43,8 +43,9 @@ def make_views(opt, n_views, seed=0, device="cpu", with_images=True):
         # set, every camera is turned towards the point (0, 0, focus) as a hand-held capture is -- otherwise no rotation
         base = float(opt.data.get("llff_baseline", None) or 0.3)
         focus = opt.data.get("llff_focus", None)
+        zs = float(opt.data.get("llff_zspread", None) or (1.0 / 6.0))   # depth of the camera cloud as a fraction of its width
         for i in range(n_views):
-            eye = np.array([base * (rng.rand() - 0.5), base * (rng.rand() - 0.5), base / 6 * (rng.rand() - 0.5)])
+            eye = np.array([base * (rng.rand() - 0.5), base * (rng.rand() - 0.5), base * zs * (rng.rand() - 0.5)])
             R = np.eye(3)
             if focus:
                 fwd = np.array([0.0, 0.0, float(focus)]) - eye
@@ -138,6 +139,28 @@ def bake_wall(tensorf, axis_frac=0.88, thickness=0.05, amplitude=40.0, component
     line[0, c, :, 0] = torch.exp(-((z - axis_frac) ** 2) / (2 * thickness * thickness))
 
 
+@torch.no_grad()
+def bake_stairs(tensorf, n_steps, z_near=0.55, z_far=0.93, thickness=0.012, amplitude=40.0, first_component=None, seed=0):
+    """A back wall whose DEPTH varies across the picture: `n_steps` opaque slabs, step k covering one vertical strip of the
+    box's x extent (in a shuffled order, so that neighbouring strips differ by several steps) at its own z fraction between
+    z_near and z_far (rank-1 each: strip indicator on plane 0 times a bump on line 0).  A single fronto-parallel wall fills
+    most of a forward-facing picture with content at ONE depth, for which a sideways camera translation and a small rotation
+    are the same image motion -- the joint optimisation then explains the views by rotating the cameras
+    (profiles/round3_llff_synthetic_pose_ambiguity.txt); depth steps across the picture make the two distinguishable."""
+    plane, line = tensorf.density_plane[0], tensorf.density_line[0]
+    C, W, L = plane.shape[1], plane.shape[3], line.shape[2]
+    c0 = C - 1 - n_steps if first_component is None else first_component
+    z = torch.linspace(0, 1, L, device=line.device)
+    x = torch.linspace(0, 1, W, device=plane.device)
+    order = np.random.RandomState(seed + 5).permutation(n_steps)
+    for k in range(n_steps):
+        lo, hi = k / n_steps, (k + 1) / n_steps
+        strip = ((x >= lo) & ((x < hi) | (k == n_steps - 1))).float()
+        zf = z_near + (z_far - z_near) * (order[k] + 0.5) / n_steps
+        plane[0, c0 + k] = amplitude * strip[None, :].expand(plane.shape[2], -1)
+        line[0, c0 + k, :, 0] = torch.exp(-((z - zf) ** 2) / (2 * thickness * thickness))
+
+
 def make_gt_scene(opt, seed=0, res=None, n_blobs=12):
     """A ground-truth field for `opt`'s configuration: the same scene class, box, ranks and MLP as the run trains, at a
     grid of `res`^3-equivalent voxels (default opt.data.gt_res or 128), with opaque blobs (bake_blobs; an extra back wall
@@ -166,9 +189,16 @@ def make_gt_scene(opt, seed=0, res=None, n_blobs=12):
     if ndc:
         # NDC depth 1 - 2 n / z: real forward-facing content sits at z_ndc in [0.2, 0.9] (2.5 ... 20 near-plane distances);
         # the box's z runs from -2 to 1, so that is the far 27 % of it; a textured wall closes the scene behind the blobs
-        n = bake_blobs(tf, n_blobs=min(n_blobs, tf.density_plane[0].shape[1] - 2), seed=seed, radius=(0.08, 0.2),
+        stairs = int(opt.data.get("gt_stairs", None) or 0)
+        C = tf.density_plane[0].shape[1]
+        rad = tuple(opt.data.get("gt_blob_radius", None) or (0.08, 0.2))
+        n = bake_blobs(tf, n_blobs=min(int(opt.data.get("gt_blobs", None) or n_blobs), C - 2 - stairs), seed=seed, radius=rad,
                        z_range=tuple(opt.data.get("gt_z_range", None) or (0.74, 0.93)))
-        bake_wall(tf, axis_frac=float(opt.data.get("gt_wall", None) or 0.975), thickness=0.012)
+        if stairs:   # a back wall in depth steps across the picture (bake_stairs) instead of one fronto-parallel slab
+            bake_stairs(tf, stairs, z_near=float(opt.data.get("gt_stairs_near", None) or 0.55),
+                        z_far=float(opt.data.get("gt_wall", None) or 0.93), seed=seed)
+        else:
+            bake_wall(tf, axis_frac=float(opt.data.get("gt_wall", None) or 0.975), thickness=0.012)
     else:
         n = bake_blobs(tf, n_blobs=min(n_blobs, tf.density_plane[0].shape[1] - 1), seed=seed)
     bake_appearance(tf, seed=seed)

@@ -31,6 +31,11 @@ def build(args, device="cuda:0"):
         over["data"]["gt_z_range"] = [float(v) for v in args.gt_z_range.split(",")]
     if getattr(args, "gt_wall", 0):
         over["data"]["gt_wall"] = args.gt_wall
+    for k in ("gt_stairs", "gt_blobs", "gt_stairs_near", "llff_zspread"):
+        if getattr(args, k, 0):
+            over["data"][k] = getattr(args, k)
+    if getattr(args, "gt_blob_radius", None):
+        over["data"]["gt_blob_radius"] = [float(v) for v in args.gt_blob_radius.split(",")]
     opt = make_options(args.config, device=device, **over)
     if args.image_size:
         h, w = opt.data.image_size
@@ -87,6 +92,11 @@ def main():
     ap.add_argument("--llff-focus", type=float, default=0.0)
     ap.add_argument("--gt-z-range", default=None, help="LLFF scene: fraction range of the box's z the blobs sit in, e.g. 0.6,0.9")
     ap.add_argument("--gt-wall", type=float, default=0.0, help="LLFF scene: z fraction of the back wall")
+    ap.add_argument("--gt-stairs", type=int, default=0, help="LLFF scene: back wall in this many depth steps across the picture")
+    ap.add_argument("--gt-stairs-near", type=float, default=0.0, help="LLFF scene: z fraction of the nearest wall step")
+    ap.add_argument("--gt-blobs", type=int, default=0)
+    ap.add_argument("--llff-zspread", type=float, default=0.0, help="LLFF scene: depth of the camera cloud / its width (1/6)")
+    ap.add_argument("--gt-blob-radius", default=None, help="LLFF scene: blob radius range, e.g. 0.15,0.35")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     opt, model = build(args)
