@@ -244,13 +244,74 @@ def _cpu_oracle_rate(grid, S, rays_per_view, seconds_budget, blur_off=True):
                 min_ms=min(times) * 1e3, max_ms=max(times) * 1e3, rays=B * r, host_cpus=ncpu)
 
 
+def _cpu_c1_protocol(threads, reps=9):
+    """BASELINE.md section 3.1 / SURVEY 8(d) for the reference's CPU-sized configuration C1 (grid 64^3, 512 rays drawn over 4
+    views, S = 221, VM 16 / 48, MLP 150 -> 64 -> 64 -> 3; fwd + loss + bwd of the parity-pinned torch port): 3-D blur off and on
+    (progress 0: sigma = 0.3 x 64 / 3 voxels, 65 taps), each with default denormals and with torch.set_flush_denormal(True),
+    one warm-up and then `reps` repetitions INTERLEAVED over the four cases; min / median / max per case."""
+    from oracle import tensorf_oracle as O
+    g = torch.Generator().manual_seed(0)
+    grid, S = [64, 64, 64], 221
+    cfg = O.SceneCfg([-1.5] * 3 + [1.5] * 3, grid, [2.0, 6.0])
+    params = O.init_params(grid, scale=0.1, bias=0.0, generator=g)
+    for _, v in O.flat_params(params):
+        v.requires_grad_(True)
+    B, r, H, W = 4, 128, 400, 400
+    from joint_tensorf_amd.synthetic import look_at
+    pose_gt = torch.tensor(np.stack([look_at(4.0 * np.array([np.cos(2 * np.pi * i / B) * 0.8, np.sin(2 * np.pi * i / B) * 0.8, 0.6]))
+                                     for i in range(B)]))
+    f = 0.5 * W / np.tan(0.5 * 0.69)
+    intr = torch.tensor([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]], dtype=torch.float32)[None].repeat(B, 1, 1)
+    se3 = (torch.randn(B, 6, generator=g) * 0.01).requires_grad_(True)
+    noise = O.se3_to_SE3(torch.randn(B, 6, generator=g) * 0.15)
+    target = torch.rand(B, r, 3, generator=g)
+    kern = O.get_kernel(cfg, 0.3, 64)   # c2f_schedule_density[0] = 0.3 at progress 0, density scale 1
+
+    def step(blur):
+        for _, v in O.flat_params(params):
+            v.grad = None
+        ray_idx = torch.randperm(H * W, generator=g)[:r]
+        pose = O.train_pose(se3, noise, pose_gt)
+        c, d = O.rays_for_pixels(pose, intr.inverse(), ray_idx, W)
+        jit = torch.rand(B * r, 1, generator=g)
+        rgb, _, _ = O.render(cfg, params, c.reshape(-1, 3), d.reshape(-1, 3), S, white_bg=True, jitter=jit,
+                             kernel_density=kern if blur else None, kernel_color=kern if blur else None)
+        (O.render_loss(rgb.view(B, r, 3), target) + 8e-5 * O.density_L1(params)).backward()
+
+    torch.set_num_threads(threads)
+    cases = [("blur_off", False, False), ("blur_on", True, False), ("blur_off_flush_denormal", False, True),
+             ("blur_on_flush_denormal", True, True)]
+    times = {name: [] for name, _, _ in cases}
+    try:
+        for rep in range(reps + 1):
+            for name, blur, flush in cases:
+                torch.set_flush_denormal(flush)
+                t0 = time.time()
+                step(blur)
+                if rep > 0:   # repetition 0 is the warm-up of every case
+                    times[name].append(time.time() - t0)
+    finally:
+        torch.set_flush_denormal(False)
+    out = {}
+    for name, ts in times.items():
+        out[name] = dict(min_ms=min(ts) * 1e3, median_ms=float(np.median(ts)) * 1e3, max_ms=max(ts) * 1e3,
+                         rays_per_s=B * r / float(np.median(ts)))
+    return dict(cases=out, rays=B * r, threads=threads, reps=reps, interleaved=True,
+                protocol="BASELINE.md 3.1: C1 (64^3, 512 rays over 4 views, S = 221), fwd + loss + bwd, 1 warm-up + %d interleaved "
+                         "repetitions per case, torch %s on the host CPUs" % (reps, torch.__version__))
+
+
 def cpu_baseline(res, S):
     """The reference algorithm on the box's host cores, same run.  `value`: a BOUNDED SAMPLE OF THE BENCH
     WORKLOAD -- the same grid and samples per ray, 4 views x 32 rays per step instead of 100 x ~20 (a step of the full
     ray batch would take minutes on the CPU).  `c1`: the reference's own CPU-sized configuration C1 (64^3, 512 rays,
     S = 221), the figure earlier lines of this file quoted."""
     main = _cpu_oracle_rate([int(v) for v in res], int(S), 32, seconds_budget=18.0)
-    c1 = _cpu_oracle_rate([64, 64, 64], 221, 128, seconds_budget=8.0)
+    c1 = _cpu_oracle_rate([64, 64, 64], 221, 128, seconds_budget=6.0)
+    try:
+        c1_protocol = _cpu_c1_protocol(c1["cores"])
+    except Exception as e:  # keep the line
+        c1_protocol = {"error": repr(e)[:300]}
     return dict(value=main["value"], unit="rays/s", cores=main["cores"], kind="port",
                 sample="bench workload at reduced ray count: grid %s, S = %d, %d rays per step (4 views x 32), fwd+loss+bwd, "
                        "blur off; best of thread counts %s: %d threads, %d reps, median %.0f ms (min %.0f / max %.0f); host "
@@ -258,7 +319,9 @@ def cpu_baseline(res, S):
                                                  main["threads_tried"], main["cores"], main["reps"], main["median_ms"],
                                                  main["min_ms"], main["max_ms"], main["host_cpus"]),
                 c1=dict(value=c1["value"], unit="rays/s", cores=c1["cores"],
-                        sample="C1: grid 64^3, 512 rays x 221 samples, median %.0f ms over %d reps" % (c1["median_ms"], c1["reps"])))
+                        sample="C1: grid 64^3, 512 rays x 221 samples, median %.0f ms over %d reps (min %.0f / max %.0f), best of "
+                               "thread counts %s" % (c1["median_ms"], c1["reps"], c1["min_ms"], c1["max_ms"], c1["threads_tried"]),
+                        protocol=c1_protocol))
 
 
 def measure_roofline(model, opt, var, reps=20):

@@ -6,12 +6,16 @@
 // accesses, coalesced across the channel lanes) of kBlurP consecutive positions along the blurred axis and
 // slides over the inputs that reach them; all factors of a scene go through one launch per pass.
 #include <algorithm>
+#include <cstdlib>
 
 #include "jt_common.h"
 
 namespace jt {
 
-constexpr int kBlurP = 8;  // outputs per thread along the blurred axis
+#ifndef JT_BLUR_P
+#define JT_BLUR_P 8
+#endif
+constexpr int kBlurP = JT_BLUR_P;  // outputs per thread along the blurred axis (a multiple of 4)
 
 // One kernel for the correlation and its adjoint.  A thread owns one channel quad of one line (all positions of
 // the non-blurred axis x channel quads) and kBlurP consecutive positions along the blurred axis: it walks the
@@ -82,8 +86,12 @@ __device__ inline void blur_axis_block(const float* __restrict__ in, float* __re
     const int qc = ADJ ? q : min(max(q, 0), n - 1);
     const float4 v = ld4(in + base + (long)qc * stride);
     const float* wrow = s_wt + (q - (p0 - r)) * kBlurP;
-    const float4 w0 = *reinterpret_cast<const float4*>(wrow), w1 = *reinterpret_cast<const float4*>(wrow + 4);
-    const float w[kBlurP] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    float w[kBlurP];
+#pragma unroll
+    for (int j = 0; j < kBlurP; j += 4) {
+      const float4 wq = *reinterpret_cast<const float4*>(wrow + j);
+      w[j] = wq.x, w[j + 1] = wq.y, w[j + 2] = wq.z, w[j + 3] = wq.w;
+    }
 #pragma unroll
     for (int j = 0; j < kBlurP; ++j) {
       acc[j].x += w[j] * v.x;
@@ -132,6 +140,169 @@ __global__ __launch_bounds__(128) void k_blur_batch(BlurBatch B) {
   blur_axis_block<ADJ>(P.in, P.out, P.H, P.W, P.C, P.along_h, P.taps, P.ntaps, local % P.gx, local / P.gx, s_dyn);
 }
 
+// ---- round 4: the same pass with the line staged in LDS -------------------------------------------------------------------
+// The kernels above let every thread fetch its own kBlurP + ntaps - 1 inputs: 9 x the bytes through the vector-memory path,
+// in 16-byte pieces 192 bytes apart (along W) or a whole row apart (along H) -- 171 us per pass over the 123 MB of a 400^3 scene's
+// factors, 23 % of what streaming them once costs (profiles/round4_blur_trace.txt).  Here a workgroup owns LINE CHUNKS: all n
+// positions along the blurred axis of one line (a row for the pass along W, a column for the pass along H) x kLineQ channel
+// quads (64 contiguous bytes per position).  The chunk is read ONCE into LDS as [quad][position] (replicate halo filled in for
+// the forward pass, zero-extended for the adjoint), every thread then slides over its kBlurP + ntaps - 1 inputs out of LDS with
+// the same block-uniform weight table, and writes its outputs.  Both passes of a plane are this one kernel with a different
+// position stride; the adjoint's two border sums (the taps that the forward's replicate padding sent to texel 0 / n - 1) are
+// two short extra sums per quad.
+constexpr int kLineQ = 4;     // channel quads per line chunk
+constexpr int kLineP = 8;     // outputs per thread
+constexpr int kLineThreads = 256;
+
+struct LinePass {
+  const float* in;
+  float* out;
+  const float* taps;
+  int n, nlines, C, ntaps;      // positions along the blurred axis, lines across it, channels
+  long pos_stride, line_stride; // floats between positions / between lines (a "line" = the other axis index)
+  int chunk0;                   // first flat chunk index of this item; chunks = nlines * (C / 4 / kLineQ)
+};
+struct LineBatch {
+  LinePass p[kBlurMaxItems];
+  int n;
+  int total;  // chunks over all items
+};
+
+template <bool ADJ>
+__global__ __launch_bounds__(kLineThreads) void k_blur_line(LineBatch B, int npad) {
+  extern __shared__ __align__(16) float s_dyn[];
+  float4* s_in = reinterpret_cast<float4*>(s_dyn);                 // [kLineQ][npad]
+  float* s_wt = s_dyn + (size_t)kLineQ * npad * 4;                 // [kLineP + ntaps - 1][kLineP]
+  // persistent: a workgroup takes a CONTIGUOUS range of chunks -- the chunks of one line (64-byte pieces of the same 128-byte
+  // lines) one after the other, so that the second and third find their lines in the cache; the weight table is rebuilt only
+  // when the tap vector changes (density / colour items)
+  const int per = (B.total + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int c_begin = (int)blockIdx.x * per, c_end = min(c_begin + per, B.total);
+  const float* cur_taps = nullptr;
+  int cur_ntaps = 0;
+  struct Desc {               // (by value: a pointer into the by-value launch argument would put the whole batch on the stack)
+    const float* src;
+    float* dst;
+    const float* taps;
+    long pos_stride;
+    int n, r, ntaps, nquad, ngroups, elems;
+  };
+  auto describe = [&](int chunk) {
+    int it = 0;
+#pragma unroll 1
+    for (int i = 1; i < B.n; ++i)
+      if (chunk >= B.p[i].chunk0) it = i;
+    Desc d;
+    const LinePass& P = B.p[it];
+    d.taps = P.taps, d.pos_stride = P.pos_stride;
+    d.ntaps = P.ntaps, d.r = d.ntaps / 2, d.n = P.n;
+    const int C4 = P.C / 4, cpl = (C4 + kLineQ - 1) / kLineQ;   // chunks per line (the last may be partial: VM-20 has 5 quads)
+    const int local = chunk - P.chunk0;
+    const int line = local / cpl, cq = local - line * cpl;
+    d.nquad = min(kLineQ, C4 - cq * kLineQ);
+    d.src = P.in + (long)line * P.line_stride + cq * (kLineQ * 4);
+    d.dst = P.out + (long)line * P.line_stride + cq * (kLineQ * 4);
+    d.ngroups = (d.n + kLineP - 1) / kLineP;
+    // positions -r .. (n rounded up to whole groups) + r - 1: forward = replicate padding, adjoint = zeros outside (the window
+    // of the last group reaches past n + r - 1; its weights there are zero, the values must still be finite)
+    d.elems = (d.ngroups * kLineP + 2 * d.r) * kLineQ;
+    return d;
+  };
+  auto element = [&](const Desc& d, int idx) {
+    const int q = idx % kLineQ, pos = idx / kLineQ - d.r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < d.nquad && (!ADJ || (pos >= 0 && pos < d.n)))
+      v = ld4(d.src + (long)min(max(pos, 0), d.n - 1) * d.pos_stride + q * 4);
+    return v;
+  };
+  // (fetching the next chunk into registers while this one is computed was measured: 92 / 109 us per pass against 98 / 101 --
+  //  the pass is not waiting for its loads, profiles/round4_blur_trace.txt)
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    const Desc d = describe(chunk);
+    const Desc& P = d;
+    const int ntaps = d.ntaps, r = d.r, n = d.n, nq = kLineP + ntaps - 1, nquad = d.nquad, ngroups = d.ngroups;
+    float* dst = d.dst;
+    float* s_cum = s_wt + nq * kLineP;                // [ntaps + 1] (adjoint: prefix sums of the taps)
+    __syncthreads();                                  // the previous chunk's readers are done with the LDS
+    // weight table Wt[qi][j]: input p0 - r + qi feeds output p0 + j with taps[t], t = qi - j (forward) / 2 r - (qi - j) (adjoint)
+    if (P.taps != cur_taps || ntaps != cur_ntaps) {
+      cur_taps = P.taps, cur_ntaps = ntaps;
+      for (int idx = threadIdx.x; idx < nq * kLineP; idx += kLineThreads) {
+        const int qi = idx / kLineP, j = idx - qi * kLineP;
+        const int t = ADJ ? 2 * r - (qi - j) : qi - j;
+        s_wt[idx] = (t >= 0 && t < ntaps) ? P.taps[t] : 0.f;
+      }
+      if (ADJ && threadIdx.x < 64) {   // inclusive prefix of the taps by one wave: s_cum[t] = sum of taps[0 .. t-1]
+        float carry = 0.f;
+        for (int t0 = 0; t0 < ntaps; t0 += 64) {
+          const int t = t0 + (int)threadIdx.x;
+          float v = t < ntaps ? P.taps[t] : 0.f;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const float u = __shfl_up(v, o);
+            if ((int)threadIdx.x >= o) v += u;
+          }
+          if (t < ntaps) s_cum[t + 1] = carry + v;
+          carry += __shfl(v, 63);
+        }
+        if (threadIdx.x == 0) s_cum[0] = 0.f;
+      }
+    }
+    for (int idx = threadIdx.x; idx < d.elems; idx += kLineThreads) s_in[(idx % kLineQ) * npad + idx / kLineQ] = element(d, idx);
+    __syncthreads();
+    for (int item = threadIdx.x; item < ngroups * kLineQ; item += kLineThreads) {
+      const int q = item % kLineQ, p0 = (item / kLineQ) * kLineP;
+      if (q >= nquad) continue;
+      const float4* row = s_in + q * npad + p0;       // input p0 - r + qi sits at row[qi]
+      float4 acc[kLineP];
+#pragma unroll
+      for (int j = 0; j < kLineP; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+      for (int qi = 0; qi < nq; ++qi) {
+        const float4 v = row[qi];
+        const float4 w0 = *reinterpret_cast<const float4*>(s_wt + qi * kLineP);
+        const float4 w1 = *reinterpret_cast<const float4*>(s_wt + qi * kLineP + 4);
+        const float w[kLineP] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int j = 0; j < kLineP; ++j) {
+          acc[j].x += w[j] * v.x;
+          acc[j].y += w[j] * v.y;
+          acc[j].z += w[j] * v.z;
+          acc[j].w += w[j] * v.w;
+        }
+      }
+      if (ADJ) {
+        // what the forward's replicate padding read from texel 0 (positions < 0) and texel n - 1 (positions >= n) comes back to
+        // them: g_in[0] += sum_x g[x] sum_{t < r - x} k[t],  g_in[n-1] += sum_x g[x] sum_{t >= n - x + r} k[t]
+        if (p0 == 0) {
+          float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int x = 0; x < min(r, n); ++x) {
+            const float c = s_cum[r - x];
+            const float4 g = s_in[q * npad + x + r];
+            e.x += c * g.x, e.y += c * g.y, e.z += c * g.z, e.w += c * g.w;
+          }
+          acc[0].x += e.x, acc[0].y += e.y, acc[0].z += e.z, acc[0].w += e.w;
+        }
+        if (p0 <= n - 1 && n - 1 < p0 + kLineP) {
+          float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int x = max(n - r, 0); x < n; ++x) {
+            const float c = s_cum[ntaps] - s_cum[min(max(n - x + r, 0), ntaps)];
+            const float4 g = s_in[q * npad + x + r];
+            e.x += c * g.x, e.y += c * g.y, e.z += c * g.z, e.w += c * g.w;
+          }
+          const int j = n - 1 - p0;
+#pragma unroll
+          for (int jj = 0; jj < kLineP; ++jj)
+            if (jj == j) acc[jj].x += e.x, acc[jj].y += e.y, acc[jj].z += e.z, acc[jj].w += e.w;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kLineP; ++j)
+        if (p0 + j < n) *reinterpret_cast<float4*>(dst + (long)(p0 + j) * P.pos_stride + q * 4) = acc[j];
+    }
+  }
+}
+
 }  // namespace jt
 
 using namespace jt;
@@ -145,8 +316,13 @@ static int blur_args(const void* a, const void* b, const void* tmp, int H, int W
 }
 
 template <bool ADJ>
+static bool launch_line_batch(const BlurPass* passes, int n, hipStream_t st);
+
+template <bool ADJ>
 static void launch_blur_axis(const float* in, float* out, int H, int W, int C, int along_h, const float* taps,
                              int n_taps, hipStream_t st) {
+  BlurPass one = {in, out, taps, H, W, C, along_h, n_taps, 0, 0};
+  if (launch_line_batch<ADJ>(&one, 1, st)) return;
   const int n = along_h ? H : W;
   const int nlines = (along_h ? W : H) * (C / 4);
   const int threads = nlines >= 4096 ? 256 : (nlines >= 128 ? 128 : 64);
@@ -188,6 +364,46 @@ extern "C" int jt_blur_backward(const float* g_out, float* g_in, float* tmp, int
   return JT_OK;
 }
 
+// the LDS-staged line kernel for one pass of a batch; false = a shape it does not take (the caller falls back)
+template <bool ADJ>
+static bool launch_line_batch(const BlurPass* passes, int n, hipStream_t st) {
+  static const bool enabled = [] { const char* e = getenv("JT_BLUR_LDS"); return !e || atoi(e) != 0; }();
+  if (!enabled) return false;
+  LineBatch L;
+  L.n = n;
+  int total = 0, max_n = 1, max_taps = 1;
+  for (int i = 0; i < n; ++i) {
+    const BlurPass& P = passes[i];
+    LinePass& Q = L.p[i];
+    Q.in = P.in, Q.out = P.out, Q.taps = P.taps, Q.C = P.C, Q.ntaps = P.ntaps;
+    if (P.along_h) {
+      Q.n = P.H, Q.nlines = P.W, Q.pos_stride = (long)P.W * P.C, Q.line_stride = P.C;
+    } else {
+      Q.n = P.W, Q.nlines = P.H, Q.pos_stride = P.C, Q.line_stride = (long)P.W * P.C;
+    }
+    Q.chunk0 = total;
+    total += Q.nlines * ((P.C / 4 + kLineQ - 1) / kLineQ);
+    max_n = std::max(max_n, Q.n);
+    max_taps = std::max(max_taps, P.ntaps);
+  }
+  L.total = total;
+  // [quad][npad] with npad = 2 mod 16 float4s: the four quads of a 16-lane LDS group land on different bank quarters
+  int npad = (max_n + kLineP - 1) / kLineP * kLineP + max_taps;
+  npad += (18 - (npad % 16)) % 16;
+  const size_t lds = ((size_t)kLineQ * npad * 4 + (size_t)(kLineP + max_taps - 1) * kLineP + max_taps + 1) * sizeof(float);
+  if (lds > 64 * 1024) return false;  // (two workgroups per CU at least)
+  static bool attr[2] = {false, false};
+  if (!attr[ADJ]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_line<ADJ>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              64 * 1024);
+    attr[ADJ] = true;
+  }
+  const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / (lds + 512))));
+  const int blocks = std::min(total, 256 * per_cu);
+  hipLaunchKernelGGL(k_blur_line<ADJ>, dim3(blocks), dim3(kLineThreads), lds, st, L, npad);
+  return true;
+}
+
 // pass 0 / 1 of the batch: planes run (W, then H) forward and (H, then W) backward; lines have one pass
 template <bool ADJ>
 static int launch_blur_batch(const JtBlurItem* items, int n_items, int pass, hipStream_t st) {
@@ -223,6 +439,10 @@ static int launch_blur_batch(const JtBlurItem* items, int n_items, int pass, hip
     ++B.n;
   }
   if (B.n == 0) return JT_OK;
+  if (launch_line_batch<ADJ>(B.p, B.n, st)) {
+    JT_LAUNCH_CHECK();
+    return JT_OK;
+  }
   const size_t lds = ((size_t)(kBlurP + max_taps - 1) * kBlurP + 2 * max_taps + 1) * sizeof(float);
   hipLaunchKernelGGL(k_blur_batch<ADJ>, dim3(blocks), dim3(128), lds, st, B);
   JT_LAUNCH_CHECK();

@@ -615,11 +615,13 @@ class Model(torch.nn.Module):
             if key == "L1":
                 first = opt.train_schedule.update_alphamask_iters[0]
                 w = float(opt.loss_weight.L1.rest if self.it > first else opt.loss_weight.L1.init)
-                total = total + w * loss["L1"]
+                total = total + w * float(getattr(self, "_reg_scale", 1.0)) * loss["L1"]
             elif opt.loss_weight[key] is not None:
                 w = float(opt.loss_weight[key])
                 if key == "render":
                     w *= render_scale
+                else:
+                    w *= float(getattr(self, "_reg_scale", 1.0))
                 if w != 0.0:
                     total = total + w * loss[key]
         loss.update(all=total)
@@ -648,7 +650,8 @@ class Model(torch.nn.Module):
         w_l1 = float(opt.loss_weight.L1.rest if self.it > first else opt.loss_weight.L1.init)
         w_tvd = float(opt.loss_weight.TV_density or 0.0) * float(getattr(self.graph.tvloss, "TVLoss_weight", 1))
         w_tvc = float(opt.loss_weight.TV_color or 0.0) * float(getattr(self.graph.tvloss, "TVLoss_weight", 1))
-        return float(opt.loss_weight.render) * render_scale, w_l1, w_tvd, w_tvc
+        rs = float(getattr(self, "_reg_scale", 1.0))   # 0 for the later ray groups of a split iteration
+        return float(opt.loss_weight.render) * render_scale, w_l1 * rs, w_tvd * rs, w_tvc * rs
 
     def train_iteration(self, opt, var):
         """One optimisation step (model/bat.py:96-116 around model/base.py:154-172)."""
@@ -662,14 +665,18 @@ class Model(torch.nn.Module):
         #  iteration, model/base.py:118, so opt.optim.grad_accum_iter > 1 only thins out the optimizer steps)
         self.optim.zero_grad()
         ops.PROFILING = bool(_has(opt, "profiling") and opt.profiling)  # roctx ranges named as model/base.py:119-153
-        with ops.prof_range("graph.forward"):
-            var = g.forward(opt, var, mode="train")
-        with ops.prof_range("graph.compute_loss"):
-            loss = g.compute_loss(opt, var, mode="train")
-        with ops.prof_range("summarize_loss"):
-            loss = self.summarize_loss(opt, var, loss)
-        with ops.prof_range("loss.all.backward()"):
-            loss.all.backward(gradient=self._backward_seed(loss.all))  # (a cached ones tensor: no fill launch per iteration)
+        groups = self.tape_groups(opt)
+        if groups > 1:
+            loss = self._forward_backward_in_groups(opt, var, groups)
+        else:
+            with ops.prof_range("graph.forward"):
+                var = g.forward(opt, var, mode="train")
+            with ops.prof_range("graph.compute_loss"):
+                loss = g.compute_loss(opt, var, mode="train")
+            with ops.prof_range("summarize_loss"):
+                loss = self.summarize_loss(opt, var, loss)
+            with ops.prof_range("loss.all.backward()"):
+                loss.all.backward(gradient=self._backward_seed(loss.all))  # (a cached ones tensor: no fill launch per iteration)
         self.reduce_pose_gradients()
         if (not _has(opt.optim, "grad_accum_iter")) or (self.it % opt.optim.grad_accum_iter) == 0:
             with ops.prof_range("optim.step"):
@@ -685,6 +692,57 @@ class Model(torch.nn.Module):
             self.sched_pose.step()
         g.nerf.set_progress(self.it / opt.max_iter)
         return loss
+
+    # ---- an iteration whose autograd tape would not fit a memory budget: forward + backward over ray groups -------------
+    def tape_groups(self, opt):
+        """How many ray groups this iteration's forward + backward is split into so that the tape of the fused appearance
+        chain (1 920 bytes per shaded sample, sized for rays x samples) stays under opt.tape_budget_gb (default 16; the
+        environment variable JT_TAPE_BUDGET_GB overrides; 0 = never split).  1 for every training configuration of the yamls
+        (2 048 - 20 480 rays: 0.6 - 11 GB); BASELINE.json configs[3] on ONE GPU (62 500 rays x 1 000 samples: 120 GB worst case,
+        86 GB sized by the shaded count) runs as 8 groups of 7 800 rays."""
+        import os
+        g = self.graph
+        if g.ray_shard is not None or opt.nerf.ray_sampling_strategy != "all_view_rand_grid" or g.lattice_override is not None:
+            return 1
+        budget = float(os.environ.get("JT_TAPE_BUDGET_GB", opt.get("tape_budget_gb", 16.0) or 0.0))
+        if budget <= 0:
+            return 1
+        need = float(opt.nerf.n_rays) * float(g.nerf.n_samples) * 1920.0
+        return max(1, int(math.ceil(need / (budget * 2 ** 30))))
+
+    def _forward_backward_in_groups(self, opt, var, groups):
+        """The iteration's lattice rendered as `groups` pixel shards (lattice points k::groups of every view -- the partition
+        ray-sharded data parallelism uses, Graph.ray_shard), each with its own forward, loss and backward: the photometric term
+        is a mean over ALL rays, so shard k contributes its own mean x its share of the rays (var.dp_render_scale), and the
+        regularisers, which do not depend on the rays, enter with the first shard only.  Gradients accumulate in .grad as
+        autograd always does; a shard's tape is gone before the next shard's forward.  Every shard consumes the SAME host /
+        device draws (lattice offsets, blur scale, white-background coin, jitter stream): the random streams are rewound to the
+        iteration's start before each shard and left where ONE forward leaves them."""
+        g = self.graph
+        state = (np.random.get_state(), torch.get_rng_state(), torch.cuda.get_rng_state(torch.device(opt.device)))
+        total = None
+        out = None
+        try:
+            for k in range(groups):
+                self._reg_scale = 1.0 if k == 0 else 0.0   # (fused_loss_weights / summarize_loss: regularisers with shard 0 only)
+                if k > 0:
+                    np.random.set_state(state[0])
+                    torch.set_rng_state(state[1])
+                    torch.cuda.set_rng_state(state[2], torch.device(opt.device))
+                g.ray_shard = ("pixel", k, groups)
+                v = g.forward(opt, Opt(dict(var)), mode="train")
+                loss = g.compute_loss(opt, v, mode="train")
+                loss = self.summarize_loss(opt, v, loss)
+                loss.all.backward(gradient=self._backward_seed(loss.all))
+                total = loss.all.detach() if total is None else total + loss.all.detach()
+                if out is None:
+                    out = loss   # (the logged terms are shard 0's; the iteration's total is in `all`)
+                del v, loss
+        finally:
+            g.ray_shard = None
+            self._reg_scale = 1.0
+        out.update(all=total)
+        return out
 
     def _backward_seed(self, t):
         key = (t.shape, t.dtype, str(t.device))
@@ -965,14 +1023,106 @@ class Model(torch.nn.Module):
         # that follows sees the refinement from before the last Adam step (model/bat.py:284, model/nerf.py:539)
         return var
 
+    @torch.enable_grad()
+    def evaluate_test_time_photometric_optim_batched(self, opt, views):
+        """model/bat.py:265-292 for SEVERAL held-out views at once.  The reference optimises the 200 test
+        views one after the other, 400 - 600 iterations each: 80 000 launch-bound iterations per evaluation.  The per-view
+        problems are independent -- a view's own se(3) vector, its own Adam moments, its own lattice draws, a photometric loss
+        over its own rays -- so V of them run as ONE iteration: a [V, 6] parameter under one Adam (element-wise: every row is
+        the serial run's state), every view's rays on ITS lattice (ragged: the lattice size depends on the offsets)
+        concatenated into one ray batch through the pose-only backward, one photometric mean PER VIEW, summed.  The host
+        draws are taken up front in the reference's order (view by view, iteration by iteration: two lattice offsets and the
+        density-blur scale), so every view sees exactly the draws of the serial run and the process's random stream ends where
+        the serial run leaves it.  Returns the views (dicts) with se3_refine_test [1, 6] / pose_refine_test as the serial
+        routine leaves them -- pose_refine_test from the top of the LAST iteration (the reference's quirk, model/bat.py:284).
+        Falls back to the serial routine when a factor blur is active at test time (per-view blur scales cannot share a
+        render) or for a single view."""
+        g = self.graph
+        V, T, dev = len(views), int(opt.optim.test_iter), opt.device
+        blur_possible = g.resolve_blur(opt, "vis")[2] is not None or (
+            opt.data.dataset == "llff" and max(float(v) for v in opt.optim.test_kernel_schedule) >= 0.001)
+        if V <= 1 or blur_possible or opt.nerf.ray_sampling_strategy != "all_view_rand_grid" or \
+                (_has(opt.optim, "test_fused") and opt.optim.test_fused):
+            return [self.evaluate_test_time_photometric_optim(opt, v) for v in views]
+        step = g.lattice_step(opt, 1)
+        draw_scale = _has(opt, "c2f_random_density_blur") and opt.c2f_random_density_blur and opt.model in ("bat", "bat_hip") \
+            and opt.c2f_mode != "None"
+        draws = []
+        for v in range(V):      # the serial run's order of host draws: Graph.forward (ox, oy), then Graph.resolve_blur (scale)
+            row = []
+            for it in range(T):
+                ox, oy = np.random.randint(step), np.random.randint(step)
+                if draw_scale:
+                    np.random.choice(opt.c2f_random_density_scale_pool)
+                row.append((ox, oy))
+            draws.append(row)
+        se3 = torch.nn.Parameter(torch.zeros(V, 6, device=dev))
+        kw = dict(fused=True) if str(dev).startswith("cuda") else {}
+        optim_pose = torch.optim.Adam([dict(params=[se3], lr=opt.optim.lr_pose)], **kw)
+        gamma = (opt.optim.lr_pose_test_end / opt.optim.lr_pose_test) ** (1.0 / opt.optim.test_iter)
+        sched_pose = torch.optim.lr_scheduler.ExponentialLR(optim_pose, gamma=gamma)
+        frozen = [p for p in g.parameters() if p.requires_grad]
+        for p in frozen:
+            p.requires_grad_(False)
+        eye = torch.eye(3, 4, device=dev)
+        bv = Opt(idx=torch.arange(V, device=dev), pose=torch.cat([v["pose"].to(dev) for v in views], 0))
+        intr = torch.cat([v["intr"].to(dev) for v in views], 0)
+        intr_inv = torch.cat([v["intr_inv"].to(dev) for v in views], 0)
+        images = [v["image"].to(dev) for v in views]
+        ndc_near = float(opt.arch.ndc_near_plane) if _has(opt.arch, "ndc_near_plane") else 1.0
+        w_render = float(opt.loss_weight.render)
+        pose_refine = None
+        try:
+            for it in range(T):
+                g.nerf.test_time_progress_host = it / T
+                g.nerf.test_time_progress.data.fill_(it / T)
+                optim_pose.zero_grad()
+                pose_refine = ops.train_pose(se3, None, eye)               # se3_to_SE3 of every view (camera.py:81-99)
+                bv.pose_refine_test = pose_refine
+                pose = g.get_pose(opt, bv, mode="test-optim")              # [V, 3, 4]
+                centers, rays, idxs = [], [], []
+                for v in range(V):
+                    ox, oy = draws[v][it]
+                    nx, ny = len(range(ox, opt.W, step)), len(range(oy, opt.H, step))
+                    ridx = g._lattice_at(opt, step, ny, nx, ox, oy)
+                    c, d = ops.ray_gen(pose[v:v + 1], intr_inv[v:v + 1], intr[v:v + 1], ridx, opt.W, ndc=bool(opt.camera.ndc),
+                                       ndc_near=ndc_near)
+                    centers.append(c.reshape(-1, 3))
+                    rays.append(d.reshape(-1, 3))
+                    idxs.append(ridx)
+                center, ray = torch.cat(centers, 0), torch.cat(rays, 0)
+                g._blur_memo = (None, None, None, None)                    # (this call's blur draw was taken above)
+                ret = g.render_rays(opt, center[None], ray[None], mode="test-optim", n_views=1, n_pixels_per_view=center.shape[0])
+                rgb = ret.rgb.view(-1, 3)
+                total, o = None, 0
+                for v in range(V):
+                    r = idxs[v].numel()
+                    term = ops.render_loss(rgb[o:o + r].view(1, r, 3), images[v], idxs[v])   # the view's OWN mean
+                    total = term if total is None else total + term
+                    o += r
+                (w_render * total).backward()
+                optim_pose.step()
+                sched_pose.step()
+        finally:
+            for p in frozen:
+                p.requires_grad_(True)
+        out = []
+        for v, view in enumerate(views):
+            view = Opt(dict(view))
+            view.se3_refine_test = torch.nn.Parameter(se3.detach()[v:v + 1].clone())
+            view.pose_refine_test = pose_refine.detach()[v:v + 1].clone()
+            view.test_optimised = True
+            out.append(view)
+        return out
+
     @torch.no_grad()
     def evaluate_view(self, opt, var, eps=1e-10):
         """The per-view body of nerf.Model.evaluate_full (model/nerf.py:534-548): optional test-time pose
         optimisation, the sliced full-image render and PSNR.  SSIM / LPIPS need packages outside this build."""
         g = self.graph
         g.eval()
-        if opt.model in ("barf", "bat", "bat_hip") and opt.optim.test_photo:
-            var = self.evaluate_test_time_photometric_optim(opt, var)
+        if opt.model in ("barf", "bat", "bat_hip") and opt.optim.test_photo and not var.get("test_optimised", False):
+            var = self.evaluate_test_time_photometric_optim(opt, var)   # (already done for views of a batched optimisation)
         var = g.forward(opt, var, mode="eval")
         invdepth = var.depth if opt.camera.ndc else 1 / (var.depth / var.opacity + eps)
         rgb_map = var.rgb.view(-1, opt.H, opt.W, 3).permute(0, 3, 1, 2)
@@ -997,7 +1147,16 @@ class Model(torch.nn.Module):
         world, rank = (dist.get_world_size(), dist.get_rank()) if (dist.is_available() and dist.is_initialized()) else (1, 0)
         test_views = list(test_views)
         mine = list(range(rank, len(test_views), world))
-        res = [self.evaluate_view(opt, Opt(dict(test_views[i]))) for i in mine]
+        # opt.optim.test_batch = V > 1: the test-time pose optimisation of V views at a time (one iteration serves V views;
+        # every view's trajectory is the serial one: evaluate_test_time_photometric_optim_batched)
+        V = int(opt.optim.get("test_batch", 0) or 0)
+        mine_views = [Opt(dict(test_views[i])) for i in mine]
+        if V > 1 and opt.model in ("barf", "bat", "bat_hip") and opt.optim.test_photo:
+            done = []
+            for a in range(0, len(mine_views), V):
+                done += self.evaluate_test_time_photometric_optim_batched(opt, mine_views[a:a + V])
+            mine_views = done
+        res = [self.evaluate_view(opt, v) for v in mine_views]
         psnr = torch.full((len(test_views),), float("nan"), device=opt.device, dtype=torch.float64)
         for i, r in zip(mine, res):
             psnr[i] = r.psnr

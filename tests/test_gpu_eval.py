@@ -169,3 +169,47 @@ def test_evaluate_full_runs_end_to_end():
     assert len(out.views) == 2 and len(out.psnr_per_view) == 2 and np.isfinite(out.psnr)
     assert 5.0 < out.psnr < 15.0  # random target image: ~9 dB
     assert model.graph.sim3 is not None
+
+
+def test_batched_test_time_optim_reproduces_the_serial_trajectories():
+    """V held-out views optimised in ONE iteration each (Model.evaluate_test_time_photometric_optim_batched: a
+    [V, 6] parameter, every view on its own lattice draws, a photometric mean per view) against the reference's serial loop
+    (model/bat.py:265-292) on the same views from the same random stream, in JT_DETERMINISTIC mode (order-independent sums):
+    every view's se(3) vector, its refinement pose and its PSNR are the serial run's, and the host random stream ends where
+    the serial run leaves it."""
+    from joint_tensorf_amd._lib import lib
+    from joint_tensorf_amd.options import Opt
+    from joint_tensorf_amd.synthetic import make_views
+    fx = Fixture("blender_test_optim")
+    opt, model = _model(fx)
+    opt.optim.test_iter = 6
+    g = model.graph
+    g.sim3 = Opt(t0=fx.t("sim3.t0", "cuda"), t1=fx.t("sim3.t1", "cuda"), s0=fx.t("sim3.s0", "cuda"),
+                 s1=fx.t("sim3.s1", "cuda"), R=fx.t("sim3.R", "cuda"))
+    tv = make_views(opt, 3, seed=21, device="cuda")
+    views = [Opt(idx=torch.arange(1, device="cuda"), pose=tv.pose[i:i + 1], intr=tv.intr[i:i + 1], intr_inv=tv.intr_inv[i:i + 1],
+                 image=tv.image[i:i + 1]) for i in range(3)]
+    prev = lib.jt_set_deterministic(1)
+    try:
+        np.random.seed(77)
+        serial = [model.evaluate_test_time_photometric_optim(opt, Opt(dict(v))) for v in views]
+        end_serial = np.random.get_state()[1][:6].tolist(), np.random.get_state()[2]
+        np.random.seed(77)
+        batched = model.evaluate_test_time_photometric_optim_batched(opt, [Opt(dict(v)) for v in views])
+        end_batched = np.random.get_state()[1][:6].tolist(), np.random.get_state()[2]
+    finally:
+        lib.jt_set_deterministic(prev)
+    assert end_serial == end_batched
+    assert len(batched) == 3 and all(b.test_optimised for b in batched)
+    for s, b in zip(serial, batched):
+        a, c = s.se3_refine_test.detach(), b.se3_refine_test.detach()
+        assert float(a.abs().max()) > 1e-3        # the optimisation moved the pose
+        assert torch.equal(a, c), (a, c)
+        assert torch.equal(s.pose_refine_test.detach(), b.pose_refine_test.detach())
+    # and through evaluate_full: opt.optim.test_batch renders the same views to the same PSNR as the serial evaluation
+    np.random.seed(78)
+    ref = model.evaluate_full(opt, [Opt(dict(v)) for v in views], fx.t("in.pose_gt", "cuda"))
+    opt.optim.test_batch = 3
+    np.random.seed(78)
+    out = model.evaluate_full(opt, [Opt(dict(v)) for v in views], fx.t("in.pose_gt", "cuda"))
+    np.testing.assert_allclose(out.psnr_per_view, ref.psnr_per_view, atol=2e-3)

@@ -27,6 +27,8 @@ def main():
                     help="test-time optimisation through the single-launch fused kernel (csrc/jt_fused.hip, "
                          "opt.optim.test_fused) instead of the staged kernels + pose-only backward")
     ap.add_argument("--no-render", action="store_true", help="skip the full-image render timing")
+    ap.add_argument("--batch-views", default="", help="also time the BATCHED test-time optimisation (Model."
+                    "evaluate_test_time_photometric_optim_batched) for these view counts, e.g. 1,8,32: ms per view-iteration")
     args = ap.parse_args()
     sys.argv = [sys.argv[0]]
     import bench
@@ -79,8 +81,21 @@ def main():
     v = model.evaluate_test_time_photometric_optim(opt, Opt(dict(var)))
     torch.cuda.synchronize()
     t_opt = (time.perf_counter() - t0) / args.test_iters
+    batched = {}
+    if args.batch_views and not args.graph and not args.fused:
+        for V in [int(x) for x in args.batch_views.split(",")]:
+            bvs = make_views(opt, V, seed=9, device=dev)
+            vs = [Opt(idx=torch.arange(1, device=dev), pose=bvs.pose[i:i + 1], intr=bvs.intr[i:i + 1],
+                      intr_inv=bvs.intr_inv[i:i + 1], image=bvs.image[i:i + 1]) for i in range(V)]
+            model.evaluate_test_time_photometric_optim_batched(opt, [Opt(dict(x)) for x in vs])   # warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.evaluate_test_time_photometric_optim_batched(opt, [Opt(dict(x)) for x in vs])
+            torch.cuda.synchronize()
+            batched[str(V)] = (time.perf_counter() - t0) / args.test_iters / V * 1e3
     rays = args.size * args.size
     print(json.dumps({
+        "test_time_optim_batched_ms_per_view_iteration": batched or None,
         "eval_render": {"image": [args.size, args.size], "samples_per_ray": int(g.nerf.n_samples),
                         "grid": g.nerf.tensorf.gridSize.tolist(), "ms_per_image": t_render * 1e3,
                         "rays_per_s": rays / t_render, "launch": "hipGraph replay" if args.graph else "eager", "Msamples_per_s": rays * g.nerf.n_samples / t_render / 1e6},
