@@ -521,6 +521,24 @@ def run_extras():
                          "test_time_pose_optim_rays_per_iter": j["test_time_optim"]["rays_per_iter"]}
         except Exception as ex:
             out[name] = {"error": repr(ex)[:200]}
+    # test-time pose optimisation of V held-out views per iteration (Model.evaluate_test_time_photometric_optim_batched): ms per
+    # VIEW-iteration, eager, against the serial eager loop of the same process (V = 1) -- the reference runs 200 views x 400
+    # iterations one after the other (model/bat.py:265-292)
+    for name, flags in (("eval_test_time_optim_batched_dense_scene", []), ("eval_test_time_optim_batched_blob_scene", ["--scene", "blobs"])):
+        try:
+            r = subprocess.run([sys.executable, tool, "--no-render", "--test-iters", "40", "--batch-views", "1,8,32"] + flags,
+                               capture_output=True, text=True, timeout=300)
+            j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            out[name] = {"ms_per_view_iteration_by_views_per_iteration": j["test_time_optim_batched_ms_per_view_iteration"],
+                         "serial_eager_ms_per_iter": j["test_time_optim"]["ms_per_iter"],
+                         "rays_per_view_iteration": j["test_time_optim"]["rays_per_iter"]}
+        except Exception as ex:
+            out[name] = {"error": repr(ex)[:200]}
+    for k in ("fitted_scene_eager", "fitted_scene_hipgraph"):
+        if k in out and "error" not in out[k]:
+            out[k]["note"] = ("the model HOLDS the ground-truth field (4 % of the nominal samples shaded): a lower bound -- the final "
+                              "stage of a run TRAINED on that scene measures 2.8 ms per iteration (profiles/round3_full_schedule_"
+                              "rendered_scene.jsonl); the dense headline is the representative case")
     return out
 
 
@@ -597,6 +615,7 @@ def main():
         from joint_tensorf_amd.graphed import GraphedTrainStep
         stepper = GraphedTrainStep(model, min_repeats=0)
     use_graph = [False]
+    tape_groups_used = [1]
 
     def one_step():
         nonlocal rays_total
@@ -611,11 +630,20 @@ def main():
             return
         g.it = model.it
         model.optim.zero_grad()
-        var = g.forward(opt, var, mode="train")
-        loss = g.compute_loss(opt, var, mode="train")
-        loss = model.summarize_loss(opt, var, loss)
-        # (render term scaled to its share of the global mean: var.dp_render_scale; the seed is Model.train_iteration's cached ones)
-        loss.all.backward(gradient=model._backward_seed(loss.all))
+        groups = model.tape_groups(opt)
+        if groups > 1:
+            # an iteration whose tape would not fit the memory budget (configs[3] on ONE GPU: 62 500 rays): forward + backward
+            # over ray groups, as Model.train_iteration does it
+            tape_groups_used[0] = groups
+            loss = model._forward_backward_in_groups(opt, var, groups)
+            n_step = int(sum(model.graph._group_rays))
+        else:
+            var = g.forward(opt, var, mode="train")
+            loss = g.compute_loss(opt, var, mode="train")
+            loss = model.summarize_loss(opt, var, loss)
+            # (render term scaled to its share of the global mean: var.dp_render_scale; the seed is Model.train_iteration's cached ones)
+            loss.all.backward(gradient=model._backward_seed(loss.all))
+            n_step = var.rgb.shape[0] * var.rgb.shape[1]
         model.reduce_pose_gradients()
         if os.environ.get("JT_BENCH_CHECKSUM") == "1":
             with torch.no_grad():
@@ -636,7 +664,7 @@ def main():
             model.sched_pose.step()
         nerf.set_progress(model.it / opt.max_iter)
         model.after_iteration(opt)
-        rays_total += var.rgb.shape[0] * var.rgb.shape[1]
+        rays_total += n_step
 
     def barrier():
         if world > 1 or FORCE_DIST:
@@ -784,6 +812,7 @@ def main():
                 "launch": ("hipGraph replay (%(replayed)d replayed / %(captured)d captured / %(eager)d eager steps)"
                            % stepper.stats) if stepper is not None else "eager",
                 "abi_calls_per_step": n_calls[0] or None,
+                "ray_groups_per_iteration": tape_groups_used[0],
                 "parallelism": ("ray-sharded data parallel x%d (%s shards of ONE %d-nominal-ray iteration = %d rays: the "
                                 "ranks together render exactly the single-process iteration), all-reduce of the VM-factor / "
                                 "basis / MLP gradients inside the backward + pose gradients behind it"

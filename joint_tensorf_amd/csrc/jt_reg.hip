@@ -115,7 +115,36 @@ struct RegBatch {
   int n;
 };
 
-__global__ __launch_bounds__(256) void k_reg_batch_fwd(RegBatch B, float* __restrict__ scratch36) {
+// the normalisation table of the combine step: (H, W, C) of the nine regularised tensors (0-2 density planes, 3-5 density
+// lines, 6-8 appearance planes)
+struct RegDims {
+  int H[9], W[9], C[9];
+};
+
+// out3 = {L1, TV_density, TV_color} with the reference's normalisations (tensoRF.py:212-228, tensorBase.py:21-38)
+__device__ inline void reg_combine(const float* sums, const RegDims& S, float* __restrict__ out3) {
+  float l1 = 0.f, tvd = 0.f, tva = 0.f;
+  for (int i = 0; i < 6; ++i) l1 += sums[i * 3] / ((float)S.H[i] * S.W[i] * S.C[i]);
+  for (int i = 0; i < 3; ++i) {
+    float ta = 0.f, tb = 0.f;
+    if (S.H[i] > 1) ta += sums[i * 3 + 1] / ((float)S.C[i] * (S.H[i] - 1) * S.W[i]);
+    if (S.W[i] > 1) ta += sums[i * 3 + 2] / ((float)S.C[i] * S.H[i] * (S.W[i] - 1));
+    const int b = 6 + i;
+    if (S.H[b] > 1) tb += sums[b * 3 + 1] / ((float)S.C[b] * (S.H[b] - 1) * S.W[b]);
+    if (S.W[b] > 1) tb += sums[b * 3 + 2] / ((float)S.C[b] * S.H[b] * (S.W[b] - 1));
+    tvd += 2.f * ta * 1e-2f;
+    tva += 2.f * tb * 1e-2f;
+  }
+  out3[0] = l1;
+  out3[1] = tvd;
+  out3[2] = tva;
+}
+
+// ONE launch (round 4; before: a zero fill of the scratch, this kernel, a combine kernel).  Every workgroup adds its partial sums
+// into scratch[0 .. 35] and takes a ticket from scratch[36]; the workgroup that draws the last ticket combines the 27 sums into
+// out3 and puts the scratch back to zero -- the scratch must be ZERO when the first call sees it and is left zero by every call.
+__global__ __launch_bounds__(256) void k_reg_batch_fwd(RegBatch B, RegDims S, float* __restrict__ scratch40,
+                                                       float* __restrict__ out3) {
   int it = 0;
 #pragma unroll 1
   for (int i = 1; i < B.n; ++i)
@@ -123,9 +152,25 @@ __global__ __launch_bounds__(256) void k_reg_batch_fwd(RegBatch B, float* __rest
   const RegBatchItem& T = B.t[it];
   const int bid = blockIdx.x - T.block0;
   if (T.tv)
-    factor_reg_fwd_body<true>(T.x, T.H, T.W, T.C, scratch36 + T.slot * 3, bid, T.nblocks);
+    factor_reg_fwd_body<true>(T.x, T.H, T.W, T.C, scratch40 + T.slot * 3, bid, T.nblocks);
   else
-    factor_reg_fwd_body<false>(T.x, T.H, T.W, T.C, scratch36 + T.slot * 3, bid, T.nblocks);
+    factor_reg_fwd_body<false>(T.x, T.H, T.W, T.C, scratch40 + T.slot * 3, bid, T.nblocks);
+  __shared__ int s_last;
+  __syncthreads();   // the three sum atomics of this workgroup have been issued ...
+  if (threadIdx.x == 0) {
+    __threadfence();   // ... and are performed before the ticket is drawn
+    const unsigned t = atomicAdd(reinterpret_cast<unsigned*>(scratch40 + 36), 1u);
+    s_last = (t == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x == 0) {
+    __threadfence();
+    float sums[36];
+    for (int k = 0; k < 36; ++k) sums[k] = __hip_atomic_load(scratch40 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    reg_combine(sums, S, out3);
+    for (int k = 0; k < 36; ++k) __hip_atomic_store(scratch40 + k, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned*>(scratch40 + 36), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // (the coefficient triple of the block's tensor from the upstream gradients g3 = dL/d{L1, TV_density, TV_color} is three
@@ -145,10 +190,6 @@ __global__ __launch_bounds__(256) void k_reg_batch_bwd(RegBatch B, const float* 
     if (T.W > 1) coef[2] = gt * 2e-2f / ((float)T.C * T.H * (T.W - 1));
   }
   factor_reg_bwd_body(T.x, T.H, T.W, T.C, coef, T.g, accumulate, blockIdx.x - T.block0, T.nblocks);
-}
-
-__global__ void k_reg_zero(float* __restrict__ p, int n) {
-  if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
 }
 
 }  // namespace jt
@@ -193,27 +234,6 @@ struct RegSet {
   RegTensor t[12];  // 0-2 density planes, 3-5 density lines, 6-8 app planes, 9-11 app lines
 };
 
-// out3 = {L1, TV_density, TV_color} with the reference's normalisations (tensoRF.py:212-228, tensorBase.py:21-38)
-__global__ void k_reg_combine(const float* __restrict__ sums, RegSet S, float* __restrict__ out3) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  float l1 = 0.f, tvd = 0.f, tva = 0.f;
-  for (int i = 0; i < 6; ++i) l1 += sums[i * 3] / ((float)S.t[i].H * S.t[i].W * S.t[i].C);
-  for (int i = 0; i < 3; ++i) {
-    const RegTensor& a = S.t[i];
-    const RegTensor& b = S.t[6 + i];
-    float ta = 0.f, tb = 0.f;
-    if (a.H > 1) ta += sums[i * 3 + 1] / ((float)a.C * (a.H - 1) * a.W);
-    if (a.W > 1) ta += sums[i * 3 + 2] / ((float)a.C * a.H * (a.W - 1));
-    if (b.H > 1) tb += sums[(6 + i) * 3 + 1] / ((float)b.C * (b.H - 1) * b.W);
-    if (b.W > 1) tb += sums[(6 + i) * 3 + 2] / ((float)b.C * b.H * (b.W - 1));
-    tvd += 2.f * ta * 1e-2f;
-    tva += 2.f * tb * 1e-2f;
-  }
-  out3[0] = l1;
-  out3[1] = tvd;
-  out3[2] = tva;
-}
-
 }  // namespace jt
 
 static int reg_set(const JtFactors* f, const JtFactors* g, const int32_t* hw, int Cd, int Ca, RegSet* S) {
@@ -239,8 +259,6 @@ extern "C" int jt_reg_losses_forward(const JtFactors* factors, const int32_t* pl
   if (rc) return rc;
   if (!scratch36 || !out3) return JT_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_reg_zero, dim3(1), dim3(64), 0, st, scratch36, 36);  // not a memset node: see jt_loss.hip
-  JT_LAUNCH_CHECK();
   RegBatch B;
   B.n = 0;
   int nblk = 0;
@@ -255,9 +273,9 @@ extern "C" int jt_reg_losses_forward(const JtFactors* factors, const int32_t* pl
     B.t[B.n++] = {t.x, nullptr, t.H, t.W, t.C, tv ? 1 : 0, i, nblk, blocks};
     nblk += blocks;
   }
-  hipLaunchKernelGGL(k_reg_batch_fwd, dim3(nblk), dim3(256), 0, st, B, scratch36);
-  JT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_reg_combine, dim3(1), dim3(64), 0, st, (const float*)scratch36, S, out3);
+  RegDims Dm;
+  for (int i = 0; i < 9; ++i) Dm.H[i] = S.t[i].H, Dm.W[i] = S.t[i].W, Dm.C[i] = S.t[i].C;
+  hipLaunchKernelGGL(k_reg_batch_fwd, dim3(nblk), dim3(256), 0, st, B, Dm, scratch36, out3);
   JT_LAUNCH_CHECK();
   return JT_OK;
 }

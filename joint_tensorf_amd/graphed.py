@@ -369,6 +369,7 @@ class GraphedTrainStep:
             tf.coin_override = coin
         ops.LOSS_WEIGHTS_STATIC = self._loss_weights(opt)
         ops.status_word(dev)  # the non-finite guard's word must exist BEFORE the capture (graph-pool memory is recycled)
+        ops._reg_scratch(dev)  # ... and so must the regularisers' self-resetting scratch
         # [lattice offset x, y | address of the supervising images (2 words) | address of the edge masks (2 words)]
         e.off = torch.zeros(6, device=dev, dtype=torch.int32)
         ops.poke_words(e.off, [0, 0] + self._supervision_words(var, sig[8]))
@@ -509,8 +510,7 @@ class GraphedTestOptim:
         last = None
         try:
             for it in range(opt.optim.test_iter):
-                g.nerf.test_time_progress_host = it / opt.optim.test_iter
-                g.nerf.test_time_progress.data.fill_(it / opt.optim.test_iter)
+                g.nerf.set_test_time_progress(it / opt.optim.test_iter)
                 graphable = (opt.nerf.ray_sampling_strategy == "all_view_rand_grid" and not opt.camera.ndc
                              and bool(opt.nerf.setbg_opaque) and not self.force_eager)
                 np_state = np.random.get_state() if graphable else None

@@ -67,10 +67,20 @@ class NeRF(torch.nn.Module):
         self.test_time_progress = torch.nn.Parameter(torch.tensor(0.0))
         self.progress_host = 0.0
         self.test_time_progress_host = 0.0
+        # the device copies are written when somebody reads the module's state (a fill launch per iteration otherwise)
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_progress())
 
     def set_progress(self, value):
         self.progress_host = float(value)
-        self.progress.data.fill_(float(value))
+
+    def set_test_time_progress(self, value):
+        self.test_time_progress_host = float(value)
+
+    def flush_progress(self):
+        """the host mirrors -> the checkpointed Parameters (model/bat.py:373-374)"""
+        with torch.no_grad():
+            self.progress.fill_(self.progress_host)
+            self.test_time_progress.fill_(self.test_time_progress_host)
 
     def reset(self, opt, bbox, n_voxel_list, n_voxels, alphamask_resolution, lr_basis, lr_index, TV_weight_color,
               TV_weight_density):
@@ -722,6 +732,7 @@ class Model(torch.nn.Module):
         state = (np.random.get_state(), torch.get_rng_state(), torch.cuda.get_rng_state(torch.device(opt.device)))
         total = None
         out = None
+        g._group_rays = []
         try:
             for k in range(groups):
                 self._reg_scale = 1.0 if k == 0 else 0.0   # (fused_loss_weights / summarize_loss: regularisers with shard 0 only)
@@ -735,6 +746,7 @@ class Model(torch.nn.Module):
                 loss = self.summarize_loss(opt, v, loss)
                 loss.all.backward(gradient=self._backward_seed(loss.all))
                 total = loss.all.detach() if total is None else total + loss.all.detach()
+                g._group_rays.append(int(v.rgb.shape[0] * v.rgb.shape[1]))
                 if out is None:
                     out = loss   # (the logged terms are shard 0's; the iteration's total is in `all`)
                 del v, loss
@@ -1006,8 +1018,7 @@ class Model(torch.nn.Module):
         eye = torch.eye(3, 4, device=opt.device)
         try:
             for it in range(opt.optim.test_iter):
-                g.nerf.test_time_progress_host = it / opt.optim.test_iter
-                g.nerf.test_time_progress.data.fill_(it / opt.optim.test_iter)
+                g.nerf.set_test_time_progress(it / opt.optim.test_iter)
                 optim_pose.zero_grad()
                 var.pose_refine_test = ops.train_pose(var.se3_refine_test, None, eye)  # se3_to_SE3 (camera.py:81-99)
                 var = g.forward(opt, var, mode="test-optim")
@@ -1074,8 +1085,7 @@ class Model(torch.nn.Module):
         pose_refine = None
         try:
             for it in range(T):
-                g.nerf.test_time_progress_host = it / T
-                g.nerf.test_time_progress.data.fill_(it / T)
+                g.nerf.set_test_time_progress(it / T)
                 optim_pose.zero_grad()
                 pose_refine = ops.train_pose(se3, None, eye)               # se3_to_SE3 of every view (camera.py:81-99)
                 bv.pose_refine_test = pose_refine

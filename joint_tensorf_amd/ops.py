@@ -176,6 +176,20 @@ def _aux_stream(dev):
     return _AUX[key]
 
 
+_REG_SCRATCH = {}
+
+
+def _reg_scratch(dev):
+    """jt_reg_losses_forward's 40 floats of device scratch: zero when the first call sees them, left zero by every call (the
+    kernel's last workgroup resets them) -- one persistent buffer per device instead of a zero fill per iteration"""
+    key = str(dev)
+    if key not in _REG_SCRATCH:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the regularisers' scratch must exist before a hipGraph capture")
+        _REG_SCRATCH[key] = torch.zeros(40, device=dev, dtype=torch.float32)
+    return _REG_SCRATCH[key]
+
+
 def _zeros_flat(groups, with_flat=False, unzeroed=()):
     """Zero tensors shaped like the tensors of `groups` (a list of lists), carved out of ONE flat buffer: one fill
     launch instead of one per tensor (19 per backward).  Offsets are rounded up to 16 bytes.  with_flat: also
@@ -471,7 +485,7 @@ class RenderRays(torch.autograd.Function):
                 H, W, _ = sdp[i].shape
                 hw += [H, W, sdl[i].shape[0]]
             Cd, Ca = sdp[0].shape[2], sap[0].shape[2]
-            scratch = torch.empty(36, **f32)
+            scratch = _reg_scratch(dev)
             reg3 = torch.empty(3, **f32)
             check(lib.jt_reg_losses_forward(fac, (ctypes.c_int32 * 9)(*hw), Cd, Ca, int(bool(flags[0])),
                                             int(bool(flags[1])), ptr(scratch), ptr(reg3), st), "jt_reg_losses_forward")
@@ -875,7 +889,7 @@ class RegLosses(torch.autograd.Function):
             hw += [H, W, st_[1][i].shape[0]]
         hw_arr = (ctypes.c_int32 * 9)(*hw)
         fac = _factors_struct(*st_)
-        scratch = torch.empty(36, device=dev, dtype=torch.float32)
+        scratch = _reg_scratch(dev)
         out = torch.empty(3, device=dev, dtype=torch.float32)
         Cd, Ca = st_[0][0].shape[2], st_[2][0].shape[2]
         check(lib.jt_reg_losses_forward(fac, hw_arr, Cd, Ca, int(bool(with_tv_density)), int(bool(with_tv_app)),
