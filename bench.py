@@ -379,7 +379,8 @@ def pmc_traffic_instep(roof, hidden=None):
     FETCH_SIZE / WRITE_SIZE runs of `bench.py --no-cpu-baseline --no-probe --no-torch-baseline --no-extras`,
     tools/profile_cmd.sh -> tools/pmc_traffic_instep.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), per shaded sample, scaled
     by the samples of the live launches; null when no in-step file is committed."""
-    path = os.path.join(ROOT, "profiles", "round3_default_pmc_traffic.json")
+    tag = "round4" if os.path.exists(os.path.join(ROOT, "profiles", "round4_default_pmc_traffic.json")) else "round3"
+    path = os.path.join(ROOT, "profiles", tag + "_default_pmc_traffic.json")
     try:
         rec = json.load(open(path))
         k = rec["k_shade_bwd"]
@@ -387,12 +388,12 @@ def pmc_traffic_instep(roof, hidden=None):
         if abs(n - rec["process_samples_per_launch"]) > 0.1 * n:
             return {"traffic": None}  # another workload than the one the counters were collected on
         out = {"traffic": k["hbm_bytes_per_sample"] * n, "traffic_unit": "bytes/launch",
-               "traffic_source": "profiles/round3_default_pmc_traffic.json", "traffic_detail": rec}
+               "traffic_source": "profiles/%s_default_pmc_traffic.json" % tag, "traffic_detail": rec}
         try:
             # matrix-pipe / vector-instruction / texture-path busy fractions of the big kernels and the launches of a step,
-            # from the committed SQ / TA counter passes and kernel trace of this same command (profiles/round3_sq_counters.txt)
-            busy = json.load(open(os.path.join(ROOT, "profiles", "round3_default_pipe_busy.json")))
-            out["pipe_busy"] = dict(busy["kernels"], source="profiles/round3_default_pipe_busy.json")
+            # from the committed SQ / TA counter passes and kernel trace of this same command (tools/pipe_busy.py)
+            busy = json.load(open(os.path.join(ROOT, "profiles", tag + "_default_pipe_busy.json")))
+            out["pipe_busy"] = dict(busy["kernels"], source="profiles/%s_default_pipe_busy.json" % tag)
             out["launches_per_step_profiled"] = busy["launches_per_step_profiled"]
         except Exception:
             pass

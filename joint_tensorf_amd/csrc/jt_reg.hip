@@ -155,21 +155,23 @@ __global__ __launch_bounds__(256) void k_reg_batch_fwd(RegBatch B, RegDims S, fl
     factor_reg_fwd_body<true>(T.x, T.H, T.W, T.C, scratch40 + T.slot * 3, bid, T.nblocks);
   else
     factor_reg_fwd_body<false>(T.x, T.H, T.W, T.C, scratch40 + T.slot * 3, bid, T.nblocks);
+  // (no __threadfence(): a release fence writes the XCD's L2 back, ~2-6 us per workgroup, 4 600 of them -- measured +115 us on
+  //  the LLFF grid.  The sums and the ticket are float / integer atomics, which execute at the memory side and never sit in an
+  //  L2: waiting for this workgroup's own atomics to be acknowledged is all the ordering the ticket needs.)
   __shared__ int s_last;
-  __syncthreads();   // the three sum atomics of this workgroup have been issued ...
+  __shared__ float s_sums[36];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence();   // ... and are performed before the ticket is drawn
     const unsigned t = atomicAdd(reinterpret_cast<unsigned*>(scratch40 + 36), 1u);
     s_last = (t == gridDim.x - 1);
   }
   __syncthreads();
-  if (s_last && threadIdx.x == 0) {
-    __threadfence();
-    float sums[36];
-    for (int k = 0; k < 36; ++k) sums[k] = __hip_atomic_load(scratch40 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    reg_combine(sums, S, out3);
-    for (int k = 0; k < 36; ++k) __hip_atomic_store(scratch40 + k, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(reinterpret_cast<unsigned*>(scratch40 + 36), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (s_last) {   // (uniform over the workgroup) read AND reset in one returning atomic per word
+    if (threadIdx.x < 36) s_sums[threadIdx.x] = atomicExch(scratch40 + threadIdx.x, 0.f);
+    if (threadIdx.x == 36) atomicExch(reinterpret_cast<unsigned*>(scratch40 + 36), 0u);
+    __syncthreads();
+    if (threadIdx.x == 0) reg_combine(s_sums, S, out3);
   }
 }
 

@@ -285,7 +285,12 @@ class GraphedTrainStep:
         w = g.se3_refine.weight
         accum = int(opt.optim.pose_grad_accum_iter) if has_key(opt.optim, "pose_grad_accum_iter") else 1
         if accum <= 1:
-            w.grad = e.pose_grad
+            if w.grad is not None:
+                # a partial sum left by the accumulation period that just ended on an iteration that is not a multiple of it
+                # (compress_schedule can produce such a switch): the eager path adds into it, so does this one
+                w.grad.add_(e.pose_grad)
+            else:
+                w.grad = e.pose_grad
             m.optim_pose.step()
             w.grad = None
         else:

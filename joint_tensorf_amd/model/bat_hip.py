@@ -374,6 +374,15 @@ class Graph(torch.nn.Module):
         if not (pose.is_cuda and torch.is_grad_enabled() and torch.is_tensor(var.get("image"))
                 and not any(p.requires_grad for p in tf.parameters())):
             return None
+        if getattr(tf, "_pose_fused_ok", None) is None:
+            # the single-launch kernel exists for the two BAT shading configurations only (jt_pose_fused_workspace_bytes
+            # returns 0 otherwise): any other scene takes the staged path instead of raising; asked once per
+            # scene object, BEFORE any host draw is consumed
+            from .._lib import lib
+            tf._pose_fused_ok = lib.jt_pose_fused_workspace_bytes(
+                tf._render_cfg(self.nerf.n_samples, bool(opt.camera.ndc), bool(opt.nerf.setbg_opaque)).scene()) > 0
+        if not tf._pose_fused_ok:
+            return None
         # the host draws of render_rays happen whichever path runs (same random streams)
         pd, pc, c2f_mode, ksize = self.resolve_blur(opt, "test-optim")
         if c2f_mode is not None:

@@ -1,5 +1,5 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out; mkdir -p $O
 cd $R
 for rep in 1 2; do

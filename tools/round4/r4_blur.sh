@@ -1,6 +1,6 @@
 #!/bin/bash
 # blurred stages: step time and kernel trace for library variants
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 VARS=${VARS:-"default blurp16 blurp32"}

@@ -1,5 +1,5 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out; mkdir -p $O
 cd $R
 timeout 2400 python3 -m pytest tests/ -x -q -m gpu > $O/r4_fulltests.log 2>&1; echo "gpu suite rc=$? $(tail -1 $O/r4_fulltests.log)"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # LLFF final grid: step time + kernel trace, auxiliary stream on / off
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out; mkdir -p $O
 TAG=${1:-r4_llff}; shift
 cd /tmp && export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 #!/bin/bash
 # ordered kernel / memcpy list of the last timed iterations of the default step
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 JT_NO_AUX=1 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/r4_order -o k -- python3 $R/bench.py --no-cpu-baseline --no-probe --no-torch-baseline --no-extras --steps 3 --warmup 2 $* > $O/r4_order.log 2>&1

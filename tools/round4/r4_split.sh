@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4: the split appearance backward (JT_BWD_SPLIT = run length) against the fused kernel: parity, step time, kernel trace
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out; mkdir -p $O
 cd $R
 export JT_TIME_WALK=1

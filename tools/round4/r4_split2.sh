@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4: what bounds k_shade_scatter -- occupancy variants, no-atomics variant, WRITE_SIZE (atomic segments) per run length
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 export JT_NO_AUX=1
