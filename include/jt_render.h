@@ -119,6 +119,16 @@ int jt_raygen_forward(const float* pose, const float* intr_inv, const float* int
 int jt_raygen_backward(const float* pose, const float* intr_inv, const float* intr, const int64_t* ray_idx,
                        int n_views, int rays_per_view, int image_w, int ndc, float ndc_near,
                        const float* g_rays_o, const float* g_rays_d, float* g_pose, void* stream);
+/* The same for a RAGGED batch of views (batched test-time pose optimisation of model/bat.py:265-292: every held-out view on its own
+ * pixel lattice): ray_idx [n_rays] is the concatenation of the views' pixel lists, view b owns rays view_offset[b] ..
+ * view_offset[b + 1] - 1 (view_offset [n_views + 1], int32, device memory).  Per ray / per view the arithmetic and the order of
+ * the sums are those of a single-view call: a view's rays and pose gradient do not depend on what else is in the batch. */
+int jt_raygen_forward_ragged(const float* pose, const float* intr_inv, const float* intr, const int64_t* ray_idx,
+                             const int32_t* view_offset, int n_views, int n_rays, int image_w, int ndc, float ndc_near,
+                             float* rays_o, float* rays_d, void* stream);
+int jt_raygen_backward_ragged(const float* pose, const float* intr_inv, const float* intr, const int64_t* ray_idx,
+                              const int32_t* view_offset, int n_views, int n_rays, int image_w, int ndc, float ndc_near,
+                              const float* g_rays_o, const float* g_rays_d, float* g_pose, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Learnable pose: pose = exp(se3) o noise o gt.
@@ -341,6 +351,14 @@ int jt_render_loss_forward(const float* rgb, const float* image, const int64_t* 
 int jt_render_loss_backward(const float* rgb, const float* image, const int64_t* ray_idx, const uint8_t* edge_mask,
                             int n_views, int rays_per_view, int n_pixels, float edge_factor, float non_edge_factor,
                             const float* acc4, const float* g_loss, float* g_rgb, void* stream);
+/* One photometric nanmean PER VIEW over a ragged batch (layout as jt_raygen_forward_ragged; image [n_views][3][n_pixels], no edge
+ * mask): loss [n_views], acc2 [n_views][2] = (sum of squares, count) kept for the backward, g_rgb[i] = g_loss[view of i] * 2 (rgb -
+ * gt) / count -- the single-view jt_render_loss_forward / backward bit for bit. */
+int jt_render_loss_views_forward(const float* rgb, const float* image, const int64_t* ray_idx, const int32_t* view_offset,
+                                 int n_views, int n_pixels, float* acc2, float* loss, void* stream);
+int jt_render_loss_views_backward(const float* rgb, const float* image, const int64_t* ray_idx, const int32_t* view_offset,
+                                  int n_views, int n_rays, int n_pixels, const float* acc2, const float* g_loss, float* g_rgb,
+                                  void* stream);
 /* The same with the supervising buffers named by DEVICE memory: slots[0] = address of the image buffer, slots[1] = address
  * of the edge-mask buffer (read only when with_edge_mask != 0).  The reference picks one of five blur scales of the
  * ground-truth images per iteration (model/nerf.py:209-227); a captured hipGraph stays the same for all of them when the

@@ -78,6 +78,10 @@ SIGNATURES = {
     "jt_version": (ctypes.c_int, []),
     "jt_raygen_forward": (I, [P, P, P, P, I, I, I, I, F, P, P, P]),
     "jt_raygen_backward": (I, [P, P, P, P, I, I, I, I, F, P, P, P, P]),
+    "jt_raygen_forward_ragged": (I, [P, P, P, P, P, I, I, I, I, F, P, P, P]),
+    "jt_raygen_backward_ragged": (I, [P, P, P, P, P, I, I, I, I, F, P, P, P, P]),
+    "jt_render_loss_views_forward": (I, [P, P, P, P, I, I, P, P, P]),
+    "jt_render_loss_views_backward": (I, [P, P, P, P, I, I, I, P, P, P, P]),
     "jt_pose_forward": (I, [P, P, P, I, I, P, P]),
     "jt_pose_backward": (I, [P, P, P, I, I, P, P, P]),
     "jt_blur_forward": (I, [P, P, P, I, I, I, P, I, P]),

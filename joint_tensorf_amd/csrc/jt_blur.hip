@@ -211,6 +211,9 @@ __global__ __launch_bounds__(kLineThreads) void k_blur_line(LineBatch B, int npa
   auto element = [&](const Desc& d, int idx) {
     const int q = idx % kLineQ, pos = idx / kLineQ - d.r;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#if JT_BLUR_ABL & 2   // profiling knob: no global loads (what the fetch of the chunks costs)
+    return make_float4((float)idx, 1.f, 2.f, 3.f);
+#endif
     if (q < d.nquad && (!ADJ || (pos >= 0 && pos < d.n)))
       v = ld4(d.src + (long)min(max(pos, 0), d.n - 1) * d.pos_stride + q * 4);
     return v;
@@ -257,8 +260,13 @@ __global__ __launch_bounds__(kLineThreads) void k_blur_line(LineBatch B, int npa
       float4 acc[kLineP];
 #pragma unroll
       for (int j = 0; j < kLineP; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#if JT_BLUR_ABL & 1   // profiling knob: one input per item instead of kLineP + ntaps - 1 (what the arithmetic costs)
+      const int nq_run = 1;
+#else
+      const int nq_run = nq;
+#endif
 #pragma unroll 4
-      for (int qi = 0; qi < nq; ++qi) {
+      for (int qi = 0; qi < nq_run; ++qi) {
         const float4 v = row[qi];
         const float4 w0 = *reinterpret_cast<const float4*>(s_wt + qi * kLineP);
         const float4 w1 = *reinterpret_cast<const float4*>(s_wt + qi * kLineP + 4);

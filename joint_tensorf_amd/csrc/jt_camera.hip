@@ -221,14 +221,35 @@ __device__ inline PixRay pixel_ray(const float* P, const float* Ki, long idx, in
   return r;
 }
 
+// view of ray t in a RAGGED batch (view b owns rays view_offset[b] .. view_offset[b + 1] - 1): the last b with offset <= t
+__device__ inline int ragged_view(const int* __restrict__ voff, int V, int t) {
+  int lo = 0, hi = V - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (voff[mid] <= t) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// RAGGED = false: B views x the SAME r pixels (ray_idx [r]).  RAGGED = true: every view its own pixel list, concatenated
+// (ray_idx [n_total], view_offset [B + 1]; `r` is n_total) -- per ray the same arithmetic, so a view's rays are bit-identical
+// whether it is rendered alone or in a batch of views (batched test-time pose optimisation).
+template <bool RAGGED>
 __global__ __launch_bounds__(256) void k_raygen_fwd(const float* __restrict__ pose, const float* __restrict__ intr_inv,
                                                     const float* __restrict__ intr,
-                                                    const int64_t* __restrict__ ray_idx, int B, int r, int W,
-                                                    int ndc, float near, float* __restrict__ rays_o,
+                                                    const int64_t* __restrict__ ray_idx, const int* __restrict__ voff, int B,
+                                                    int r, int W, int ndc, float near, float* __restrict__ rays_o,
                                                     float* __restrict__ rays_d) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= B * r) return;
-  int b = t / r, k = t - b * r;
+  if (t >= (RAGGED ? r : B * r)) return;
+  int b, k;
+  if (RAGGED) {
+    b = ragged_view(voff, B, t);
+    k = t;
+  } else {
+    b = t / r;
+    k = t - b * r;
+  }
   PixRay pr = pixel_ray(pose + b * 12, intr_inv + b * 9, ray_idx[k], W);
   float o[3] = {pr.c0[0], pr.c0[1], pr.c0[2]}, d[3] = {pr.d[0], pr.d[1], pr.d[2]};
   if (ndc) {
@@ -251,20 +272,23 @@ __global__ __launch_bounds__(256) void k_raygen_fwd(const float* __restrict__ po
 }
 
 // one workgroup per view: deterministic reduction of the 12 pose-gradient entries over the view's rays
+template <bool RAGGED>
 __global__ __launch_bounds__(256) void k_raygen_bwd(const float* __restrict__ pose, const float* __restrict__ intr_inv,
                                                     const float* __restrict__ intr,
-                                                    const int64_t* __restrict__ ray_idx, int B, int r, int W,
-                                                    int ndc, float near, const float* __restrict__ g_o,
+                                                    const int64_t* __restrict__ ray_idx, const int* __restrict__ voff, int B,
+                                                    int r_all, int W, int ndc, float near, const float* __restrict__ g_o,
                                                     const float* __restrict__ g_d, float* __restrict__ g_pose) {
   __shared__ float red[4][12];
   const int b = blockIdx.x;
   const float* P = pose + b * 12;
+  // (ragged: the view's own rays in the same thread order as a single-view launch: the same sums bit for bit)
+  const int base = RAGGED ? voff[b] : 0, r = RAGGED ? voff[b + 1] - voff[b] : r_all;
   float acc[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) acc[i] = 0.f;
   for (int k = threadIdx.x; k < r; k += blockDim.x) {
-    PixRay pr = pixel_ray(P, intr_inv + b * 9, ray_idx[k], W);
-    size_t t = (size_t)b * r + k;
+    PixRay pr = pixel_ray(P, intr_inv + b * 9, ray_idx[base + k], W);
+    size_t t = RAGGED ? (size_t)base + k : (size_t)b * r + k;
     float go[3] = {g_o[t * 3], g_o[t * 3 + 1], g_o[t * 3 + 2]};
     float gd[3] = {g_d[t * 3], g_d[t * 3 + 1], g_d[t * 3 + 2]};
     if (ndc) {
@@ -344,8 +368,34 @@ extern "C" int jt_raygen_forward(const float* pose, const float* intr_inv, const
     return JT_ERR_ARG;
   if (ndc && !intr) return JT_ERR_ARG;
   int n = n_views * rays_per_view;
-  hipLaunchKernelGGL(k_raygen_fwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pose, intr_inv, intr,
-                     ray_idx, n_views, rays_per_view, image_w, ndc, ndc_near, rays_o, rays_d);
+  hipLaunchKernelGGL(k_raygen_fwd<false>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pose, intr_inv, intr,
+                     ray_idx, (const int*)nullptr, n_views, rays_per_view, image_w, ndc, ndc_near, rays_o, rays_d);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
+extern "C" int jt_raygen_forward_ragged(const float* pose, const float* intr_inv, const float* intr, const int64_t* ray_idx,
+                                        const int32_t* view_offset, int n_views, int n_rays, int image_w, int ndc,
+                                        float ndc_near, float* rays_o, float* rays_d, void* stream) {
+  if (!pose || !intr_inv || !ray_idx || !view_offset || !rays_o || !rays_d || n_views < 1 || n_rays < 1 || image_w < 1)
+    return JT_ERR_ARG;
+  if (ndc && !intr) return JT_ERR_ARG;
+  hipLaunchKernelGGL(k_raygen_fwd<true>, dim3((n_rays + 255) / 256), dim3(256), 0, (hipStream_t)stream, pose, intr_inv, intr,
+                     ray_idx, view_offset, n_views, n_rays, image_w, ndc, ndc_near, rays_o, rays_d);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
+extern "C" int jt_raygen_backward_ragged(const float* pose, const float* intr_inv, const float* intr, const int64_t* ray_idx,
+                                         const int32_t* view_offset, int n_views, int n_rays, int image_w, int ndc,
+                                         float ndc_near, const float* g_rays_o, const float* g_rays_d, float* g_pose,
+                                         void* stream) {
+  if (!pose || !intr_inv || !ray_idx || !view_offset || !g_rays_o || !g_rays_d || !g_pose || n_views < 1 || n_rays < 1 ||
+      image_w < 1)
+    return JT_ERR_ARG;
+  if (ndc && !intr) return JT_ERR_ARG;
+  hipLaunchKernelGGL(k_raygen_bwd<true>, dim3(n_views), dim3(256), 0, (hipStream_t)stream, pose, intr_inv, intr, ray_idx,
+                     view_offset, n_views, n_rays, image_w, ndc, ndc_near, g_rays_o, g_rays_d, g_pose);
   JT_LAUNCH_CHECK();
   return JT_OK;
 }
@@ -358,8 +408,8 @@ extern "C" int jt_raygen_backward(const float* pose, const float* intr_inv, cons
       image_w < 1)
     return JT_ERR_ARG;
   if (ndc && !intr) return JT_ERR_ARG;
-  hipLaunchKernelGGL(k_raygen_bwd, dim3(n_views), dim3(256), 0, (hipStream_t)stream, pose, intr_inv, intr, ray_idx,
-                     n_views, rays_per_view, image_w, ndc, ndc_near, g_rays_o, g_rays_d, g_pose);
+  hipLaunchKernelGGL(k_raygen_bwd<false>, dim3(n_views), dim3(256), 0, (hipStream_t)stream, pose, intr_inv, intr, ray_idx,
+                     (const int*)nullptr, n_views, rays_per_view, image_w, ndc, ndc_near, g_rays_o, g_rays_d, g_pose);
   JT_LAUNCH_CHECK();
   return JT_OK;
 }

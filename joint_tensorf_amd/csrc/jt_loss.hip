@@ -152,6 +152,66 @@ __global__ __launch_bounds__(256) void k_render_loss_bwd(const float* __restrict
   }
 }
 
+// ---- one photometric mean PER VIEW over a ragged batch (batched test-time pose optimisation, model/bat.py:265-292) -------------
+// view b owns rays voff[b] .. voff[b + 1] - 1 of rgb [n][3] / ray_idx [n]; image [V][3][HW].  One workgroup per view, with the
+// summation structure of k_render_loss_fwd_one for a single view: loss[b] and the backward's per-element gradient are the
+// single-view launch's bit for bit.
+__global__ __launch_bounds__(1024) void k_render_loss_views_fwd(const float* __restrict__ rgb, const float* __restrict__ image,
+                                                                const int64_t* __restrict__ ray_idx,
+                                                                const int* __restrict__ voff, int HW,
+                                                                float* __restrict__ acc2, float* __restrict__ loss) {
+  __shared__ float red[16][2];
+  const int b = blockIdx.x, base = voff[b], r = voff[b + 1] - voff[b];
+  const long n = (long)r * 3;
+  float s0 = 0.f, c0 = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const int ch = (int)(i % 3);
+    const long k = i / 3;
+    const long pix = ray_idx[base + k];
+    const float d = rgb[(long)base * 3 + i] - image[((long)b * 3 + ch) * HW + pix];
+    const float e = 1.f * d;
+    if (e == e) {
+      s0 += e * e;
+      c0 += 1.f;
+    }
+  }
+  s0 = wave_sum(s0);
+  c0 = wave_sum(c0);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) red[wv][0] = s0, red[wv][1] = c0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a0 = 0.f, a1 = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) a0 += red[w][0], a1 += red[w][1];
+    acc2[b * 2] = a0, acc2[b * 2 + 1] = a1;
+    loss[b] = a0 / a1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_render_loss_views_bwd(const float* __restrict__ rgb, const float* __restrict__ image,
+                                                               const int64_t* __restrict__ ray_idx,
+                                                               const int* __restrict__ voff, int V, int n_rays, int HW,
+                                                               const float* __restrict__ acc2, const float* __restrict__ g,
+                                                               float* __restrict__ g_rgb) {
+  const long n = (long)n_rays * 3;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % 3);
+    const int t = (int)(i / 3);
+    int lo = 0, hi = V - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (voff[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    const int b = lo;
+    const float ke = 1.f * 2.f / acc2[b * 2 + 1];
+    const float d = rgb[i] - image[((long)b * 3 + ch) * HW + ray_idx[t]];
+    const float e = 1.f * d;
+    float v = 0.f;
+    if (e == e) v += ke * 1.f * e;
+    g_rgb[i] = g[b] * v;
+  }
+}
+
 // total = w_render * render + w_reg . reg3  and its backward: the weighted sum of model/tensorf.py:31-47 as one launch
 // each way (as stock ops: a multiply and an add per term, a select-backward fill + copy per regulariser, ...).
 __global__ void k_loss_sum_fwd(const float* __restrict__ render, const float* __restrict__ reg3, float wr, float w0,
@@ -290,6 +350,28 @@ static int render_loss_backward(const float* rgb, const float* image, const int6
   hipLaunchKernelGGL(k_render_loss_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rgb, image, ray_idx,
                      edge_mask, n_views, rays_per_view, n_pixels, acc4, edge_factor, non_edge_factor, g_loss, g_rgb,
                      (const unsigned long long*)slots);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
+extern "C" int jt_render_loss_views_forward(const float* rgb, const float* image, const int64_t* ray_idx,
+                                            const int32_t* view_offset, int n_views, int n_pixels, float* acc2, float* loss,
+                                            void* stream) {
+  if (!rgb || !image || !ray_idx || !view_offset || !acc2 || !loss || n_views < 1 || n_pixels < 1) return JT_ERR_ARG;
+  hipLaunchKernelGGL(k_render_loss_views_fwd, dim3(n_views), dim3(1024), 0, (hipStream_t)stream, rgb, image, ray_idx,
+                     view_offset, n_pixels, acc2, loss);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
+extern "C" int jt_render_loss_views_backward(const float* rgb, const float* image, const int64_t* ray_idx,
+                                             const int32_t* view_offset, int n_views, int n_rays, int n_pixels,
+                                             const float* acc2, const float* g_loss, float* g_rgb, void* stream) {
+  if (!rgb || !image || !ray_idx || !view_offset || !acc2 || !g_loss || !g_rgb || n_views < 1 || n_rays < 1 || n_pixels < 1)
+    return JT_ERR_ARG;
+  const long n = (long)n_rays * 3;
+  hipLaunchKernelGGL(k_render_loss_views_bwd, dim3((int)min((n + 255) / 256, 512L)), dim3(256), 0, (hipStream_t)stream, rgb,
+                     image, ray_idx, view_offset, n_views, n_rays, n_pixels, acc2, g_loss, g_rgb);
   JT_LAUNCH_CHECK();
   return JT_OK;
 }

@@ -1088,9 +1088,10 @@ class Model(torch.nn.Module):
         bv = Opt(idx=torch.arange(V, device=dev), pose=torch.cat([v["pose"].to(dev) for v in views], 0))
         intr = torch.cat([v["intr"].to(dev) for v in views], 0)
         intr_inv = torch.cat([v["intr_inv"].to(dev) for v in views], 0)
-        images = [v["image"].to(dev) for v in views]
+        images = torch.cat([v["image"].to(dev) for v in views], 0)      # [V, 3, H, W]
         ndc_near = float(opt.arch.ndc_near_plane) if _has(opt.arch, "ndc_near_plane") else 1.0
         w_render = float(opt.loss_weight.render)
+        voff = torch.zeros(V + 1, device=dev, dtype=torch.int32)        # rewritten every iteration (launch arguments: no copy)
         pose_refine = None
         try:
             for it in range(T):
@@ -1099,27 +1100,23 @@ class Model(torch.nn.Module):
                 pose_refine = ops.train_pose(se3, None, eye)               # se3_to_SE3 of every view (camera.py:81-99)
                 bv.pose_refine_test = pose_refine
                 pose = g.get_pose(opt, bv, mode="test-optim")              # [V, 3, 4]
-                centers, rays, idxs = [], [], []
+                idxs, offs = [], [0]
                 for v in range(V):
                     ox, oy = draws[v][it]
                     nx, ny = len(range(ox, opt.W, step)), len(range(oy, opt.H, step))
-                    ridx = g._lattice_at(opt, step, ny, nx, ox, oy)
-                    c, d = ops.ray_gen(pose[v:v + 1], intr_inv[v:v + 1], intr[v:v + 1], ridx, opt.W, ndc=bool(opt.camera.ndc),
-                                       ndc_near=ndc_near)
-                    centers.append(c.reshape(-1, 3))
-                    rays.append(d.reshape(-1, 3))
-                    idxs.append(ridx)
-                center, ray = torch.cat(centers, 0), torch.cat(rays, 0)
+                    idxs.append(g._lattice_at(opt, step, ny, nx, ox, oy))
+                    offs.append(offs[-1] + nx * ny)
+                ridx = torch.cat(idxs, 0)
+                for lo in range(0, V + 1, 256):
+                    ops.poke_words(voff, offs[lo:lo + 256], offset=lo)
+                # every view's rays on its own lattice in ONE launch each way (jt_raygen_*_ragged), one render of all of them,
+                # one photometric mean per view (jt_render_loss_views_*): per ray / per view the single-view arithmetic
+                center, ray = ops.ray_gen_ragged(pose, intr_inv, intr, ridx, voff, opt.W, ndc=bool(opt.camera.ndc),
+                                                 ndc_near=ndc_near)
                 g._blur_memo = (None, None, None, None)                    # (this call's blur draw was taken above)
                 ret = g.render_rays(opt, center[None], ray[None], mode="test-optim", n_views=1, n_pixels_per_view=center.shape[0])
-                rgb = ret.rgb.view(-1, 3)
-                total, o = None, 0
-                for v in range(V):
-                    r = idxs[v].numel()
-                    term = ops.render_loss(rgb[o:o + r].view(1, r, 3), images[v], idxs[v])   # the view's OWN mean
-                    total = term if total is None else total + term
-                    o += r
-                (w_render * total).backward()
+                per_view = ops.render_loss_views(ret.rgb.view(-1, 3), images, ridx, voff)
+                (w_render * per_view.sum()).backward()
                 optim_pose.step()
                 sched_pose.step()
         finally:

@@ -1111,6 +1111,76 @@ def ray_gen(pose, intr_inv, intr, ray_idx, image_w, ndc=False, ndc_near=1.0):
     return RayGen.apply(pose, intr_inv, intr, ray_idx, image_w, ndc, ndc_near)
 
 
+class RayGenRagged(torch.autograd.Function):
+    """rays of V views, every view on ITS OWN pixel list (camera.py:231-261 + 303-340; jt_raygen_*_ragged): ray_idx [n] is the
+    concatenation of the views' lists, view_offset [V + 1] int32.  Returns (o [n, 3], d [n, 3])."""
+
+    @staticmethod
+    def forward(ctx, pose, intr_inv, intr, ray_idx, view_offset, image_w, ndc, ndc_near):
+        pose_c = pose.detach().contiguous().float()
+        V = pose_c.shape[0]
+        ki = intr_inv.detach().contiguous().float()
+        k = None if intr is None else intr.detach().contiguous().float()
+        idx = ray_idx.detach().contiguous().to(torch.int64)
+        voff = view_offset.detach().contiguous().to(torch.int32)
+        n = idx.numel()
+        o = torch.empty(n, 3, device=pose_c.device, dtype=torch.float32)
+        d = torch.empty_like(o)
+        check(lib.jt_raygen_forward_ragged(ptr(pose_c), ptr(ki), ptr(k), ptr(idx), ptr(voff), V, n, int(image_w),
+                                           int(bool(ndc)), float(ndc_near), ptr(o), ptr(d), _stream()),
+              "jt_raygen_forward_ragged")
+        ctx.saved = (pose_c, ki, k, idx, voff, int(image_w), int(bool(ndc)), float(ndc_near))
+        return o, d
+
+    @staticmethod
+    def backward(ctx, g_o, g_d):
+        pose_c, ki, k, idx, voff, W, ndc, near = ctx.saved
+        V, n = pose_c.shape[0], idx.numel()
+        g_o = g_o.contiguous().float()
+        g_d = g_d.contiguous().float()
+        g_pose = torch.empty(V, 3, 4, device=pose_c.device, dtype=torch.float32)
+        check(lib.jt_raygen_backward_ragged(ptr(pose_c), ptr(ki), ptr(k), ptr(idx), ptr(voff), V, n, W, ndc, near, ptr(g_o),
+                                            ptr(g_d), ptr(g_pose), _stream()), "jt_raygen_backward_ragged")
+        return g_pose, None, None, None, None, None, None, None
+
+
+def ray_gen_ragged(pose, intr_inv, intr, ray_idx, view_offset, image_w, ndc=False, ndc_near=1.0):
+    return RayGenRagged.apply(pose, intr_inv, intr, ray_idx, view_offset, image_w, ndc, ndc_near)
+
+
+class RenderLossViews(torch.autograd.Function):
+    """one photometric nanmean PER VIEW over a ragged batch: rgb [n, 3], image [V, 3, H, W], ray_idx [n], view_offset [V + 1]
+    -> loss [V] (jt_render_loss_views_*: the single-view RenderLoss bit for bit, view by view)."""
+
+    @staticmethod
+    def forward(ctx, rgb, image, ray_idx, view_offset):
+        rgb_c = rgb.detach().contiguous().float()
+        V = image.shape[0]
+        img = image.detach().contiguous().float().view(V, 3, -1)
+        idx = ray_idx.detach().contiguous().to(torch.int64)
+        voff = view_offset.detach().contiguous().to(torch.int32)
+        acc = torch.empty(V, 2, device=rgb_c.device, dtype=torch.float32)
+        loss = torch.empty(V, device=rgb_c.device, dtype=torch.float32)
+        check(lib.jt_render_loss_views_forward(ptr(rgb_c), ptr(img), ptr(idx), ptr(voff), V, img.shape[2], ptr(acc), ptr(loss),
+                                               _stream()), "jt_render_loss_views_forward")
+        ctx.saved = (rgb_c, img, idx, voff, acc)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        rgb_c, img, idx, voff, acc = ctx.saved
+        gc = g.contiguous().float()
+        g_rgb = torch.empty_like(rgb_c)
+        check(lib.jt_render_loss_views_backward(ptr(rgb_c), ptr(img), ptr(idx), ptr(voff), img.shape[0], rgb_c.shape[0],
+                                                img.shape[2], ptr(acc), ptr(gc), ptr(g_rgb), _stream()),
+              "jt_render_loss_views_backward")
+        return g_rgb, None, None, None
+
+
+def render_loss_views(rgb, image, ray_idx, view_offset):
+    return RenderLossViews.apply(rgb, image, ray_idx, view_offset)
+
+
 def dense_alpha(cfg, density_plane, density_line, xyz, length):
     """alpha [n] = 1 - exp(-sigma(xyz) * length) at world points xyz [n,3] (BatBase.compute_alpha, batBase.py:27-41;
     points the scene's alpha mask drops get 0)."""
