@@ -80,6 +80,10 @@ typedef struct JtScene {
   int32_t mask_dims[3]; /* the volume's gridSize (x, y, z); the tensor is [z][y][x]                      */
   float mask_lo[3];     /* its own box: aabb[0]                                                         */
   float mask_inv[3];    /* 1.0 / (aabb[1] - aabb[0]) * 2, rounded like AlphaGridMask.invgridSize        */
+  /* optional (NULL = use near_plane): one float in DEVICE memory holding near_far[0] for the depth map's
+   * "- near_far[0] + 0.05" (batBase.py:147-150).  A launch captured into a hipGraph keeps reading the current
+   * value while tensorf_near_plane_schedule (model/tensorf.py:230-232) moves the near plane between replays. */
+  const float* near_plane_dev;
 } JtScene;
 
 /* the 12 VM factor tensors (or their gradients) */

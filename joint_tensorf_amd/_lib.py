@@ -36,6 +36,7 @@ class JtScene(ctypes.Structure):
         ("app_dim", c_i), ("mlp_kind", c_i), ("mlp_hidden", c_i), ("view_pe", c_i), ("fea_pe", c_i),
         ("view_pe_progress", c_f), ("fea_pe_progress", c_f),
         ("mask_dims", c_i * 3), ("mask_lo", c_f * 3), ("mask_inv", c_f * 3),
+        ("near_plane_dev", ctypes.c_void_p),
     ]
 
 

@@ -20,6 +20,7 @@ struct Dev {
   int ph[3], pw[3], ll[3];
   int Cd, Ca;
   float step, near_, far_, dist_scale, shift, thres;
+  const float* near_dev;  // JtScene.near_plane_dev (depth term only)
   int act, S, ndc, white_bg;
   const float* dP[3];
   const float* dL[3];
@@ -49,6 +50,7 @@ inline int make_dev(const JtScene* s, const JtFactors* f, Dev* d) {
   d->Ca = s->n_comp_app;
   d->step = s->step_size;
   d->near_ = s->near_plane;
+  d->near_dev = s->near_plane_dev;
   d->far_ = s->far_plane;
   d->dist_scale = s->distance_scale;
   d->shift = s->density_shift;

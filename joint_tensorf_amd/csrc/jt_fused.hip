@@ -475,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void k_pose_fused(Dev D, MlpDev M, PeMask p
       if (lane == 0) {
         tabs->acc[wv] = acc;
         A.opacity[ray] = acc;
-        A.depth[ray] = dep + (1.f - acc) * r.d[2] - D.near_ + 0.05f;   // batBase.py:147-150
+        A.depth[ray] = dep + (1.f - acc) * r.d[2] - (D.near_dev ? *D.near_dev : D.near_) + 0.05f;   // batBase.py:147-150
       }
     }
     if (lane == 0) {

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_march_fwd(Dev D, const float* __restric
     count[ray] = cnt;
     opacity[ray] = acc;
     // depth = sum w z + (1-acc) * ray_dir_z - near + 0.05        (batBase.py:147-150)
-    depth[ray] = dep + (1.f - acc) * r.d[2] - D.near_ + 0.05f;
+    depth[ray] = dep + (1.f - acc) * r.d[2] - (D.near_dev ? *D.near_dev : D.near_) + 0.05f;
   }
 }
 

@@ -297,8 +297,10 @@ class RenderCfg:
     def __init__(self, aabb, plane_hw, line_len, n_comp_density, n_comp_app, step_size, near_far,
                  distance_scale, density_shift, density_act, weight_thres, n_samples, ndc, white_bg,
                  app_dim, mlp_kind, mlp_hidden, view_pe, fea_pe, view_pe_progress=1.0, fea_pe_progress=1.0,
-                 alpha_mask=None):
+                 alpha_mask=None, near_dev=None):
         self.aabb = [float(v) for v in aabb]  # lo xyz, hi xyz
+        # a one-float device tensor holding near_far[0] (JtScene.near_plane_dev: hipGraph replay under a moving near plane)
+        self.near_dev = near_dev
         self.plane_hw = [(int(h), int(w)) for h, w in plane_hw]
         self.line_len = [int(v) for v in line_len]
         self.n_comp_density = int(n_comp_density)
@@ -333,6 +335,7 @@ class RenderCfg:
         s.n_comp_app = self.n_comp_app
         s.step_size = self.step_size
         s.near_plane, s.far_plane = self.near_far
+        s.near_plane_dev = self.near_dev.data_ptr() if self.near_dev is not None else None
         s.distance_scale = self.distance_scale
         s.density_shift = self.density_shift
         s.density_act = self.density_act

@@ -403,7 +403,8 @@ class BAT_VMSplit(torch.nn.Module):
         if bool(get("detach_ndc_center_shift", False)):
             raise NotImplementedError("arch.detach_ndc_center_shift=true is not built (false in bat_llff_VM_MLP)")
 
-    def _render_cfg(self, S, ndc_ray, white_bg, plane_hw=None, view_pe_progress=1.0, fea_pe_progress=1.0, use_mask=True):
+    def _render_cfg(self, S, ndc_ray, white_bg, plane_hw=None, view_pe_progress=1.0, fea_pe_progress=1.0, use_mask=True,
+                    near_dev=None):
         """the scene description a render launch takes (ops.RenderCfg mirrors JtScene)"""
         g = self.gridSize.tolist()
         if plane_hw is None:
@@ -419,7 +420,8 @@ class BAT_VMSplit(torch.nn.Module):
             weight_thres=self.rayMarch_weight_thres, n_samples=S, ndc=ndc_ray, white_bg=white_bg, app_dim=self.app_dim,
             mlp_kind=self.renderModule.kind, mlp_hidden=self.featureC, view_pe=self.view_pe, fea_pe=self.fea_pe,
             view_pe_progress=view_pe_progress, fea_pe_progress=fea_pe_progress,
-            alpha_mask=self.alphaMask.kernel_args() if (self.alphaMask is not None and use_mask) else None)
+            alpha_mask=self.alphaMask.kernel_args() if (self.alphaMask is not None and use_mask) else None,
+            near_dev=near_dev)
 
     def render_pose_fused(self, opt, center, ray_dir, image, ray_idx, rays_per_view, white_bg=True, ndc_ray=False,
                           N_samples=-1, view_pe_progress=1.0, fea_pe_progress=1.0):
@@ -452,10 +454,11 @@ class BAT_VMSplit(torch.nn.Module):
         S = N_samples if N_samples > 0 else self.nSamples
         near, far = float(self.near_far[0]), float(self.near_far[1])
         R = center.shape[0]
-        jitter = zvals = None
+        jitter = zvals = near_dev = None
         if ndc_ray:
             zs = getattr(self, "zvals_static", None)
             if zs is not None and zs[0].numel() == S:
+                near_dev = zs[0]  # its first element IS the current near plane: the depth map's "- near" follows it too
                 # hipGraph capture / replay (graphed.GraphedTrainStep): the un-jittered row linspace(near, far, S) and the
                 # jitter scale (far - near) / S live in static device memory, refreshed in front of every replay -- the
                 # near plane follows a schedule (model/tensorf.py:230-232) and must not be baked into the graph
@@ -499,7 +502,8 @@ class BAT_VMSplit(torch.nn.Module):
             wb = False
         cfg = self._render_cfg(S, ndc_ray, wb, plane_hw, view_pe_progress, fea_pe_progress,
                                # empty-space samples are dropped only while the blur is off (batBase.py:76-82)
-                               use_mask=(c2f_mode is None and c2f_parameter_density is None and c2f_parameter_color is None))
+                               use_mask=(c2f_mode is None and c2f_parameter_density is None and c2f_parameter_color is None),
+                               near_dev=near_dev)
         # blur off and a backward to come: the regularisers ride on the render node (ops.RenderRays), so that their
         # gradient is added into the render gradient in place; _reg() then finds the values in its cache
         lw = opt.get("loss_weight", None) if isinstance(opt, dict) else getattr(opt, "loss_weight", None)

@@ -53,8 +53,9 @@ def test_struct_layout_matches_header(tmp_path):
         '#include <stdio.h>\n#include <stddef.h>\n#include "jt_render.h"\n'
         "int main(void) {\n"
         '  printf("%zu %zu %zu %zu\\n", sizeof(JtScene), sizeof(JtFactors), sizeof(JtMlp), sizeof(JtBlurItem));\n'
-        '  printf("%zu %zu %zu %zu %zu\\n", offsetof(JtScene, n_comp_density), offsetof(JtScene, fea_pe_progress),\n'
-        "         offsetof(JtScene, mask_dims), offsetof(JtScene, mask_inv), offsetof(JtFactors, alpha_volume));\n"
+        '  printf("%zu %zu %zu %zu %zu %zu\\n", offsetof(JtScene, n_comp_density), offsetof(JtScene, fea_pe_progress),\n'
+        "         offsetof(JtScene, mask_dims), offsetof(JtScene, mask_inv), offsetof(JtFactors, alpha_volume),\n"
+        "         offsetof(JtScene, near_plane_dev));\n"
         "  return 0;\n}\n")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
@@ -62,8 +63,9 @@ def test_struct_layout_matches_header(tmp_path):
     assert sizes == [ctypes.sizeof(_lib.JtScene), ctypes.sizeof(_lib.JtFactors), ctypes.sizeof(_lib.JtMlp),
                      ctypes.sizeof(_lib.JtBlurItem)]
     assert offs == [_lib.JtScene.n_comp_density.offset, _lib.JtScene.fea_pe_progress.offset,
-                    _lib.JtScene.mask_dims.offset, _lib.JtScene.mask_inv.offset, _lib.JtFactors.alpha_volume.offset]
-    assert ctypes.sizeof(_lib.JtScene) == 43 * 4  # 4-byte fields only
+                    _lib.JtScene.mask_dims.offset, _lib.JtScene.mask_inv.offset, _lib.JtFactors.alpha_volume.offset,
+                    _lib.JtScene.near_plane_dev.offset]
+    assert ctypes.sizeof(_lib.JtScene) == 43 * 4 + 4 + 8  # 43 four-byte fields, padding, near_plane_dev
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():

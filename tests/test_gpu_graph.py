@@ -266,20 +266,26 @@ def test_graph_replay_of_llff_iterations_is_bit_identical_to_eager(it0):
             np.random.seed(5)
             torch.manual_seed(123)   # the coin stream
             stepper = GraphedTrainStep(model, min_repeats=0) if use_graph else None
-            losses, tvw = [], []
+            losses, tvw, depths = [], [], []
             for k in range(K):
                 model.before_iteration(opt)
                 var = Opt(dict(var0))
                 loss = stepper.train_iteration(opt, var, force_eager=k < 2) if use_graph else model.train_iteration(opt, var)
                 losses.append([float(loss[t].detach()) for t in ("all", "render", "L1", "TV_density", "TV_color")])
+                depths.append((stepper.last_var if use_graph else var).depth.detach().flatten().clone())
                 model.after_iteration(opt)
                 tvw.append(float(opt.loss_weight.TV_density))
             sd = {k_: v.detach().clone() for k_, v in model.graph.state_dict().items()}
             res.append((np.array(losses), sd, stepper.stats if use_graph else None, float(torch.rand((1,))), tvw,
-                        None if stepper is None else (stepper._lw.cpu().tolist(), list(model.fused_loss_weights(opt)))))
+                        None if stepper is None else (stepper._lw.cpu().tolist(), list(model.fused_loss_weights(opt))),
+                        depths))
     finally:
         lib.jt_set_deterministic(prev)
-    (l_e, sd_e, _, r_e, tv_e, _), (l_g, sd_g, stats, r_g, tv_g, lw) = res
+    (l_e, sd_e, _, r_e, tv_e, _, d_e), (l_g, sd_g, stats, r_g, tv_g, lw, d_g) = res
+    # the depth map carries "- near_far[0] + 0.05" (batBase.py:147-150): under replay the near plane of THIS iteration, not the
+    # one the launch was captured with (JtScene.near_plane_dev)
+    for k in range(K):
+        assert torch.equal(d_e[k], d_g[k]), "depth map of iteration %d" % k
     assert stats["replayed"] >= K - 8 and stats["captured"] >= 2, stats
     assert r_e == r_g and tv_e == tv_g and tv_e[0] > tv_e[-1] > 0   # same coin stream consumed, TV weights decaying
     if it0 < 20000:  # the first half of the run: pose steps every 8th iteration, the near plane on its way down

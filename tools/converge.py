@@ -72,6 +72,17 @@ def pose_errors(opt, model):
     return float(np.rad2deg(err.R.mean().item())), float(err.t.mean().item())
 
 
+def relative_rotation_error(opt, model):
+    """Alignment-free: mean angle between R_i R_0^T of the recovered cameras and of the ground truth (degrees).  A common
+    rotation of the whole rig -- what the Procrustes fit of a small planar camera cloud cannot pin down -- cancels."""
+    pose, pose_gt = model.get_all_training_poses(opt)
+    rel = pose[:, :, :3] @ pose[:1, :, :3].transpose(-2, -1)
+    rel_gt = pose_gt[:, :, :3] @ pose_gt[:1, :, :3].transpose(-2, -1)
+    d = rel @ rel_gt.transpose(-2, -1)
+    tr = d[:, 0, 0] + d[:, 1, 1] + d[:, 2, 2]
+    return float(np.rad2deg(((tr - 1) / 2).clamp(-1 + 1e-7, 1 - 1e-7).acos()[1:].mean().item()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="bat_blender_VM")
@@ -123,11 +134,12 @@ def main():
     torch.cuda.synchronize()
     t_train = time.perf_counter() - t_start
     r1, t1 = pose_errors(opt, model)
+    rrel = relative_rotation_error(opt, model)
     res = model.evaluate_full(opt)
     print(json.dumps(dict(final=True, iterations=model.it, train_seconds=round(t_train, 2), loss=round(float(loss.all), 6),
                           rot_deg_start=round(r0, 4), rot_deg_end=round(r1, 4), trans_start=round(t0, 5),
                           trans_end=round(t1, 5), rot_gain=round(r0 / max(r1, 1e-9), 1),
-                          trans_gain=round(t0 / max(t1, 1e-9), 1), test_psnr=round(res.psnr, 2),
+                          trans_gain=round(t0 / max(t1, 1e-9), 1), rot_rel_deg_end=round(rrel, 4), test_psnr=round(res.psnr, 2),
                           psnr_per_view=[round(p, 2) for p in res.psnr_per_view])), flush=True)
 
 
