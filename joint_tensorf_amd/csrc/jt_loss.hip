@@ -76,21 +76,35 @@ __global__ __launch_bounds__(1024) void k_render_loss_fwd_one(const float* __res
   }
   const long n = (long)B * r * 3;
   float s0 = 0.f, c0 = 0.f, s1 = 0.f, c1 = 0.f;
-  for (long i = threadIdx.x; i < n; i += blockDim.x) {
-    const int ch = (int)(i % 3);
-    const long bk = i / 3;
-    const int k = (int)(bk % r), b = (int)(bk / r);
-    const long pix = ray_idx[k];
-    const float d = rgb[i] - image[((long)b * 3 + ch) * HW + pix];
-    const float m = mask ? (float)mask[(long)b * HW + pix] : 1.f;
-    const float e = m * d, ne = (1.f - m) * d;
-    if (e == e) {
-      s0 += e * e;
-      c0 += 1.f;
+  // a thread's elements (i = t, t + 1024, ...) are summed in that order, but FETCHED eight at a time: the index -> pixel chain
+  // is two dependent loads, and one workgroup working through them one after the other took 19 us for 6 000 colours
+  constexpr int U = 8;
+  for (long i0 = threadIdx.x; i0 < n; i0 += (long)U * blockDim.x) {
+    float dv[U], mv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = i0 + (long)u * blockDim.x;
+      const long ii = i < n ? i : n - 1;
+      const int ch = (int)(ii % 3);
+      const long bk = ii / 3;
+      const int k = (int)(bk % r), b = (int)(bk / r);
+      const long pix = ray_idx[k];
+      dv[u] = rgb[ii] - image[((long)b * 3 + ch) * HW + pix];
+      mv[u] = mask ? (float)mask[(long)b * HW + pix] : 1.f;
     }
-    if (ne == ne) {
-      s1 += ne * ne;
-      c1 += 1.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (i0 + (long)u * blockDim.x >= n) break;
+      const float d = dv[u], m = mv[u];
+      const float e = m * d, ne = (1.f - m) * d;
+      if (e == e) {
+        s0 += e * e;
+        c0 += 1.f;
+      }
+      if (ne == ne) {
+        s1 += ne * ne;
+        c1 += 1.f;
+      }
     }
   }
   s0 = wave_sum(s0);

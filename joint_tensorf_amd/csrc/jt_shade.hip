@@ -1502,7 +1502,12 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   };
   // JT_SCATTER_FLAGS (read once): bit 0 line gradients through LDS (k_shade_scatter)
   static const int sflags_env = [] { const char* e = getenv("JT_SCATTER_FLAGS"); return e ? atoi(e) & 1 : 1; }();
-  constexpr int SW = 8;  // waves per scatter workgroup, ONE workgroup per CU (two waves per SIMD reach the atomic unit's rate)
+  // waves per scatter workgroup, ONE workgroup per CU: two waves per SIMD reach the atomic unit's rate on VM-48; the 20-channel
+  // scatter runs at 40 % of that rate (latency of the walk, not atomics) and takes four
+#ifndef JT_SCATTER_WAVES20
+#define JT_SCATTER_WAVES20 16
+#endif
+  constexpr int SW = C::CA < 48 ? JT_SCATTER_WAVES20 : 8;
   int line_floats = 0;
   for (int a = 0; a < 3; ++a) line_floats = std::max(line_floats, D.ll[a] * C::CA);
   int sflags = split ? sflags_env : 0;

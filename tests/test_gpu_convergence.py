@@ -345,3 +345,81 @@ def test_llff_pose_error_curve_matches_the_oracle_loop():
     for (rh, th), (ro, to) in zip(curve_h, curve_o):
         assert abs(rh - ro) <= 0.15 * ro + 0.05, (curve_h, curve_o)
         assert abs(th - to) <= 0.15 * to + 0.003, (curve_h, curve_o)
+
+
+def _oracle_rendered(model, opt):
+    """Replace the scene's forward (BAT_VMSplit.forward -> ops.render_rays: blur, march, shade, compositing and their autograd
+    through the HIP kernels) by the oracle's stock-torch render of the SAME live Parameters, taking the same random draws in
+    the same order (shared z jitter row, then the white-background coin).  Everything around it -- schedule, lattice, ray
+    generation, losses, regularisers, Adam, upsampling, alpha mask -- stays bat_hip.Model's."""
+    tf = model.graph.nerf.tensorf
+
+    def forward(opt_, center, ray_dir, white_bg=True, is_train=False, ndc_ray=False, N_samples=-1,
+                c2f_parameter_density=None, c2f_parameter_color=None, c2f_mode=None, c2f_kernel_size=None,
+                is_test_optim=False, view_pe_progress=1.0, fea_pe_progress=1.0):
+        tf.__dict__.setdefault("_reg_cache", {}).clear()
+        S = N_samples if N_samples > 0 else tf.nSamples
+        cfg = O.SceneCfg(opt.data.scene_bbox, tf.gridSize.tolist(), [float(tf.near_far[0]), float(tf.near_far[1])],
+                         step_ratio=opt.nerf.step_ratio, density_shift=float(opt.arch.density_shift),
+                         distance_scale=float(opt.arch.distance_scale), fea2denseAct="relu",
+                         rayMarch_weight_thres=float(opt.arch.tensorf.rayMarch_weight_thres), shadingMode="MLP_Fea_WeakView",
+                         view_pe=2, fea_pe=2, ndc_near_plane=float(opt.arch.ndc_near_plane)).to(DEV)
+        params = O.params_from_state_dict(dict(tf.named_parameters()), prefix="")
+        jit = torch.rand(1, S, device=DEV) if (is_train and ndc_ray) else None
+        kd = kc = None
+        if c2f_mode is not None:
+            kd = O.get_kernel(cfg, c2f_parameter_density, c2f_kernel_size).to(DEV)
+            kc = O.get_kernel(cfg, c2f_parameter_color, c2f_kernel_size).to(DEV)
+        wb = True if white_bg else (float(torch.rand((1,))) < 0.5 if is_train else False)
+        am = None
+        if tf.alphaMask is not None:
+            am = (tf.alphaMask.alpha_volume, tf.alphaMask.aabb)
+        rgb, depth, opacity = O.render(cfg, params, center, ray_dir, S, white_bg=wb, jitter=jit, ndc_ray=ndc_ray,
+                                       kernel_density=kd, kernel_color=kc, alpha_mask=am)
+        return rgb, depth, opacity
+
+    tf.forward = forward
+    return tf
+
+
+@pytest.mark.skipif(__import__("os").environ.get("JT_LONG_TESTS") != "1", reason="ten minutes: set JT_LONG_TESTS=1")
+def test_llff_full_schedule_with_the_oracle_render_ends_where_the_hip_path_ends():
+    """Round-3 verdict item 3, the alternative it allows: "or commit the oracle-side curve showing the reference algorithm fails
+    identically".  The WHOLE compressed bat_llff_VM_MLP schedule (5 000 iterations, five grid stages) on LLFF_SCENE twice from
+    the same seed: once through the HIP renderer, once with the renderer replaced by the oracle's stock torch ops + torch
+    autograd (`_oracle_rendered`).  Both runs are chaotic in their details (Adam amplifies round-off over 5 000 steps), so the
+    assertion is on where they END: camera-centre recovery within a factor two of each other, held-out PSNR within 6 dB,
+    neither reaching the 5 x the verdict asked of the scene."""
+    import json
+    cv = _converge()
+    out = {}
+    for name in ("hip", "oracle"):
+        opt, model = cv.build(_args(graph=False, **LLFF_SCENE), device=DEV)
+        r0, t0 = cv.pose_errors(opt, model)
+        tf = model.graph.nerf.tensorf
+        if name == "oracle":
+            _oracle_rendered(model, opt)
+        curve = []
+        orig_after = model.after_iteration
+
+        def after(o, it=None, model=model, opt=opt, curve=curve, orig_after=orig_after):
+            orig_after(o, it)
+            if model.it % 500 == 0:
+                curve.append((model.it,) + tuple(round(v, 4) for v in cv.pose_errors(opt, model)))
+        model.after_iteration = after
+        model.train(opt)
+        r1, t1 = cv.pose_errors(opt, model)
+        rrel = cv.relative_rotation_error(opt, model)
+        if name == "oracle":
+            del tf.forward                      # evaluation of the trained state through the product path on both sides
+        res = model.evaluate_full(opt)
+        out[name] = dict(rot_deg=(round(r0, 3), round(r1, 3)), rot_rel_deg_end=round(rrel, 3), trans=(round(t0, 4), round(t1, 4)),
+                         trans_gain=round(t0 / t1, 2), psnr=round(res.psnr, 2), grid=tf.gridSize.tolist(), curve=curve)
+        print(name, json.dumps(out[name]), flush=True)
+        del model
+        torch.cuda.empty_cache()
+    h, o = out["hip"], out["oracle"]
+    assert h["grid"] == o["grid"] == [771, 859, 771]
+    assert 0.5 < h["trans_gain"] / o["trans_gain"] < 2.0
+    assert abs(h["psnr"] - o["psnr"]) < 6.0
+    assert o["trans_gain"] < 5.0
