@@ -408,7 +408,7 @@ int jt_loss_sum_backward_dyn(const float* g_total, const float* w4, float* g_ren
 
 /* All regularisers of one scene in one call (replaces the loop bodies of model/tensorf.py:127-130):
  *   out3 = { density_L1(), TV_loss_density(TVLoss()), TV_loss_app(TVLoss()) }   (tensoRF.py:212-228).
- * plane_hw_line[9] = {H_i, W_i, L_i} for i = 0..2; scratch36 (forward): 48 floats of device scratch that must be ZERO when the
+ * plane_hw_line[9] = {H_i, W_i, L_i} for i = 0..2; scratch36 (forward): 640 floats of device scratch that must be ZERO when the
  * first call sees them and are left zero by every call (the one launch sums into them and its last workgroup combines and resets
  * them: no zero fill and no combine launch per iteration); not to be shared by calls that run concurrently.
  * with_tv_density / with_tv_app == 0: that TV term has weight zero in the run; it is not evaluated and out3

@@ -76,25 +76,26 @@ __global__ __launch_bounds__(1024) void k_render_loss_fwd_one(const float* __res
   }
   const long n = (long)B * r * 3;
   float s0 = 0.f, c0 = 0.f, s1 = 0.f, c1 = 0.f;
-  // a thread's elements (i = t, t + 1024, ...) are summed in that order, but FETCHED eight at a time: the index -> pixel chain
-  // is two dependent loads, and one workgroup working through them one after the other took 19 us for 6 000 colours
+  // a thread's elements (i = t, t + 1024, ...) are summed in that order, but FETCHED eight at a time (the index -> pixel chain is
+  // two dependent loads), with 32-bit index arithmetic (n < 2^31 is checked by the caller; with `long` the four divisions per
+  // element were most of this kernel's 19 us)
   constexpr int U = 8;
-  for (long i0 = threadIdx.x; i0 < n; i0 += (long)U * blockDim.x) {
+  const unsigned un = (unsigned)n, ur = (unsigned)r;
+  for (unsigned i0 = threadIdx.x; i0 < un; i0 += U * blockDim.x) {
     float dv[U], mv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long i = i0 + (long)u * blockDim.x;
-      const long ii = i < n ? i : n - 1;
-      const int ch = (int)(ii % 3);
-      const long bk = ii / 3;
-      const int k = (int)(bk % r), b = (int)(bk / r);
+      const unsigned i = i0 + u * blockDim.x;
+      const unsigned ii = i < un ? i : un - 1;
+      const unsigned bk = ii / 3u, ch = ii - bk * 3u;
+      const unsigned b = bk / ur, k = bk - b * ur;
       const long pix = ray_idx[k];
       dv[u] = rgb[ii] - image[((long)b * 3 + ch) * HW + pix];
       mv[u] = mask ? (float)mask[(long)b * HW + pix] : 1.f;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (i0 + (long)u * blockDim.x >= n) break;
+      if (i0 + u * blockDim.x >= un) break;
       const float d = dv[u], m = mv[u];
       const float e = m * d, ne = (1.f - m) * d;
       if (e == e) {
@@ -151,10 +152,10 @@ __global__ __launch_bounds__(256) void k_render_loss_bwd(const float* __restrict
   const long n = (long)B * r * 3;
   const float gg = g[0];
   const float ke = (mask ? fe : 1.f) * 2.f / acc[1], kne = mask ? fne * 2.f / acc[3] : 0.f;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const int ch = (int)(i % 3);
-    const long bk = i / 3;
-    const int k = (int)(bk % r), b = (int)(bk / r);
+  const unsigned un = (unsigned)n, ur = (unsigned)r;   // (n < 2^31: checked by the caller)
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < un; i += gridDim.x * blockDim.x) {
+    const unsigned bk = i / 3u, ch = i - bk * 3u;
+    const unsigned b = bk / ur, k = bk - b * ur;
     const long pix = ray_idx[k];
     const float d = rgb[i] - image[((long)b * 3 + ch) * HW + pix];
     const float m = mask ? (float)mask[(long)b * HW + pix] : 1.f;
@@ -360,6 +361,7 @@ static int render_loss_backward(const float* rgb, const float* image, const int6
   if (!rgb || !image || !ray_idx || !acc4 || !g_loss || !g_rgb || n_views < 1 || rays_per_view < 1 || n_pixels < 1)
     return JT_ERR_ARG;
   long n = (long)n_views * rays_per_view * 3;
+  if (n >= (1l << 31)) return JT_ERR_UNSUPPORTED;
   int blocks = (int)min((n + 255) / 256, 512L);
   hipLaunchKernelGGL(k_render_loss_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rgb, image, ray_idx,
                      edge_mask, n_views, rays_per_view, n_pixels, acc4, edge_factor, non_edge_factor, g_loss, g_rgb,

@@ -14,14 +14,19 @@ template <bool TV>
 __device__ inline void factor_reg_fwd_body(const float* __restrict__ x, int H, int W, int C, float* __restrict__ out,
                                            int bid, int nblocks) {
   __shared__ float red[4][3];
-  const int C4 = C / 4;
-  const long total = (long)H * W * C4;
+  const unsigned C4 = C / 4;
+  const unsigned total = (unsigned)H * W * C4;  // (< 2^31: checked by the callers)
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (long idx = bid * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)nblocks * blockDim.x) {
-    const int c4 = (int)(idx % C4);
-    const long tex = idx / C4;
-    const int xx = (int)(tex % W), yy = (int)(tex / W);
-    const float* p = x + tex * C + c4 * 4;
+  // (32-bit index arithmetic: with `long` the three divisions per item were most of the kernel's instructions)
+#pragma unroll 4
+  for (unsigned idx = bid * blockDim.x + threadIdx.x; idx < total; idx += (unsigned)nblocks * blockDim.x) {
+    int xx = 0, yy = 0;
+    if (TV) {
+      const unsigned tex = idx / C4;
+      yy = (int)(tex / (unsigned)W);
+      xx = (int)(tex - (unsigned)yy * W);
+    }
+    const float* p = x + (size_t)idx * 4;   // [tex][C] with C = 4 C4: quad idx starts at float 4 idx
     const float4 v = ld4(p);
     s0 += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
     if (TV && yy + 1 < H) {
@@ -62,14 +67,17 @@ __device__ inline void factor_reg_bwd_body(const float* __restrict__ x, int H, i
                                            const float* __restrict__ coef, float* __restrict__ g, int accumulate,
                                            int bid, int nblocks) {
   const float c0 = coef[0], c1 = coef[1], c2 = coef[2];
-  const int C4 = C / 4;
-  const long total = (long)H * W * C4;
+  const unsigned C4 = C / 4;
+  const unsigned total = (unsigned)H * W * C4;
   const bool tv = (c1 != 0.f) || (c2 != 0.f);
-  for (long idx = bid * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)nblocks * blockDim.x) {
-    const int c4 = (int)(idx % C4);
-    const long tex = idx / C4;
-    const int xx = (int)(tex % W), yy = (int)(tex / W);
-    const long off = tex * C + c4 * 4;
+  for (unsigned idx = bid * blockDim.x + threadIdx.x; idx < total; idx += (unsigned)nblocks * blockDim.x) {
+    int xx = 0, yy = 0;
+    if (tv) {
+      const unsigned tex = idx / C4;
+      yy = (int)(tex / (unsigned)W);
+      xx = (int)(tex - (unsigned)yy * W);
+    }
+    const long off = (long)idx * 4;
     const float4 v = ld4(x + off);
     float4 r;
     r.x = c0 * ((v.x > 0.f) - (v.x < 0.f));
@@ -141,12 +149,15 @@ __device__ inline void reg_combine(const float* sums, const RegDims& S, float* _
 }
 
 // ONE launch (round 4; before: a zero fill of the scratch, this kernel, a combine kernel).  Every workgroup adds its partial sums
-// into scratch[0 .. 35] and takes a ticket; the workgroup that draws the last ticket combines the 27 sums into out3 and puts the
-// scratch back to zero -- the scratch must be ZERO when the first call sees it and is left zero by every call.  The tickets are
-// two-level: one counter per tensor (scratch[37 + slot]), and the workgroup that completes a tensor draws from the master counter
-// (scratch[36]) -- one word serves ~88 returning atomics per microsecond, and 1 500 (Blender) / 4 600 (LLFF) workgroups drawing
-// from ONE word made the tickets, not the 30 / 286 MB of factors, the duration of the launch.
-// scratch: 36 sums, the master counter, nine per-tensor counters = 46 words (the interface asks for 48)
+// into one of kRegShards copies of the 36 sums and takes a ticket; the workgroup that draws the last ticket adds the copies up,
+// combines the 27 sums into out3 and puts the scratch back to zero -- the scratch must be ZERO when the first call sees it and is
+// left zero by every call.  Why copies: float atomics on ONE address are serialised at the memory side (~50 ns each), and 512
+// workgroups per tensor adding into the same three words took 25 us whatever the tensor's size (30 MB of density factors:
+// 37.6 us; one word per 32 workgroups: 17 us).  The tickets are two-level for the same reason: one counter per tensor, and the
+// workgroup that completes a tensor draws from the master counter.
+// scratch (floats): [shard][36] sums, then the master counter and nine per-tensor counters; the interface asks for 640.
+constexpr int kRegShards = 16;
+constexpr int kRegCounters = kRegShards * 36;
 __global__ __launch_bounds__(256) void k_reg_batch_fwd(RegBatch B, RegDims S, float* __restrict__ scratch,
                                                        float* __restrict__ out3) {
   int it = 0;
@@ -155,10 +166,11 @@ __global__ __launch_bounds__(256) void k_reg_batch_fwd(RegBatch B, RegDims S, fl
     if ((int)blockIdx.x >= B.t[i].block0) it = i;
   const RegBatchItem& T = B.t[it];
   const int bid = blockIdx.x - T.block0;
+  float* sums = scratch + (bid % kRegShards) * 36 + T.slot * 3;
   if (T.tv)
-    factor_reg_fwd_body<true>(T.x, T.H, T.W, T.C, scratch + T.slot * 3, bid, T.nblocks);
+    factor_reg_fwd_body<true>(T.x, T.H, T.W, T.C, sums, bid, T.nblocks);
   else
-    factor_reg_fwd_body<false>(T.x, T.H, T.W, T.C, scratch + T.slot * 3, bid, T.nblocks);
+    factor_reg_fwd_body<false>(T.x, T.H, T.W, T.C, sums, bid, T.nblocks);
   // (no __threadfence(): a release fence writes the XCD's L2 back, ~2-6 us per workgroup, 4 600 of them -- measured +115 us on
   //  the LLFF grid.  The sums and the tickets are float / integer atomics, which execute at the memory side and never sit in an
   //  L2: waiting for this workgroup's own atomics to be acknowledged is all the ordering a ticket needs.)
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(256) void k_reg_batch_fwd(RegBatch B, RegDims S, fl
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned* cnt = reinterpret_cast<unsigned*>(scratch + 36);
+    unsigned* cnt = reinterpret_cast<unsigned*>(scratch + kRegCounters);
     bool last = false;
     if (atomicAdd(cnt + 1 + T.slot, 1u) == (unsigned)T.nblocks - 1u)   // this tensor is complete ...
       last = atomicAdd(cnt, 1u) == (unsigned)B.n - 1u;                 // ... and it was the last one
@@ -175,8 +187,12 @@ __global__ __launch_bounds__(256) void k_reg_batch_fwd(RegBatch B, RegDims S, fl
   }
   __syncthreads();
   if (s_last) {   // (uniform over the workgroup) read AND reset in one returning atomic per word
-    if (threadIdx.x < 36) s_sums[threadIdx.x] = atomicExch(scratch + threadIdx.x, 0.f);
-    if (threadIdx.x >= 36 && threadIdx.x < 36 + 10) atomicExch(reinterpret_cast<unsigned*>(scratch + threadIdx.x), 0u);
+    if (threadIdx.x < 36) {
+      float a = 0.f;
+      for (int sh = 0; sh < kRegShards; ++sh) a += atomicExch(scratch + sh * 36 + threadIdx.x, 0.f);
+      s_sums[threadIdx.x] = a;
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 10) atomicExch(reinterpret_cast<unsigned*>(scratch + kRegCounters) + (threadIdx.x - 64), 0u);
     __syncthreads();
     if (threadIdx.x == 0) reg_combine(s_sums, S, out3);
   }
@@ -209,6 +225,7 @@ extern "C" int jt_factor_reg_forward(const float* x, int H, int W, int C, float*
   if (!x || !out3 || H < 1 || W < 1 || C < 4) return JT_ERR_ARG;
   if (C % 4) return JT_ERR_UNSUPPORTED;
   long total = (long)H * W * (C / 4);
+  if (total >= (1l << 31)) return JT_ERR_UNSUPPORTED;  // the kernels index quads with 32 bits
   int blocks = (int)min((total + 255) / 256, 1024L);
   hipLaunchKernelGGL(k_factor_reg_fwd<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, H, W, C, out3);
   JT_LAUNCH_CHECK();
@@ -220,6 +237,7 @@ extern "C" int jt_factor_reg_backward(const float* x, int H, int W, int C, const
   if (!x || !coef3 || !g || H < 1 || W < 1 || C < 4) return JT_ERR_ARG;
   if (C % 4) return JT_ERR_UNSUPPORTED;
   long total = (long)H * W * (C / 4);
+  if (total >= (1l << 31)) return JT_ERR_UNSUPPORTED;  // the kernels index quads with 32 bits
   int blocks = (int)min((total + 255) / 256, 2048L);
   hipLaunchKernelGGL(k_factor_reg_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, H, W, C, coef3, g, accumulate);
   JT_LAUNCH_CHECK();
@@ -277,7 +295,11 @@ extern "C" int jt_reg_losses_forward(const JtFactors* factors, const int32_t* pl
     if (i >= 6 && !tv) continue;  // appearance planes only enter TV_color
     const RegTensor& t = S.t[i];
     long total = (long)t.H * t.W * (t.C / 4);
-    int blocks = (int)min((total + 255) / 256, 512L);  // every block ends in three same-address atomics
+    if (total >= (1l << 31)) return JT_ERR_UNSUPPORTED;  // the kernels index quads with 32 bits
+    // (measured, 400^3 L1-only / LLFF final grid with both TV terms: 128 workgroups per tensor 17 / 126 us, 512: 27 / 107,
+    //  1 024: 44 / 131 -- the three-load TV items want the parallelism, the one-load L1 items the shorter epilogue)
+    static const long max_blocks = [] { const char* e = getenv("JT_REG_BLOCKS"); return e ? atol(e) : 0L; }();
+    int blocks = (int)min((total + 255) / 256, max_blocks > 0 ? max_blocks : (tv ? 512L : 128L));
     if (jt_deterministic()) blocks = 1;                // one workgroup per tensor: a fixed summation order
     B.t[B.n++] = {t.x, nullptr, t.H, t.W, t.C, tv ? 1 : 0, i, nblk, blocks};
     nblk += blocks;
@@ -308,6 +330,7 @@ extern "C" int jt_reg_losses_backward(const JtFactors* factors, const int32_t* p
     if (!t.g) return JT_ERR_ARG;
     (void)with_tv_density;  // the TV coefficient of a density plane is on the device (0 when its weight is 0)
     long total = (long)t.H * t.W * (t.C / 4);
+    if (total >= (1l << 31)) return JT_ERR_UNSUPPORTED;  // the kernels index quads with 32 bits
     int blocks = (int)min((total + 255) / 256, 2048L);
     B.t[B.n++] = {t.x, t.g, t.H, t.W, t.C, 0, i, nblk, blocks};
     nblk += blocks;

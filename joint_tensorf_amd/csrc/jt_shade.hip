@@ -1502,46 +1502,52 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   };
   // JT_SCATTER_FLAGS (read once): bit 0 line gradients through LDS (k_shade_scatter)
   static const int sflags_env = [] { const char* e = getenv("JT_SCATTER_FLAGS"); return e ? atoi(e) & 1 : 1; }();
-  // waves per scatter workgroup, ONE workgroup per CU: two waves per SIMD reach the atomic unit's rate on VM-48; the 20-channel
-  // scatter runs at 40 % of that rate (latency of the walk, not atomics) and takes four
-#ifndef JT_SCATTER_WAVES20
-#define JT_SCATTER_WAVES20 16
-#endif
-  constexpr int SW = C::CA < 48 ? JT_SCATTER_WAVES20 : 8;
+  // waves per scatter workgroup, ONE workgroup per CU: two waves per SIMD (8) reach the atomic unit's rate on VM-48; the
+  // 20-channel scatter runs at 40 % of that rate (latency of the walk, not atomics) and takes four per SIMD (16) where the LDS
+  // line still fits beside their step records (runs of 8)
   int line_floats = 0;
   for (int a = 0; a < 3; ++a) line_floats = std::max(line_floats, D.ll[a] * C::CA);
   int sflags = split ? sflags_env : 0;
   if (det) sflags &= ~1;
-  auto scatter_lds = [&](int run, int fl) {
-    return (size_t)(ScatCfg<C>::BT_FLOATS + ((fl & 1) ? line_floats : 0) + SW * ScatCfg<C>::wave_floats(run)) * sizeof(float);
+  auto scatter_lds = [&](int run, int fl, int sw) {
+    return (size_t)(ScatCfg<C>::BT_FLOATS + ((fl & 1) ? line_floats : 0) + sw * ScatCfg<C>::wave_floats(run)) * sizeof(float);
   };
-  if (split && scatter_lds(split, sflags) > 160 * 1024) sflags &= ~1;  // a line too long for the LDS: global atomics as before
+  static const int sw_env = [] { const char* e = getenv("JT_SCATTER_WAVES"); return e ? atoi(e) : 0; }();
+  int sw = 8;
+  if (C::CA < 48 && split && (sw_env == 16 || (sw_env == 0 && scatter_lds(split, sflags, 16) <= 160 * 1024))) sw = 16;
+  if (split && scatter_lds(split, sflags, sw) > 160 * 1024) sflags &= ~1;  // a line too long for the LDS: global atomics as before
   auto launch_scatter = [&](int ci) -> int {
     if (!split || (ablate & 1)) return JT_OK;
     const int start = ci * chunk, ccap = std::min(chunk, cap - start);
     const float* rc = recs + W::rec_floats_per_chunk() * ci;
-    const size_t lds_s = scatter_lds(split, sflags);
-#define JT_SCATTER_LAUNCH(RUN_, DET_, FL_)                                                                              \
+    const size_t lds_s = scatter_lds(split, sflags, sw);
+#define JT_SCATTER_LAUNCH(RUN_, DET_, FL_, SW_)                                                                         \
   {                                                                                                                     \
     static bool attr = false;                                                                                           \
     if (!attr) {                                                                                                        \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_scatter<C, DET_, RUN_, SW, FL_>),                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_scatter<C, DET_, RUN_, SW_, FL_>),                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                \
       attr = true;                                                                                                      \
     }                                                                                                                   \
     const long nbatch = ((long)ccap + 4 * RUN_ - 1) / (4 * RUN_);                                                       \
-    const int sblocks = (int)std::min<long>((nbatch + SW - 1) / SW, 256L);                                              \
-    hipLaunchKernelGGL((k_shade_scatter<C, DET_, RUN_, SW, FL_>), dim3(sblocks), dim3(SW * 64), lds_s, st, D, M, G,     \
+    const int sblocks = (int)std::min<long>((nbatch + SW_ - 1) / SW_, 256L);                                            \
+    hipLaunchKernelGGL((k_shade_scatter<C, DET_, RUN_, SW_, FL_>), dim3(sblocks), dim3(SW_ * 64), lds_s, st, D, M, G,   \
                        offset, R, g_xyz, rc, start, ccap, cap, bad, line_floats);                                       \
+  }
+#define JT_SCATTER_FL(RUN_, SW_)                                                                \
+  {                                                                                             \
+    if (det) JT_SCATTER_LAUNCH(RUN_, true, 0, SW_)                                              \
+    else if (sflags == 1) JT_SCATTER_LAUNCH(RUN_, false, 1, SW_)                                \
+    else JT_SCATTER_LAUNCH(RUN_, false, 0, SW_)                                                 \
   }
 #define JT_SCATTER_RUN(RUN_)                                                                    \
   {                                                                                             \
-    if (det) JT_SCATTER_LAUNCH(RUN_, true, 0)                                                   \
-    else if (sflags == 1) JT_SCATTER_LAUNCH(RUN_, false, 1)                                     \
-    else JT_SCATTER_LAUNCH(RUN_, false, 0)                                                      \
+    if (C::CA < 48 && sw == 16) JT_SCATTER_FL(RUN_, (C::CA < 48 ? 16 : 8))                      \
+    else JT_SCATTER_FL(RUN_, 8)                                                                 \
   }
     if (split == 8) JT_SCATTER_RUN(8) else JT_SCATTER_RUN(16)
 #undef JT_SCATTER_RUN
+#undef JT_SCATTER_FL
 #undef JT_SCATTER_LAUNCH
     JT_LAUNCH_CHECK();
     return JT_OK;

@@ -180,13 +180,13 @@ _REG_SCRATCH = {}
 
 
 def _reg_scratch(dev):
-    """jt_reg_losses_forward's 48 floats of device scratch: zero when the first call sees them, left zero by every call (the
+    """jt_reg_losses_forward's 640 floats of device scratch: zero when the first call sees them, left zero by every call (the
     kernel's last workgroup resets them) -- one persistent buffer per device instead of a zero fill per iteration"""
     key = str(dev)
     if key not in _REG_SCRATCH:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("the regularisers' scratch must exist before a hipGraph capture")
-        _REG_SCRATCH[key] = torch.zeros(48, device=dev, dtype=torch.float32)
+        _REG_SCRATCH[key] = torch.zeros(640, device=dev, dtype=torch.float32)
     return _REG_SCRATCH[key]
 
 
