@@ -241,8 +241,8 @@ def _build_llff(it0):
     return opt, model, var0
 
 
-@pytest.mark.parametrize("it0", [30000, 7000])
-def test_graph_replay_of_llff_iterations_is_bit_identical_to_eager(it0):
+@pytest.mark.parametrize("it0,switch", [(30000, 0), (7000, 0), (7000, 11)])
+def test_graph_replay_of_llff_iterations_is_bit_identical_to_eager(it0, switch):
     """bat_llff_VM_MLP: it0 = 30 000, past the point where its near-plane schedule has settled (progress 0.5), and -- round
     3 -- it0 = 7 000, in the FIRST half of the run, which round 2 refused to capture: the near plane moves every iteration
     (the un-jittered depth row and the jitter scale reach the graph through static memory, GraphedTrainStep._zvals_static),
@@ -250,6 +250,8 @@ def test_graph_replay_of_llff_iterations_is_bit_identical_to_eager(it0):
     pose steps fall into the 20 iterations).  NDC rays, WeakView MLP,
     the white-background COIN of every training call (two graph variants, the draw handed to whichever path runs), TV
     weights that decay every iteration (read from device memory inside the graph), pose-lr warm-up bookkeeping.
+    switch = 11: the accumulation period drops from 8 to 1 at iteration it0 + 11, which is not a multiple of
+    8 -- three iterations' partial pose-gradient sum is pending at the switch and must enter the first single step on both paths.
     Run in JT_DETERMINISTIC mode, where neither path has order-dependent sums: every loss term of every iteration and
     every parameter after 20 iterations must be EXACTLY equal between the eager loop and the hipGraph-replayed one
     (in the default mode the two drift apart like two eager runs do: Adam turns atomics-order noise in a near-zero
@@ -263,6 +265,8 @@ def test_graph_replay_of_llff_iterations_is_bit_identical_to_eager(it0):
     try:
         for use_graph in (False, True):
             opt, model, var0 = _build_llff(it0)
+            if switch:
+                opt.train_schedule.change_n_AccumPoseGrad_after_n_iters = it0 + switch
             np.random.seed(5)
             torch.manual_seed(123)   # the coin stream
             stepper = GraphedTrainStep(model, min_repeats=0) if use_graph else None
@@ -289,7 +293,7 @@ def test_graph_replay_of_llff_iterations_is_bit_identical_to_eager(it0):
     assert stats["replayed"] >= K - 8 and stats["captured"] >= 2, stats
     assert r_e == r_g and tv_e == tv_g and tv_e[0] > tv_e[-1] > 0   # same coin stream consumed, TV weights decaying
     if it0 < 20000:  # the first half of the run: pose steps every 8th iteration, the near plane on its way down
-        assert int(opt.optim.pose_grad_accum_iter) == 8 and 0.0 < float(opt.nerf.depth.range[0]) < 0.4
+        assert int(opt.optim.pose_grad_accum_iter) == (1 if switch else 8) and 0.0 < float(opt.nerf.depth.range[0]) < 0.4
     np.testing.assert_array_equal(l_g, l_e)
     for k in sd_e:
         assert torch.equal(sd_e[k], sd_g[k]), k
