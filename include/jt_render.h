@@ -404,6 +404,11 @@ int jt_loss_sum_backward(const float* g_total, float w_render, float w_l1, float
  * the host schedule changes the weights every iteration (LLFF: the TV weights decay per iteration, model/tensorf.py:441-447);
  * the caller rewrites w4 with jt_poke in front of a replay. */
 int jt_loss_sum_forward_dyn(const float* render, const float* reg3, const float* w4, float* total, void* stream);
+/* jt_loss_sum_forward (w4_host: the four weights as host floats) or _dyn (w4_dev, used when w4_host is NULL) AND
+ * jt_finite_check of `items` in ONE launch; the total itself is checked as well and reports `loss_bit`. */
+int jt_loss_sum_check_forward(const float* render, const float* reg3, const float* w4_host, const float* w4_dev,
+                              float* total, const JtFiniteItem* items, int n_items, int32_t loss_bit,
+                              int32_t* status_word, void* stream);
 int jt_loss_sum_backward_dyn(const float* g_total, const float* w4, float* g_render, float* g_reg3, void* stream);
 
 /* All regularisers of one scene in one call (replaces the loop bodies of model/tensorf.py:127-130):
@@ -446,6 +451,11 @@ int jt_adam_step(const JtAdamItem* items, int n_items, float beta1, float beta2,
  * iteration is captured, joint_tensorf_amd/graphed.py) is replayed with new coefficients written by jt_poke. */
 int jt_adam_step_dyn(const JtAdamItem* items, int n_items, float beta1, float beta2, float eps, const float* dyn,
                      void* stream);
+/* The same step with the SAME two coefficients per item given as floats in HOST memory (coefs_host[2 i], [2 i + 1]; the
+ * lr / bias_correction fields are ignored): they travel as launch arguments.  An eager iteration steps with exactly the
+ * float values a replayed one reads from `dyn`, without the jt_poke launch in front. */
+int jt_adam_step_coefs(const JtAdamItem* items, int n_items, float beta1, float beta2, float eps,
+                       const float* coefs_host, void* stream);
 
 /* Write n_words (1..256) 32-bit words from HOST memory `words` to device memory `dst` on `stream`: the values
  * travel as launch arguments (no host staging buffer, no synchronisation, the host array may be reused at once).

@@ -113,11 +113,13 @@ SIGNATURES = {
     "jt_loss_sum_forward": (I, [P, P, F, F, F, F, P, P]),
     "jt_loss_sum_backward": (I, [P, F, F, F, F, P, P, P]),
     "jt_loss_sum_forward_dyn": (I, [P, P, P, P, P]),
+    "jt_loss_sum_check_forward": (I, [P, P, P, P, P, P, I, I, P, P]),
     "jt_loss_sum_backward_dyn": (I, [P, P, P, P, P]),
     "jt_reg_losses_forward": (I, [FP, P, I, I, I, I, P, P, P]),
     "jt_reg_losses_backward": (I, [FP, P, I, I, P, I, I, FP, I, P, P]),
     "jt_adam_step": (I, [P, I, F, F, F, P]),
     "jt_adam_step_dyn": (I, [P, I, F, F, F, P, P]),
+    "jt_adam_step_coefs": (I, [P, I, F, F, F, P, P]),
     "jt_poke": (I, [P, P, I, P]),
     "jt_dense_alpha": (I, [SP, FP, P, ctypes.c_long, F, P, P]),
     "jt_blur_batch_forward": (I, [P, I, P]),

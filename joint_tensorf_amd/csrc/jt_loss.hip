@@ -456,6 +456,63 @@ __global__ __launch_bounds__(256) void k_finite_check(FiniteArgs A, int32_t* __r
   }
 }
 
+// the loss head's tail in ONE launch: total = w . (render, reg3) as k_loss_sum_fwd / _dyn computes it, the finiteness of that
+// total (loss_bit), and the finiteness of the listed tensors (pose, colours) -- two launches of ~4.5 us each before
+__global__ __launch_bounds__(256) void k_loss_sum_check(const float* __restrict__ render, const float* __restrict__ reg3,
+                                                        float wr, float w0, float w1, float w2,
+                                                        const float* __restrict__ w4, float* __restrict__ out,
+                                                        FiniteArgs A, int32_t* __restrict__ flag, int loss_bit) {
+  int bits = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (w4) wr = w4[0], w0 = w4[1], w1 = w4[2], w2 = w4[3];
+    float t = 0.f;
+    if (wr != 0.f) t += wr * render[0];
+    t += w0 * reg3[0];
+    if (w1 != 0.f) t += w1 * reg3[1];
+    if (w2 != 0.f) t += w2 * reg3[2];
+    out[0] = t;
+    if (!(fabsf(t) <= 3.402823466e38f)) bits |= loss_bit;
+  }
+  for (int k = 0; k < A.count; ++k) {
+    const float* p = A.p[k];
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < A.n[k]; i += (long)gridDim.x * blockDim.x) {
+      const float v = p[i];
+      if (!(fabsf(v) <= 3.402823466e38f)) bits |= A.bit[k];
+    }
+  }
+  if (__any(bits != 0)) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) bits |= __shfl_xor(bits, o);
+    if ((threadIdx.x & 63) == 0) atomicOr(flag, bits);
+  }
+}
+
+extern "C" int jt_loss_sum_check_forward(const float* render, const float* reg3, const float* w4_host,
+                                         const float* w4_dev, float* total, const JtFiniteItem* items, int n_items,
+                                         int32_t loss_bit, int32_t* status_word, void* stream) {
+  if (!render || !reg3 || !total || !status_word || (!w4_host && !w4_dev) || n_items < 0 || n_items > JT_FINITE_MAX ||
+      (n_items > 0 && !items))
+    return JT_ERR_ARG;
+  FiniteArgs A;
+  long most = 1;
+  for (int k = 0; k < n_items; ++k) {
+    if (!items[k].data || items[k].n < 0) return JT_ERR_ARG;
+    A.p[k] = items[k].data;
+    A.n[k] = items[k].n;
+    A.bit[k] = items[k].bit;
+    most = std::max(most, (long)items[k].n);
+  }
+  A.count = n_items;
+  const int blocks = (int)std::min<long>((most + 255) / 256, 256);
+  const float z = 0.f;
+  const float* w = w4_host ? w4_host : &z;
+  hipLaunchKernelGGL(k_loss_sum_check, dim3(std::max(blocks, 1)), dim3(256), 0, (hipStream_t)stream, render, reg3,
+                     w4_host ? w[0] : 0.f, w4_host ? w[1] : 0.f, w4_host ? w[2] : 0.f, w4_host ? w[3] : 0.f, w4_dev, total, A,
+                     status_word, (int)loss_bit);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
 extern "C" int jt_finite_check(const JtFiniteItem* items, int n_items, int32_t* status_word, void* stream) {
   if (!items || !status_word || n_items < 1 || n_items > JT_FINITE_MAX) return JT_ERR_ARG;
   FiniteArgs A;

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_adam_batch(AdamBatch B) {
 using namespace jt;
 
 static int adam_launch(const JtAdamItem* items, int n_items, float beta1, float beta2, float eps, const float* dyn,
-                       void* stream) {
+                       void* stream, const float* coefs_host = nullptr) {
   if (!items || n_items < 1) return JT_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   for (int first = 0; first < n_items; first += kAdamMaxItems) {
@@ -124,7 +124,7 @@ static int adam_launch(const JtAdamItem* items, int n_items, float beta1, float 
     for (int i = 0; i < B.n; ++i) {
       const JtAdamItem& s = items[first + i];
       if (!s.p || !s.g || !s.m || !s.v || s.n < 1) return JT_ERR_ARG;
-      if (!dyn && (!(s.bias_correction1 > 0.f) || !(s.bias_correction2 > 0.f))) return JT_ERR_ARG;
+      if (!dyn && !coefs_host && (!(s.bias_correction1 > 0.f) || !(s.bias_correction2 > 0.f))) return JT_ERR_ARG;
       if ((((uintptr_t)s.p | (uintptr_t)s.g | (uintptr_t)s.m | (uintptr_t)s.v) & 15) != 0) return JT_ERR_UNSUPPORTED;
       AdamItemDev& d = B.t[i];
       d.p = s.p;
@@ -132,8 +132,8 @@ static int adam_launch(const JtAdamItem* items, int n_items, float beta1, float 
       d.m = s.m;
       d.v = s.v;
       d.n = s.n;
-      d.step_size = dyn ? 0.f : s.lr / s.bias_correction1;
-      d.inv_bc2_sqrt = dyn ? 0.f : 1.f / sqrtf(s.bias_correction2);
+      d.step_size = dyn ? 0.f : coefs_host ? coefs_host[2 * (first + i)] : s.lr / s.bias_correction1;
+      d.inv_bc2_sqrt = dyn ? 0.f : coefs_host ? coefs_host[2 * (first + i) + 1] : 1.f / sqrtf(s.bias_correction2);
       d.block0 = blocks;
       blocks += (int)((s.n + kAdamElemsPerBlock - 1) / kAdamElemsPerBlock);
     }
@@ -151,6 +151,12 @@ extern "C" int jt_adam_step_dyn(const JtAdamItem* items, int n_items, float beta
                                 const float* dyn, void* stream) {
   if (!dyn) return JT_ERR_ARG;
   return adam_launch(items, n_items, beta1, beta2, eps, dyn, stream);
+}
+
+extern "C" int jt_adam_step_coefs(const JtAdamItem* items, int n_items, float beta1, float beta2, float eps,
+                                  const float* coefs_host, void* stream) {
+  if (!coefs_host) return JT_ERR_ARG;
+  return adam_launch(items, n_items, beta1, beta2, eps, nullptr, stream, coefs_host);
 }
 
 extern "C" int jt_poke(void* dst, const uint32_t* words, int n_words, void* stream) {

@@ -410,13 +410,19 @@ class GraphedTrainStep:
         # 0.07-0.1 ms (measured, dense and sparse scene)
         aux_was = ops.USE_AUX_STREAM
         ops.USE_AUX_STREAM = aux_was and os.environ.get("JT_GRAPH_AUX", "0") == "1"
+        # dL/dtotal = the model's cached ones tensor (created BEFORE the capture): no fill in the graph, and the weighted sum's
+        # backward hands the device-resident weights on as they are (ops.LossSumDyn)
+        seed = m._backward_seed(torch.empty((), device=opt.device, dtype=torch.float32))
+        # the optimizer's coefficient buffer must exist BEFORE the capture as well (eager steps hand their coefficients over as
+        # launch arguments and never create it): allocated inside, its zero fill would be replayed behind every poke
+        m.optim._dyn_buffer(torch.device(opt.device), sum(len(gr["params"]) for gr in m.optim.param_groups))
         try:
             def body():
                 with stateless._reparametrize_module(g, subs):
                     v = g.forward(opt, Opt(dict(var)), mode="train")
                     loss = g.compute_loss(opt, v, mode="train")
                     loss = m.summarize_loss(opt, v, loss)
-                    grads = torch.autograd.grad(loss.all, list(subs.values()), allow_unused=True)
+                    grads = torch.autograd.grad(loss.all, list(subs.values()), grad_outputs=[seed], allow_unused=True)
                 for (_, p), gr in zip(named, grads):
                     p.grad = gr
                 m.optim.launch_step()

@@ -13,6 +13,7 @@ only, sampling, interpolation, MLP, compositing and their backward are HIP kerne
 Logging / visualisation / dataset loading of the reference engine are out of scope.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -569,9 +570,14 @@ class Model(torch.nn.Module):
         def register(o):
             self.optim = o
         nerf.register_new_optimizer = register
-        algo = getattr(torch.optim, opt.optim.pose_algo)
-        kw = dict(fused=True) if (opt.optim.pose_algo == "Adam" and str(opt.device).startswith("cuda")) else {}
-        self.optim_pose = algo([dict(params=self.graph.se3_refine.parameters(), lr=opt.optim.lr_pose)], **kw)
+        if opt.optim.pose_algo == "Adam" and str(opt.device).startswith("cuda"):
+            # the pose step through the same one-launch kernel as the factors' (torch's fused Adam is two: the device-side
+            # step counter, then the update); Adam's defaults, Adam's state keys (optim.VMAdam)
+            from ..optim import VMAdam
+            self.optim_pose = VMAdam([dict(params=self.graph.se3_refine.parameters(), lr=opt.optim.lr_pose)])
+        else:
+            algo = getattr(torch.optim, opt.optim.pose_algo)
+            self.optim_pose = algo([dict(params=self.graph.se3_refine.parameters(), lr=opt.optim.lr_pose)])
         self.sched_pose = None
         if opt.optim.sched_pose:
             assert opt.optim.sched_pose.type == "ExponentialLR"
@@ -621,13 +627,14 @@ class Model(torch.nn.Module):
         total = 0.0
         # ray-sharded data parallelism: only the photometric term is a mean over the (global) ray batch
         render_scale = float(var.get("dp_render_scale", None) or getattr(self, "render_loss_scale", 1.0))
-        fused = self._summarize_fused(opt, loss, render_scale)
+        # device-side guard: NaN pose / render / loss leave a bit in the status word (read by check_finite) -- in the launch
+        # that forms the weighted sum
+        guard = None
+        if not (_has(opt, "finite_checks") and not opt.finite_checks):
+            guard = [(var.get("current_pose"), ops.FINITE_POSE), (var.get("rgb"), ops.FINITE_RENDER)]
+        fused = self._summarize_fused(opt, loss, render_scale, guard)
         if fused is not None:
             loss.update(all=fused)
-            if not (_has(opt, "finite_checks") and not opt.finite_checks):
-                # device-side guard: NaN pose / render / loss leave a bit in the status word (read by check_finite)
-                ops.finite_check([(var.get("current_pose"), ops.FINITE_POSE), (var.get("rgb"), ops.FINITE_RENDER),
-                                  (fused, ops.FINITE_LOSS)])
             return loss
         for key in loss:
             assert key in opt.loss_weight, f"loss {key} not in opt.loss_weight"
@@ -646,7 +653,7 @@ class Model(torch.nn.Module):
         loss.update(all=total)
         return loss
 
-    def _summarize_fused(self, opt, loss, render_scale):
+    def _summarize_fused(self, opt, loss, render_scale, guard=None):
         """The same weighted sum, same order of terms, as ONE launch each way (ops.loss_sum) when the terms are the
         four of the BAT yamls and live on the GPU; None otherwise (the generic loop below then does it)."""
         keys = list(loss.keys())
@@ -659,7 +666,8 @@ class Model(torch.nn.Module):
             if key == "all" or (opt.loss_weight[key] is not None and float(opt.loss_weight[key]) != 0.0):
                 return None
         tf = self.graph.nerf.tensorf
-        return ops.loss_sum(loss.render, tf._reg(), *self.fused_loss_weights(opt, render_scale))
+        return ops.loss_sum(loss.render, tf._reg(), *self.fused_loss_weights(opt, render_scale), check_items=guard,
+                            loss_bit=ops.FINITE_LOSS if guard is not None else 0)
 
     def fused_loss_weights(self, opt, render_scale=None):
         """(w_render, w_L1, w_TV_density, w_TV_color) of this iteration's weighted loss sum (model/tensorf.py:31-47)"""
@@ -769,7 +777,7 @@ class Model(torch.nn.Module):
         key = (t.shape, t.dtype, str(t.device))
         memo = self.__dict__.setdefault("_seed_memo", {})
         if key not in memo:
-            memo[key] = torch.ones_like(t)
+            memo[key] = ops.register_unit_seed(torch.ones_like(t))
         return memo[key]
 
     def after_iteration(self, opt, it=None):

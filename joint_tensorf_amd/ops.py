@@ -924,29 +924,64 @@ def reg_losses(density_plane, density_line, app_plane, app_line, with_tv_density
     return RegLosses.apply(with_tv_density, with_tv_app, *density_plane, *density_line, *app_plane, *app_line)
 
 
+# Upstream gradients known to be exactly 1.0 (Model._backward_seed registers its cached ones tensors here): the backward of the
+# weighted loss sum is then the weights themselves, and the launch that multiplies them by 1.0 can be skipped
+UNIT_SEEDS = {}
+
+
+def register_unit_seed(t):
+    UNIT_SEEDS[id(t)] = t
+    return t
+
+
+def _finite_items(check_items):
+    items = [(t.detach(), b) for t, b in (check_items or ()) if t is not None and t.numel() > 0]
+    keep = [t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float() for t, _ in items]
+    arr = (_lib.JtFiniteItem * max(len(items), 1))()
+    for k, (t, (_, b)) in enumerate(zip(keep, items)):
+        arr[k].data, arr[k].n, arr[k].bit = ptr(t), t.numel(), int(b)
+    return arr, len(items), keep
+
+
 class LossSum(torch.autograd.Function):
     """total = w_render * render + (w_l1, w_tv_density, w_tv_color) . reg3 (Model.summarize_loss,
     model/tensorf.py:31-47) in one launch each way; as stock ops the same sum is a multiply and an add per term
-    plus a select-backward (fill + copy) per regulariser -- twenty launches of a few microseconds each."""
+    plus a select-backward (fill + copy) per regulariser -- twenty launches of a few microseconds each.
+    check_items / loss_bit: the iteration's finiteness guard (finite_check) rides in the same launch."""
+
+    _last = None   # (weights, g_render, g_reg) of the previous unit-seed backward: reused while the weights stay the same
 
     @staticmethod
-    def forward(ctx, render, reg3, w_render, w_l1, w_tvd, w_tvc):
+    def forward(ctx, render, reg3, w_render, w_l1, w_tvd, w_tvc, check_items=None, loss_bit=0):
         r = render.detach().reshape(1).float()
         q = reg3.detach().contiguous().float()
         out = torch.empty(1, device=r.device, dtype=torch.float32)
-        check(lib.jt_loss_sum_forward(ptr(r), ptr(q), w_render, w_l1, w_tvd, w_tvc, ptr(out), _stream()),
-              "jt_loss_sum_forward")
+        if check_items is not None:
+            arr, n, keep = _finite_items(check_items)
+            w = (ctypes.c_float * 4)(w_render, w_l1, w_tvd, w_tvc)
+            check(lib.jt_loss_sum_check_forward(ptr(r), ptr(q), w, None, ptr(out), arr, n, int(loss_bit),
+                                                ptr(status_word(r.device)), _stream()), "jt_loss_sum_check_forward")
+        else:
+            check(lib.jt_loss_sum_forward(ptr(r), ptr(q), w_render, w_l1, w_tvd, w_tvc, ptr(out), _stream()),
+                  "jt_loss_sum_forward")
         ctx.w = (float(w_render), float(w_l1), float(w_tvd), float(w_tvc))
         ctx.render_shape = render.shape
         return out[0]
 
     @staticmethod
     def backward(ctx, g):
+        last = LossSum._last
+        unit = id(g) in UNIT_SEEDS and UNIT_SEEDS[id(g)] is g
+        if unit and last is not None and last[0] == (ctx.w, str(g.device)):
+            # dL/dtotal is the cached ones tensor and the weights are last iteration's: so are the products
+            return last[1].reshape(ctx.render_shape), last[2], None, None, None, None, None, None
         gc = g.contiguous().float().reshape(1)
         g_render = torch.empty(1, device=gc.device, dtype=torch.float32)
         g_reg = torch.empty(3, device=gc.device, dtype=torch.float32)
         check(lib.jt_loss_sum_backward(ptr(gc), *ctx.w, ptr(g_render), ptr(g_reg), _stream()), "jt_loss_sum_backward")
-        return g_render.reshape(ctx.render_shape), g_reg, None, None, None, None
+        if unit and not torch.cuda.is_current_stream_capturing():
+            LossSum._last = ((ctx.w, str(g.device)), g_render, g_reg)
+        return g_render.reshape(ctx.render_shape), g_reg, None, None, None, None, None, None
 
 
 def tv_depth_value(depth, n_views, grid_h, grid_w):
@@ -964,33 +999,43 @@ class LossSumDyn(torch.autograd.Function):
     launch arguments of a captured hipGraph stay the same while the host schedule changes the weights."""
 
     @staticmethod
-    def forward(ctx, render, reg3, w4):
+    def forward(ctx, render, reg3, w4, check_items=None, loss_bit=0):
         r = render.detach().reshape(1).float()
         q = reg3.detach().contiguous().float()
         out = torch.empty(1, device=r.device, dtype=torch.float32)
-        check(lib.jt_loss_sum_forward_dyn(ptr(r), ptr(q), ptr(w4), ptr(out), _stream()), "jt_loss_sum_forward_dyn")
+        if check_items is not None:
+            arr, n, keep = _finite_items(check_items)
+            check(lib.jt_loss_sum_check_forward(ptr(r), ptr(q), None, ptr(w4), ptr(out), arr, n, int(loss_bit),
+                                                ptr(status_word(r.device)), _stream()), "jt_loss_sum_check_forward")
+        else:
+            check(lib.jt_loss_sum_forward_dyn(ptr(r), ptr(q), ptr(w4), ptr(out), _stream()), "jt_loss_sum_forward_dyn")
         ctx.w4 = w4
         ctx.render_shape = render.shape
         return out[0]
 
     @staticmethod
     def backward(ctx, g):
+        if id(g) in UNIT_SEEDS and UNIT_SEEDS[id(g)] is g:
+            # dL/dtotal is the cached ones tensor: the gradients ARE the weights, which the consumers read from device memory
+            return ctx.w4[0:1].reshape(ctx.render_shape), ctx.w4[1:4], None, None, None
         gc = g.contiguous().float().reshape(1)
         g_render = torch.empty(1, device=gc.device, dtype=torch.float32)
         g_reg = torch.empty(3, device=gc.device, dtype=torch.float32)
         check(lib.jt_loss_sum_backward_dyn(ptr(gc), ptr(ctx.w4), ptr(g_render), ptr(g_reg), _stream()),
               "jt_loss_sum_backward_dyn")
-        return g_render.reshape(ctx.render_shape), g_reg, None
+        return g_render.reshape(ctx.render_shape), g_reg, None, None, None
 
 
 # While this is a device tensor [4] (set by graphed.GraphedTrainStep around a capture), loss_sum reads its weights from it
 LOSS_WEIGHTS_STATIC = None
 
 
-def loss_sum(render, reg3, w_render, w_l1, w_tv_density, w_tv_color):
+def loss_sum(render, reg3, w_render, w_l1, w_tv_density, w_tv_color, check_items=None, loss_bit=0):
+    """check_items = [(tensor, status bit)] (+ loss_bit for the total itself): the finiteness guard in the same launch"""
     if LOSS_WEIGHTS_STATIC is not None:
-        return LossSumDyn.apply(render, reg3, LOSS_WEIGHTS_STATIC)
-    return LossSum.apply(render, reg3, float(w_render), float(w_l1), float(w_tv_density), float(w_tv_color))
+        return LossSumDyn.apply(render, reg3, LOSS_WEIGHTS_STATIC, check_items, loss_bit)
+    return LossSum.apply(render, reg3, float(w_render), float(w_l1), float(w_tv_density), float(w_tv_color), check_items,
+                         loss_bit)
 
 
 # While this is a device tensor int64[2] (set by graphed.GraphedTrainStep around a capture), render_loss reads the
@@ -1080,6 +1125,28 @@ def train_pose(se3, noise, gt):
     return TrainPose.apply(se3, noise, gt)
 
 
+_CONTIG_MEMO = {}
+
+
+def _contig_cached(t):
+    """t.detach().contiguous().float() for the small per-dataset constants (intrinsics and their inverses: torch's batched
+    inverse hands back column-major matrices, so `.contiguous()` on it was a copy launch in EVERY iteration), remembered per
+    source tensor (identity, version, layout); the source is kept alive with its copy so that an address cannot be reused."""
+    if t is None:
+        return None
+    if t.is_contiguous() and t.dtype == torch.float32:
+        return t.detach()
+    if torch.is_grad_enabled() and t.requires_grad:
+        return t.detach().contiguous().float()
+    key = (id(t), t.data_ptr(), t._version, tuple(t.stride()), tuple(t.shape), t.dtype)
+    hit = _CONTIG_MEMO.get(key)
+    if hit is None:
+        if len(_CONTIG_MEMO) >= 64:
+            _CONTIG_MEMO.clear()
+        hit = _CONTIG_MEMO[key] = (t, t.detach().contiguous().float())
+    return hit[1]
+
+
 class RayGen(torch.autograd.Function):
     """rays for the sampled pixel lattice only (camera.py:231-261 + 303-340)."""
 
@@ -1087,8 +1154,8 @@ class RayGen(torch.autograd.Function):
     def forward(ctx, pose, intr_inv, intr, ray_idx, image_w, ndc, ndc_near):
         pose_c = pose.detach().contiguous().float()
         B = pose_c.shape[0]
-        ki = intr_inv.detach().contiguous().float()
-        k = None if intr is None else intr.detach().contiguous().float()
+        ki = _contig_cached(intr_inv)
+        k = _contig_cached(intr)
         idx = ray_idx.detach().contiguous().to(torch.int64)
         r = idx.numel()
         o = torch.empty(B, r, 3, device=pose_c.device, dtype=torch.float32)
@@ -1122,8 +1189,8 @@ class RayGenRagged(torch.autograd.Function):
     def forward(ctx, pose, intr_inv, intr, ray_idx, view_offset, image_w, ndc, ndc_near):
         pose_c = pose.detach().contiguous().float()
         V = pose_c.shape[0]
-        ki = intr_inv.detach().contiguous().float()
-        k = None if intr is None else intr.detach().contiguous().float()
+        ki = _contig_cached(intr_inv)
+        k = _contig_cached(intr)
         idx = ray_idx.detach().contiguous().to(torch.int64)
         voff = view_offset.detach().contiguous().to(torch.int32)
         n = idx.numel()

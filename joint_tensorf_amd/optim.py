@@ -74,10 +74,12 @@ class VMAdam(torch.optim.Optimizer):
         return d[key]
 
     @torch.no_grad()
-    def prepare_step(self, params_with_grad=None):
+    def prepare_step(self, params_with_grad=None, poke=True):
         """Advance the step counters and write this iteration's (lr / bias_correction1, 1 / sqrt(bias_correction2))
-        of every tensor to the device.  `params_with_grad`: the ids of the parameters the following launch will step (default:
-        those that have a .grad now); the order must be the one `launch_step` sees."""
+        of every tensor to the device (poke=True: one jt_poke, for a launch that reads them from device memory -- a captured
+        hipGraph) or just return them (poke=False: the eager step hands them to the launch as arguments).
+        `params_with_grad`: the ids of the parameters the following launch will step (default: those that have a .grad now);
+        the order must be the one `launch_step` sees."""
         coefs = []
         dev = None
         for group in self.param_groups:
@@ -101,17 +103,22 @@ class VMAdam(torch.optim.Optimizer):
                 coefs.append(float(group["lr"]) / (1.0 - b1 ** t))
                 coefs.append(1.0 / math.sqrt(1.0 - b2 ** t))
         if not coefs:
-            return
+            return coefs
         if len({(float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])) for g in self.param_groups}) != 1:
             raise RuntimeError("VMAdam: one (betas, eps) combination per optimizer (the reference uses a single one)")
-        from .ops import poke_floats
+        # (the buffer exists from the first step on, poked or not: a hipGraph capture that meets launch_step() must find it --
+        #  allocated inside the capture, its zero fill would be replayed behind every poke)
         dyn = self._dyn_buffer(dev, len(coefs) // 2)
-        for lo in range(0, len(coefs), 256):
-            poke_floats(dyn, coefs[lo:lo + 256], offset=lo)
+        if poke:
+            from .ops import poke_floats
+            for lo in range(0, len(coefs), 256):
+                poke_floats(dyn, coefs[lo:lo + 256], offset=lo)
+        return coefs
 
     @torch.no_grad()
-    def launch_step(self):
-        """One launch over all parameter tensors that have a gradient (coefficients from `prepare_step`)."""
+    def launch_step(self, coefs=None):
+        """One launch over all parameter tensors that have a gradient.  coefs = None: the coefficients `prepare_step` poked
+        into device memory; a list: the same values as launch arguments (same floats, same arithmetic in the kernel)."""
         keep = []
         stream = _stream()
         for (b1, b2, eps), plist in self._items().items():
@@ -130,8 +137,13 @@ class VMAdam(torch.optim.Optimizer):
                 m, v = st["exp_avg"], st["exp_avg_sq"]
                 assert self._layout_ok(m, p) and self._layout_ok(v, p)
                 arr[k].p, arr[k].g, arr[k].m, arr[k].v, arr[k].n = ptr(p), ptr(g), ptr(m), ptr(v), p.numel()
-            dyn = self._dyn_buffer(plist[0][0].device, len(plist))
-            check(lib.jt_adam_step_dyn(arr, len(plist), b1, b2, eps, ptr(dyn), stream), "jt_adam_step_dyn")
+            if coefs is not None:
+                import ctypes
+                host = (ctypes.c_float * len(coefs))(*coefs)
+                check(lib.jt_adam_step_coefs(arr, len(plist), b1, b2, eps, host, stream), "jt_adam_step_coefs")
+            else:
+                dyn = self._dyn_buffer(plist[0][0].device, len(plist))
+                check(lib.jt_adam_step_dyn(arr, len(plist), b1, b2, eps, ptr(dyn), stream), "jt_adam_step_dyn")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -139,6 +151,7 @@ class VMAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        self.prepare_step()
-        self.launch_step()
+        coefs = self.prepare_step(poke=False)
+        if coefs:
+            self.launch_step(coefs)
         return loss

@@ -58,7 +58,7 @@ def make_views(opt, n_views, seed=0, device="cpu", with_images=True):
     pose = torch.tensor(np.stack(poses))
     intr = torch.tensor([[f, 0, W / 2], [0, f, H / 2], [0, 0, 1]], dtype=torch.float32)[None].repeat(n_views, 1, 1)
     var = Opt(idx=torch.arange(n_views, device=device), pose=pose.to(device), intr=intr.to(device),
-              intr_inv=intr.inverse().to(device))
+              intr_inv=intr.inverse().contiguous().to(device))
     if with_images:
         g = torch.Generator().manual_seed(seed + 1)
         var.image = torch.rand(n_views, 3, H, W, generator=g).to(device)

@@ -16,8 +16,8 @@ for f in glob.glob("$O/r4_order/*memory_copy_trace.csv"):
 rows.sort()
 # last iteration = from the last k_pose_fwd... print the tail 75 entries
 names=[r[2] for r in rows]
-idx=[i for i,n in enumerate(names) if "k_adam_batch" in n]
-start=idx[-2]+1 if len(idx)>=2 else 0
+idx=[i for i,n in enumerate(names) if "k_pose_fwd" in n]   # an iteration starts with the pose composition
+start=idx[-1] if idx else 0
 prev=None
 for s,e,n in rows[start:]:
     gap = (s-prev)/1000 if prev else 0
