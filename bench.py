@@ -397,6 +397,13 @@ def pmc_traffic_instep(roof, hidden=None):
             out["launches_per_step_profiled"] = busy["launches_per_step_profiled"]
         except Exception:
             pass
+        try:
+            # ... and of ONE steady-state iteration, counted in the ordered trace of the same command (tools/profile_cmd.sh):
+            # the figure above divides ALL launches of the process (data-set upload, parameter / moment fills, priming) by the steps
+            lp = json.load(open(os.path.join(ROOT, "profiles", tag + "_default_launches_per_iteration.json")))
+            out["launches_per_iteration"] = dict(lp, source="profiles/%s_default_launches_per_iteration.json" % tag)
+        except Exception:
+            pass
         if hidden:
             # the second bound of a scatter kernel: the chip retires ~20.9 G float-atomic 64-byte segments per second
             # whatever the access pattern (tools/atomic_rate.hip, profiles/round2_atomic_rate.txt).  Segments of a launch =

@@ -26,5 +26,22 @@ python3 tools/pmc_traffic_instep.py $O/${TAG}_pmc_FETCH_SIZE/p_counter_collectio
 fi
 head -16 $O/${TAG}_trace_summary.txt
 [ -z "$NO_PMC" ] && cat $O/${TAG}_pmc_traffic.json
+# launches of ONE iteration, from the ordered trace: iterations are delimited by k_pose_fwd (the first launch of a training
+# iteration); the per-kernel stats above also count the process's set-up (one upload per view of the image set, parameter and
+# moment fills) and its priming iterations
+python3 - > $O/${TAG}_launches_per_iteration.json <<PY
+import csv, glob, json, statistics
+rows = []
+for f in glob.glob("$O/${TAG}_trace/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+cuts = [i for i, (_, n) in enumerate(rows) if "k_pose_fwd" in n]
+per = [b - a for a, b in zip(cuts, cuts[1:])]
+tail = per[len(per) // 2:] or per or [0]
+print(json.dumps(dict(launches_per_iteration_median=statistics.median(tail), min=min(tail), max=max(tail), iterations=len(tail),
+                      all_launches_of_the_process=len(rows), delimiter="k_pose_fwd")))
+PY
+cat $O/${TAG}_launches_per_iteration.json
 rm -rf $O/${TAG}_trace/*kernel_trace.csv 2>/dev/null   # keep the merged-back set small: stats + pmc csvs stay
 true
