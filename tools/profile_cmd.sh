@@ -11,7 +11,9 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 export JT_TIME_WALK=1
 python3 $CMD > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -o k -- python3 $CMD > $O/${TAG}_trace.log 2>&1
+# (the trace without the in-step timing of the density walk: two launches per iteration that count its listed samples; bench.py
+#  still turns it on by itself for every configuration but the default one)
+JT_TIME_WALK=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -o k -- python3 $CMD > $O/${TAG}_trace.log 2>&1
 if [ -z "$NO_PMC" ]; then
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_FETCH_SIZE -o p -- python3 $CMD > $O/${TAG}_pmc_FETCH_SIZE.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_WRITE_SIZE -o p -- python3 $CMD > $O/${TAG}_pmc_WRITE_SIZE.log 2>&1
