@@ -188,7 +188,7 @@ def test_march_stage_vs_oracle(name):
         assert np.array_equal(sidx_np[r_, :len(want)], want)
 
 
-@pytest.mark.parametrize("shape", [(16, 14, 14), (48, 23, 17), (16, 33, 1)])
+@pytest.mark.parametrize("shape", [(16, 14, 14), (48, 23, 17), (16, 33, 1), (20, 45, 37), (16, 64, 5), (48, 32, 9)])  # H >= 32: the row-walking TV kernels
 def test_factor_reg_vs_oracle(shape):
     """fused L1 / TV sums and their gradient against the oracle's torch ops."""
     from joint_tensorf_amd import ops
