@@ -757,6 +757,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_shade_scatter(Dev D, MlpDev M, J
   }
 }
 
+}  // namespace jt (jt_tile.h opens its own)
+#include "jt_tile.h"
+namespace jt {
+
 // ---- weight gradients: dW[m][n] += sum_p A[p][m] * B[p][n],  db[m] += sum_p A[p][m] ------------------------
 // A skinny GEMM over the sample axis with v_mfma_f32_32x32x2_f32: the two lane halves take two consecutive
 // samples per step, lane & 31 is the unit index for both operands (coalesced 128-byte row reads).
@@ -1281,7 +1285,8 @@ extern "C" int jt_debug_read_stamps(unsigned long long* out8) {
 }
 #endif
 // Split appearance backward: 0 = one kernel (chain + scatter in k_shade_bwd), 8 / 16 = k_shade_bwd<SPLIT> + k_shade_scatter
-// with runs of that many samples per 16-lane group, -1 = per scene kind (the default): split 16 for the 20-channel WeakView
+// with runs of that many samples per 16-lane group, 1 = k_shade_bwd<SPLIT> + the TILE-OWNED scatter of jt_tile.h (pairs binned
+// by plane tile, gradient slices summed in LDS), -1 = per scene kind (the default): split 16 for the 20-channel WeakView
 // scene (bat_llff_VM_MLP: its line gradients, privatised in LDS by the scatter kernel, are 40 % of the fused kernel's time:
 // 0.49 -> 0.35 ms per launch), fused for VM-48 (profiles/round4_bwd_split_ablation.txt).  JT_BWD_SPLIT (read once) overrides.
 static std::atomic<int> g_bwd_split{-2};
@@ -1290,7 +1295,7 @@ static int bwd_split_mode() {
   if (m < -1) {
     const char* e = getenv("JT_BWD_SPLIT");
     m = e ? atoi(e) : -1;
-    if (m != 0 && m != 8 && m != 16) m = -1;
+    if (m != 0 && m != 1 && m != 8 && m != 16) m = -1;
     g_bwd_split.store(m, std::memory_order_relaxed);
   }
   return m;
@@ -1298,7 +1303,7 @@ static int bwd_split_mode() {
 extern "C" int jt_shade_bwd_split(void) { return bwd_split_mode(); }
 extern "C" int jt_shade_set_bwd_split(int run) {
   const int prev = bwd_split_mode();
-  if (run == -1 || run == 0 || run == 8 || run == 16) g_bwd_split.store(run, std::memory_order_relaxed);
+  if (run == -1 || run == 0 || run == 1 || run == 8 || run == 16) g_bwd_split.store(run, std::memory_order_relaxed);
   return prev;
 }
 extern "C" int jt_shade_chunk_entries(void) { return chunk_entries(); }
@@ -1332,6 +1337,10 @@ struct WsLayout {
   // they take what `cap` samples need, not whole chunks; the slabs follow
   static size_t rec_floats(int cap) { return (size_t)B::REC_FLOATS * (((size_t)std::max(cap, 1) + 31) / 32 * 32); }
   static size_t bytes(int cap) {
+    return main_bytes(cap) + tile_ws_bytes(cap, kChunkEntries);
+  }
+  // records + slabs; the tile-owned scatter's lists and counters (jt_tile.h) sit behind them
+  static size_t main_bytes(int cap) {
     const int nchunks = (cap + kChunkEntries - 1) / kChunkEntries;
     return (rec_floats(cap) + slab_floats_per_chunk() * (size_t)std::max(nchunks, 1)) * sizeof(float);
   }
@@ -1435,6 +1444,50 @@ extern "C" int jt_shade_forward(const JtScene* scene, const JtFactors* factors, 
                                    st);
 }
 
+// the tile-owned scatter's instantiations per scene kind: configuration 0 = tile values staged in LDS, 1 = larger tiles, the
+// plane taps gathered from memory (JT_TILE_CFG, read once)
+template <class C>
+struct TileSel {
+  // VM-48: 11 x 11 cells (12 x 12 texels: 27 KB slice + 27 KB values beside the 77 KB line) / 16 x 16 cells un-staged;
+  // the 20-channel scene (80-byte texels): 16 x 16 cells staged / 24 x 24 un-staged
+  static constexpr int TX0 = (C::CA >= 48) ? 11 : 16, TX1 = (C::CA >= 48) ? 16 : 24;
+  static constexpr int WAVES = 16;
+  typedef TileScatCfg<C, TX0, TX0, true, WAVES> Q0;
+  typedef TileScatCfg<C, TX1, TX1, false, WAVES> Q1;
+  static size_t lds_bytes(int cfg, int line_floats) { return cfg ? Q1::lds_bytes(line_floats) : Q0::lds_bytes(line_floats); }
+  static int tiles(int cfg, int H, int W) {
+    const int t = cfg ? TX1 : TX0;
+    return tiles_along(W, t) * tiles_along(H, t);
+  }
+  template <int CFG>
+  static int launch(const Dev& D, const MlpDev& M, const JtFactors& G, const TileWs& TW, const int32_t* offset, int R,
+                    float* g_xyz, const float* rc, int start, int ccap, int cap, int line_floats, hipStream_t st) {
+    constexpr int T = CFG ? TX1 : TX0;
+    constexpr bool STAGE = CFG == 0;
+    typedef TileScatCfg<C, T, T, STAGE, WAVES> Q;
+    int nt[3], ntmax = 1;
+    for (int a = 0; a < 3; ++a) nt[a] = tiles_along(D.pw[a], T) * tiles_along(D.ph[a], T), ntmax = std::max(ntmax, nt[a]);
+    const int nblk = (ccap + 255) / 256;
+    hipLaunchKernelGGL(k_tile_zero, dim3((ntmax + 255) / 256, 3), dim3(256), 0, st, TW, nt[0], nt[1], nt[2]);
+    hipLaunchKernelGGL((k_tile_bin<C, T, T, false>), dim3(nblk), dim3(256), 0, st, D, TW, offset, R, rc, start, ccap, cap);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, TW, nt[0], nt[1], nt[2]);
+    hipLaunchKernelGGL((k_tile_bin<C, T, T, true>), dim3(nblk), dim3(256), 0, st, D, TW, offset, R, rc, start, ccap, cap);
+    const size_t lds = Q::lds_bytes(line_floats);
+    static size_t attr = 0;
+    if (attr < lds) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_scatter<C, T, T, STAGE, WAVES>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return JT_ERR_UNSUPPORTED;
+      attr = lds;
+    }
+    static const int nwg = [] { const char* e = getenv("JT_TILE_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 255; }();
+    hipLaunchKernelGGL((k_tile_scatter<C, T, T, STAGE, WAVES>), dim3(nwg), dim3(WAVES * 64), lds, st, D, M, G, TW, rc,
+                       line_floats);
+    hipLaunchKernelGGL(k_tile_gxyz, dim3(nblk), dim3(256), 0, st, TW, offset, R, g_xyz, start, ccap, cap);
+    return JT_OK;
+  }
+};
+
 template <class C>
 static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, const JtFactors& G, const JtMlp& GM,
                             const int32_t* offset, int R, const float* rgb_s, const float* g_rgb_s, float* g_xyz,
@@ -1470,9 +1523,23 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   static const bool pipe = [] { const char* e = getenv("JT_WGRAD_PIPE"); return !e || atoi(e) != 0; }();
   hipStream_t ws_st = use_aux ? aux : st;
   const int RR = B::REC_FLOATS;
-  const int split = bwd_split_mode() >= 0 ? bwd_split_mode() : (C::CA < 48 ? 16 : 0);
+  int split = bwd_split_mode() >= 0 ? bwd_split_mode() : (C::CA < 48 ? 16 : 0);
   unsigned* bad = jt::fixed_bad_flag();
   if (!bad) return JT_ERR_ARG;
+  // tile-owned scatter (split == 1): needs factor gradients to write, float accumulation, a scene whose tiles and LDS line fit
+  // what the kernel and the workspace are sized for -- otherwise the scene kind's default takes over
+  typedef TileSel<C> TS;
+  int tile_line_floats = 0;
+  for (int a = 0; a < 3; ++a) tile_line_floats = std::max(tile_line_floats, D.ll[a] * C::CA);
+  static const int tile_cfg_env = [] { const char* e = getenv("JT_TILE_CFG"); return e ? atoi(e) : 0; }();
+  const int tile_cfg = (tile_cfg_env == 1) ? 1 : 0;
+  if (split == 1) {
+    bool ok = !det && G.app_plane[0] && G.app_line[0] && TS::lds_bytes(tile_cfg, tile_line_floats) <= 160 * 1024;
+    for (int a = 0; a < 3 && ok; ++a) ok = TS::tiles(tile_cfg, D.ph[a], D.pw[a]) <= kTileMaxTiles;
+    if (!ok) split = (C::CA < 48 ? 16 : 0);
+  }
+  const bool tile = (split == 1);
+  const TileWs TW = tile_ws_carve(reinterpret_cast<char*>(ws) + W::main_bytes(cap), cap, chunk);
   // fused: one kernel per chunk.  Split: the chain (launch_bwd) and the scatter (launch_scatter) -- the weight-gradient GEMMs only
   // need the chain's records, so they are forked BEHIND THE CHAIN and run next to the atomic-bound scatter.
   auto launch_bwd = [&](int ci) -> int {
@@ -1514,12 +1581,19 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   };
   static const int sw_env = [] { const char* e = getenv("JT_SCATTER_WAVES"); return e ? atoi(e) : 0; }();
   int sw = 8;
-  if (C::CA < 48 && split && (sw_env == 16 || (sw_env == 0 && scatter_lds(split, sflags, 16) <= 160 * 1024))) sw = 16;
-  if (split && scatter_lds(split, sflags, sw) > 160 * 1024) sflags &= ~1;  // a line too long for the LDS: global atomics as before
+  if (C::CA < 48 && split && !tile && (sw_env == 16 || (sw_env == 0 && scatter_lds(split, sflags, 16) <= 160 * 1024))) sw = 16;
+  if (split && !tile && scatter_lds(split, sflags, sw) > 160 * 1024) sflags &= ~1;  // a line too long for the LDS: global atomics as before
   auto launch_scatter = [&](int ci) -> int {
     if (!split || (ablate & 1)) return JT_OK;
     const int start = ci * chunk, ccap = std::min(chunk, cap - start);
     const float* rc = recs + W::rec_floats_per_chunk() * ci;
+    if (tile) {
+      int rc_ = (tile_cfg == 1) ? TS::template launch<1>(D, M, G, TW, offset, R, g_xyz, rc, start, ccap, cap, tile_line_floats, st)
+                                : TS::template launch<0>(D, M, G, TW, offset, R, g_xyz, rc, start, ccap, cap, tile_line_floats, st);
+      if (rc_) return rc_;
+      JT_LAUNCH_CHECK();
+      return JT_OK;
+    }
     const size_t lds_s = scatter_lds(split, sflags, sw);
 #define JT_SCATTER_LAUNCH(RUN_, DET_, FL_, SW_)                                                                         \
   {                                                                                                                     \
