@@ -1444,46 +1444,57 @@ extern "C" int jt_shade_forward(const JtScene* scene, const JtFactors* factors, 
                                    st);
 }
 
-// the tile-owned scatter's instantiations per scene kind: configuration 0 = tile values staged in LDS, 1 = larger tiles, the
-// plane taps gathered from memory (JT_TILE_CFG, read once)
+// the tile-owned scatter (jt_tile.h) per scene kind.  Configuration 0 (default): sixteen-wave workgroups; VM-48's three channel
+// groups form two classes (groups 0..1 | group 2) because a 400 x 48 line of doubles does not fit the LDS beside anything else.
+// Configuration 1 (JT_TILE_CFG=1, read once): one class, eight-wave workgroups with the whole line.
 template <class C>
 struct TileSel {
-  // VM-48: 11 x 11 cells (12 x 12 texels: 27 KB slice + 27 KB values beside the 77 KB line) / 16 x 16 cells un-staged;
-  // the 20-channel scene (80-byte texels): 16 x 16 cells staged / 24 x 24 un-staged
-  static constexpr int TX0 = (C::CA >= 48) ? 11 : 16, TX1 = (C::CA >= 48) ? 16 : 24;
-  static constexpr int WAVES = 16;
-  typedef TileScatCfg<C, TX0, TX0, true, WAVES> Q0;
-  typedef TileScatCfg<C, TX1, TX1, false, WAVES> Q1;
-  static size_t lds_bytes(int cfg, int line_floats) { return cfg ? Q1::lds_bytes(line_floats) : Q0::lds_bytes(line_floats); }
-  static int tiles(int cfg, int H, int W) {
-    const int t = cfg ? TX1 : TX0;
-    return tiles_along(W, t) * tiles_along(H, t);
-  }
+  static constexpr int NG = (C::CA + 15) / 16;
+  static constexpr int SPLIT0 = (NG >= 3) ? 2 : 0;
+  static int ch_max(int cfg) { return (cfg == 0 && SPLIT0) ? 16 * SPLIT0 : C::CA; }
+  static int waves(int cfg) { return cfg == 0 ? 16 : 8; }
+  static size_t lds_bytes(int cfg, int line_len) { return tile_lds_bytes(line_len, ch_max(cfg), waves(cfg)); }
+  static int tiles(int H, int W) { return tiles_along(W) * tiles_along(H); }
   template <int CFG>
   static int launch(const Dev& D, const MlpDev& M, const JtFactors& G, const TileWs& TW, const int32_t* offset, int R,
-                    float* g_xyz, const float* rc, int start, int ccap, int cap, int line_floats, hipStream_t st) {
-    constexpr int T = CFG ? TX1 : TX0;
-    constexpr bool STAGE = CFG == 0;
-    typedef TileScatCfg<C, T, T, STAGE, WAVES> Q;
+                    float* g_xyz, const float* rc, int start, int ccap, int cap, int line_len, hipStream_t st) {
+    constexpr int SPLIT = CFG == 0 ? SPLIT0 : 0;
+    constexpr int WAVES = CFG == 0 ? 16 : 8;
+    constexpr int NCLS = SPLIT ? 2 : 1;
     int nt[3], ntmax = 1;
-    for (int a = 0; a < 3; ++a) nt[a] = tiles_along(D.pw[a], T) * tiles_along(D.ph[a], T), ntmax = std::max(ntmax, nt[a]);
+    for (int a = 0; a < 3; ++a) nt[a] = tiles(D.ph[a], D.pw[a]), ntmax = std::max(ntmax, nt[a]);
     const int nblk = (ccap + 255) / 256;
     hipLaunchKernelGGL(k_tile_zero, dim3((ntmax + 255) / 256, 3), dim3(256), 0, st, TW, nt[0], nt[1], nt[2]);
-    hipLaunchKernelGGL((k_tile_bin<C, T, T, false>), dim3(nblk), dim3(256), 0, st, D, TW, offset, R, rc, start, ccap, cap);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, TW, nt[0], nt[1], nt[2]);
-    hipLaunchKernelGGL((k_tile_bin<C, T, T, true>), dim3(nblk), dim3(256), 0, st, D, TW, offset, R, rc, start, ccap, cap);
-    const size_t lds = Q::lds_bytes(line_floats);
+    hipLaunchKernelGGL((k_tile_bin<C, false>), dim3(nblk), dim3(256), 0, st, D, TW, offset, R, rc, start, ccap, cap);
+    hipLaunchKernelGGL(k_tile_scan, dim3(3), dim3(1024), 0, st, TW, nt[0], nt[1], nt[2]);
+    hipLaunchKernelGGL((k_tile_bin<C, true>), dim3(nblk), dim3(256), 0, st, D, TW, offset, R, rc, start, ccap, cap);
+    const size_t lds = lds_bytes(CFG, line_len);
     static size_t attr = 0;
     if (attr < lds) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_scatter<C, T, T, STAGE, WAVES>),
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_scatter<C, SPLIT, WAVES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return JT_ERR_UNSUPPORTED;
       attr = lds;
     }
-    static const int nwg = [] { const char* e = getenv("JT_TILE_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 255; }();
-    hipLaunchKernelGGL((k_tile_scatter<C, T, T, STAGE, WAVES>), dim3(nwg), dim3(WAVES * 64), lds, st, D, M, G, TW, rc,
-                       line_floats);
-    hipLaunchKernelGGL(k_tile_gxyz, dim3(nblk), dim3(256), 0, st, TW, offset, R, g_xyz, start, ccap, cap);
+    // workgroups: one per CU, dealt to the (plane, class) sets; a class of two channel groups gets JT_TILE_RATIO per cent of
+    // its plane's share (the per-pair set-up -- list entry, GF rows, tap records -- is the same for both classes)
+    static const int nwg = [] { const char* e = getenv("JT_TILE_WGS"); const int v = e ? atoi(e) : 0; return v >= 6 ? v : 256; }();
+    static const int ratio = [] { const char* e = getenv("JT_TILE_RATIO"); const int v = e ? atoi(e) : 0; return (v > 0 && v < 100) ? v : 62; }();
+    TileClasses TC;
+    int acc = 0;
+    for (int pl = 0; pl < 3; ++pl) {
+      const int share = nwg / 3 + (pl < nwg % 3 ? 1 : 0);
+      const int c0 = NCLS == 2 ? std::max(1, std::min(share - 1, share * ratio / 100)) : share;
+      TC.start[pl * NCLS] = acc;
+      acc += c0;
+      if (NCLS == 2) {
+        TC.start[pl * NCLS + 1] = acc;
+        acc += share - c0;
+      }
+    }
+    for (int k = 3 * NCLS; k <= kTileMaxClasses; ++k) TC.start[k] = acc;
+    hipLaunchKernelGGL((k_tile_scatter<C, SPLIT, WAVES>), dim3(acc), dim3(WAVES * 64), lds, st, D, M, G, TW, rc, TC);
+    hipLaunchKernelGGL(k_tile_gxyz, dim3(nblk), dim3(256), 0, st, TW, 3 * NCLS, offset, R, g_xyz, start, ccap, cap);
     return JT_OK;
   }
 };
@@ -1529,13 +1540,14 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   // tile-owned scatter (split == 1): needs factor gradients to write, float accumulation, a scene whose tiles and LDS line fit
   // what the kernel and the workspace are sized for -- otherwise the scene kind's default takes over
   typedef TileSel<C> TS;
-  int tile_line_floats = 0;
-  for (int a = 0; a < 3; ++a) tile_line_floats = std::max(tile_line_floats, D.ll[a] * C::CA);
+  int tile_line_len = 0;
+  for (int a = 0; a < 3; ++a) tile_line_len = std::max(tile_line_len, D.ll[a]);
   static const int tile_cfg_env = [] { const char* e = getenv("JT_TILE_CFG"); return e ? atoi(e) : 0; }();
-  const int tile_cfg = (tile_cfg_env == 1) ? 1 : 0;
+  int tile_cfg = (tile_cfg_env == 1) ? 1 : 0;
   if (split == 1) {
-    bool ok = !det && G.app_plane[0] && G.app_line[0] && TS::lds_bytes(tile_cfg, tile_line_floats) <= 160 * 1024;
-    for (int a = 0; a < 3 && ok; ++a) ok = TS::tiles(tile_cfg, D.ph[a], D.pw[a]) <= kTileMaxTiles;
+    if (TS::lds_bytes(tile_cfg, tile_line_len) > 160 * 1024) tile_cfg ^= 1;  // the other workgroup shape may still fit
+    bool ok = !det && G.app_plane[0] && G.app_line[0] && TS::lds_bytes(tile_cfg, tile_line_len) <= 160 * 1024;
+    for (int a = 0; a < 3 && ok; ++a) ok = TS::tiles(D.ph[a], D.pw[a]) <= kTileMaxTiles;
     if (!ok) split = (C::CA < 48 ? 16 : 0);
   }
   const bool tile = (split == 1);
@@ -1588,8 +1600,8 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     const int start = ci * chunk, ccap = std::min(chunk, cap - start);
     const float* rc = recs + W::rec_floats_per_chunk() * ci;
     if (tile) {
-      int rc_ = (tile_cfg == 1) ? TS::template launch<1>(D, M, G, TW, offset, R, g_xyz, rc, start, ccap, cap, tile_line_floats, st)
-                                : TS::template launch<0>(D, M, G, TW, offset, R, g_xyz, rc, start, ccap, cap, tile_line_floats, st);
+      int rc_ = (tile_cfg == 1) ? TS::template launch<1>(D, M, G, TW, offset, R, g_xyz, rc, start, ccap, cap, tile_line_len, st)
+                                : TS::template launch<0>(D, M, G, TW, offset, R, g_xyz, rc, start, ccap, cap, tile_line_len, st);
       if (rc_) return rc_;
       JT_LAUNCH_CHECK();
       return JT_OK;
