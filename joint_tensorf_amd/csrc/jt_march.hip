@@ -460,7 +460,7 @@ __device__ inline float sel3f(int i, float a, float b, float c) { return i == 0 
 constexpr int kWalkPrefixRays = 16384;
 // kWalkWaves = 16: one workgroup per CU (a long line: LLFF's 55 KB); 8: two per CU when their LDS fits twice (finer grains for
 // whatever runs beside the walk: the weight-gradient GEMMs on the auxiliary stream)
-template <int CD, bool DET, bool LLINE, int kWalkWaves>
+template <int CD, bool DET, int LLINE, int kWalkWaves>
 __global__ __launch_bounds__(kWalkWaves * 64) void k_march_bwd_walk(Dev D, JtFactors G, const float* __restrict__ rays_o,
                                                         const float* __restrict__ rays_d,
                                                         const float* __restrict__ jitter,
@@ -489,6 +489,7 @@ __global__ __launch_bounds__(kWalkWaves * 64) void k_march_bwd_walk(Dev D, JtFac
   // instead was twice as slow: one word serves ~88 returning atomics per microsecond, MI355X_MICROARCH.md "dequeue".)
   const int nblk = (int)gridDim.x;
   const int pl = (int)blockIdx.x % 3, pb = (int)blockIdx.x / 3, npeers = (nblk - pl + 2) / 3;
+  // (LLINE = 2: the line copy holds doubles, line_floats counts its 4-byte words)
   int* s_pre = reinterpret_cast<int*>(sline + (LLINE ? line_floats : 0));   // [R] inclusive prefix of ceil(nvalid / 128)
   int n_items = witems;
   if (prefix) {
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(kWalkWaves * 64) void k_march_bwd_walk(Dev D, JtFac
             LL = sel3(pl, D.ll[0], D.ll[1], D.ll[2]);
   float* gline = pl == 0 ? G.density_line[0] : (pl == 1 ? G.density_line[1] : G.density_line[2]);
   if (LLINE) {
-    for (int i = threadIdx.x; i < LL * CD; i += kWalkWaves * 64) sline[i] = 0.f;
+    for (int i = threadIdx.x; i < LL * CD * (LLINE == 2 ? 2 : 1); i += kWalkWaves * 64) sline[i] = 0.f;
     __syncthreads();
   }
 #pragma unroll 1
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(kWalkWaves * 64) void k_march_bwd_walk(Dev D, JtFac
     __syncthreads();
     if (gline != nullptr)
       for (int i = threadIdx.x; i < LL * CD; i += kWalkWaves * 64) {
-        const float v = sline[i];
+        const float v = (LLINE == 2) ? (float)reinterpret_cast<const double*>(sline)[i] : sline[i];
         if (v != 0.f) atomicAdd(gline + i, v);
       }
     __syncthreads();
@@ -889,21 +890,47 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
   const long witems = (long)n_rays * (runs / 4);
   int line_floats = 0;
   for (int a = 0; a < 3; ++a) line_floats = std::max(line_floats, D.ll[a] * D.Cd);
-  static const bool lline_env = [] { const char* e = getenv("JT_WALK_LDS_LINE"); return !e || atoi(e) != 0; }();
+  // JT_WALK_LDS_LINE (read once): 0 no LDS line, 1 a float copy, 2 a copy of doubles, unset: doubles where they fit the
+  // preferred workgroup shape, floats otherwise.  JT_WALK_WAVES = 8 / 16 forces the workgroup size.
+  static const int lline_env = [] { const char* e = getenv("JT_WALK_LDS_LINE"); return e ? atoi(e) : -1; }();
   static const int waves_env = [] { const char* e = getenv("JT_WALK_WAVES"); return e ? atoi(e) : 0; }();
-  int nw = 8;
+  int nw = 8, lline = 0, prefix = 0;
   size_t wlds = 0;
-  bool lline = false;
-  int prefix = 0;
-  for (;;) {
-    const size_t rec_bytes = (size_t)nw * 4 * (kWalkSub * kWalkRecW + 16) * sizeof(float);
-    lline = lline_env && !det && rec_bytes + (size_t)line_floats * sizeof(float) <= 158 * 1024;
-    wlds = rec_bytes + (lline ? (size_t)line_floats * sizeof(float) : 0);
-    prefix = (n_rays <= kWalkPrefixRays && wlds + (size_t)n_rays * sizeof(int) <= 158 * 1024) ? 1 : 0;
-    if (prefix) wlds += (size_t)n_rays * sizeof(int);
+  // a candidate (line mode, waves, two workgroups per CU wanted): its LDS bytes, or 0 when it does not fit
+  auto shape = [&](int lm, int w, bool two, int* pre) -> size_t {
+    const size_t rec_bytes = (size_t)w * 4 * (kWalkSub * kWalkRecW + 16) * sizeof(float);
+    size_t b = rec_bytes + (size_t)line_floats * sizeof(float) * lm;
+    if (b > 158 * 1024) return 0;
+    *pre = (n_rays <= kWalkPrefixRays && b + (size_t)n_rays * sizeof(int) <= 158 * 1024) ? 1 : 0;
+    if (*pre) b += (size_t)n_rays * sizeof(int);
+    if (two && 2 * (b + 256) > 160 * 1024) return 0;
+    return b;
+  };
+  {
     // eight-wave workgroups only where two of them fit a CU (otherwise sixteen waves: four per SIMD either way)
-    if (nw == 16 || (waves_env != 16 && 2 * (wlds + 256) <= 160 * 1024)) break;
-    nw = 16;
+    const int modes[2] = {2, 1};
+    bool found = false;
+    for (int mi = 0; mi < 2 && !found; ++mi) {
+      const int lm = modes[mi];
+      if (det || lline_env == 0 || (lline_env > 0 && lline_env != lm)) continue;
+      for (int w = 8; w <= 16 && !found; w += 8) {
+        if (waves_env == 8 || waves_env == 16) {
+          if (w != waves_env) continue;
+        }
+        int pre = 0;
+        const size_t b = shape(lm, w, w == 8 && waves_env != 8, &pre);
+        if (b) nw = w, lline = lm, prefix = pre, wlds = b, found = true;
+      }
+    }
+    if (!found) {
+      for (int w = 8; w <= 16 && !found; w += 8) {
+        if ((waves_env == 8 || waves_env == 16) && w != waves_env) continue;
+        int pre = 0;
+        const size_t b = shape(0, w, w == 8 && waves_env != 8, &pre);
+        if (b) nw = w, lline = 0, prefix = pre, wlds = b, found = true;
+      }
+    }
+    if (!found) return JT_ERR_UNSUPPORTED;
   }
   const int blocks = (int)std::min<long>(3 * ((witems + nw - 1) / nw), 255L * (16 / nw));  // 85 / 170 workgroups per plane
 #define JT_WALK_ONE(CD_, DET_, LL_, NW_)                                                                                    \
@@ -916,7 +943,7 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
     }                                                                                                                       \
     hipLaunchKernelGGL((k_march_bwd_walk<CD_, DET_, LL_, NW_>), dim3(blocks), dim3(NW_ * 64), wlds, st, D, GF, rays_o,      \
                        rays_d, jitter, zvals, tmin, n_rays, gfeat, vlist, nvalid, runs, g_rays_o, g_rays_d, rays_fixed,     \
-                       bad, lline ? line_floats : 0, prefix);                                                               \
+                       bad, lline * line_floats, prefix);                                                               \
   } while (0)
 #define JT_WALK_NW(CD_, DET_, LL_)              \
   do {                                          \
@@ -925,9 +952,10 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
   } while (0)
 #define JT_WALK(CD_)                               \
   do {                                             \
-    if (det) JT_WALK_NW(CD_, true, false);         \
-    else if (lline) JT_WALK_NW(CD_, false, true);  \
-    else JT_WALK_NW(CD_, false, false);            \
+    if (det) JT_WALK_NW(CD_, true, 0);             \
+    else if (lline == 2) JT_WALK_NW(CD_, false, 2); \
+    else if (lline == 1) JT_WALK_NW(CD_, false, 1); \
+    else JT_WALK_NW(CD_, false, 0);                \
   } while (0)
   if (D.Cd == 16) JT_WALK(16);
   else if (D.Cd == 8) JT_WALK(8);

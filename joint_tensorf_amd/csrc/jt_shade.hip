@@ -1300,6 +1300,14 @@ static int bwd_split_mode() {
   }
   return m;
 }
+#if JT_TILE_STAMP
+extern "C" int jt_debug_read_tile_stamps(unsigned long long* out16) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tstamps), 16 * sizeof(unsigned long long)) != hipSuccess) return JT_ERR_ARG;
+  unsigned long long z[16] = {};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_tstamps), z, sizeof(z)) != hipSuccess) return JT_ERR_ARG;
+  return JT_OK;
+}
+#endif
 extern "C" int jt_shade_bwd_split(void) { return bwd_split_mode(); }
 extern "C" int jt_shade_set_bwd_split(int run) {
   const int prev = bwd_split_mode();

@@ -29,6 +29,20 @@
 #define JT_TILE_ABL 0  // profiling knob: 1 no slice MFMA / flush, 2 no line atomics, 4 no line-tap loads, 8 no coordinate gradients
 #endif
 
+#if JT_TILE_STAMP
+// profiling build only (tools/build_variant.py -DJT_TILE_STAMP=1; tools/round5/stamp_tile.py): s_memtime ticks a wave of
+// k_tile_scatter spends per phase of a group, summed over all waves; [15] counts the groups
+__device__ unsigned long long g_tstamps[16];
+#define JT_TS(k)                                               \
+  {                                                            \
+    const unsigned long long now__ = __builtin_readcyclecounter(); \
+    ts_acc[k] += now__ - ts_last;                              \
+    ts_last = now__;                                           \
+  }
+#else
+#define JT_TS(k)
+#endif
+
 namespace jt {
 
 constexpr int kTileCells = 3;           // cells per tile side: a 2 x 2 footprint that starts in the tile ends inside its 4 x 4 texels
@@ -288,7 +302,11 @@ __device__ inline void tile_scatter_body(const Dev& D, const MlpDev& M, const Jt
         for (int c = 0; c < NCB; ++c) V[c][kk] = ldf(P, tb + chan_off(c));  // (texels outside the plane: zeroed at use)
       }
     };
+#if JT_TILE_STAMP
+    unsigned long long ts_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ts_last = __builtin_readcyclecounter(), ts_groups = 0;
+#endif
     for (;;) {
+      JT_TS(8)
       int first = 0;
       if (lane == 0) first = atomicAdd(&W.ctl[4 + cls], kTileGrab);
       first = __builtin_amdgcn_readfirstlane(first);
@@ -322,7 +340,11 @@ __device__ inline void tile_scatter_body(const Dev& D, const MlpDev& M, const Jt
       if (d1.valid) ent1 = load_entry(d1);
       load_gf(ent, av);
       int x0 = 0, y0 = 0;
+      JT_TS(9)
       while (d0.valid) {
+#if JT_TILE_STAMP
+        ++ts_groups;
+#endif
         // prefetches: entries of the group after next, GF rows of the next group, the values of the next item's tile
         if (d2.valid) ent2 = load_entry(d2);
         if (d1.valid) load_gf(ent1, av1);
@@ -338,6 +360,7 @@ __device__ inline void tile_scatter_body(const Dev& D, const MlpDev& M, const Jt
         }
         if (d0.last && d1.valid) load_tile(d1.tile, Vn);
         const int nlive = d0.nl;
+        JT_TS(0)
         // mapping (a): the lane's pair is lane & 15 -- its cell inside the tile, fractions, line taps
         const Axis ax = axis_taps(__uint_as_float(ent.y), Wd);
         const Axis ay = axis_taps(__uint_as_float(ent.z), H);
@@ -363,6 +386,7 @@ __device__ inline void tile_scatter_body(const Dev& D, const MlpDev& M, const Jt
           Ax[kk] = dxg * wy;
           Ay[kk] = wxg * dy;
         }
+        JT_TS(1)
         wave_lds_sync();
         // mapping (b): lane (g, n) carries channel n of pairs 4 g + i in register i
         float lw0[4], lw1[4], lm0[4], lm1[4];
@@ -381,6 +405,7 @@ __device__ inline void tile_scatter_body(const Dev& D, const MlpDev& M, const Jt
           ls0[i] = 8u * ((sp & 0xffffu) + (unsigned)n), ls1[i] = 8u * ((sp >> 16) + (unsigned)n);
           At[i] = tent(n & 3, __float_as_int(r0.x), r0.z) * tent(n >> 2, __float_as_int(r0.y), r0.w);
         }
+        JT_TS(2)
         // the line taps of all channel groups go out before the matrix work that does not need them
         float lu[NCB][4], lv_[NCB][4];
 #pragma unroll
@@ -393,6 +418,7 @@ __device__ inline void tile_scatter_body(const Dev& D, const MlpDev& M, const Jt
             lu[c][i] = ldf(Ln, lb0[i] + chan_off(c)), lv_[c][i] = ldf(Ln, lb1[i] + chan_off(c));
 #endif
           }
+        JT_TS(3)
         float aix[4] = {0.f, 0.f, 0.f, 0.f}, aiy[4] = {0.f, 0.f, 0.f, 0.f}, ail[4] = {0.f, 0.f, 0.f, 0.f};
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -442,6 +468,7 @@ __device__ inline void tile_scatter_body(const Dev& D, const MlpDev& M, const Jt
           S[c][0] += gpv[0] + gpv[1] + gpv[2] + gpv[3];
 #endif
         }
+        JT_TS(4)
 #if !(JT_TILE_ABL & 8)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -455,6 +482,7 @@ __device__ inline void tile_scatter_body(const Dev& D, const MlpDev& M, const Jt
           }
         }
 #endif
+        JT_TS(5)
         wave_lds_sync();
         // the slice leaves once: register i of lane (g, n) is texel (column i, row g) of the tile, channel n
         if (d0.last) {
@@ -476,13 +504,21 @@ __device__ inline void tile_scatter_body(const Dev& D, const MlpDev& M, const Jt
           if (S[0][0] == 123.f) gxo[0] = make_float4(S[NCB - 1][0], 0.f, 0.f, 0.f);
 #endif
         }
+        JT_TS(6)
         ent = ent1, ent1 = ent2;
 #pragma unroll
         for (int k = 0; k < KS; ++k) av[k] = av1[k];
         d0 = d1, d1 = d2, d2 = next_group(d2);
+        JT_TS(7)
       }
       wave_lds_sync();
     }
+#if JT_TILE_STAMP
+    if (lane == 0) {
+      for (int k = 0; k < 10; ++k) atomicAdd(&g_tstamps[k], ts_acc[k]);
+      atomicAdd(&g_tstamps[15], ts_groups);
+    }
+#endif
   }
   __syncthreads();
   float* gl = G.app_line[pl];

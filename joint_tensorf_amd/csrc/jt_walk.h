@@ -122,9 +122,12 @@ __device__ inline float row16_sum(float v) {
 // Run-length accumulator of one plane + its line, driven by step records.
 // FX: 0 = float atomics, 1 = JT_DETERMINISTIC fixed point, 2 = chosen at run time by init()'s flag (a kernel that is
 // instantiated once; the density walk, short of registers, is instantiated per mode)
-// LDSL: the LINE gradients are added into a workgroup-private copy of the line in LDS (gL points there; LDS float atomics,
-// the owner adds the copy into the real gradient once) instead of going out as global atomics
-template <int NCH, int CA, int FX = 2, bool LDSL = false>
+// LDSL: the LINE gradients are added into a workgroup-private copy of the line in LDS (gL points there; LDS atomics, the owner
+// adds the copy into the real gradient once) instead of going out as global atomics.  1: a float copy (ds_add_f32);
+// 2: a copy of DOUBLES, same element indexing (ds_add_f64) -- on gfx950 ds_add_f32 retires one lane every three cycles
+// (193 cycles per full wave instruction) while ds_add_f64 takes 9 (tools/lds_atomic_rate.hip), so the double copy is the one
+// to use wherever twice the bytes fit
+template <int NCH, int CA, int FX = 2, int LDSL = 0>
 struct RecWalker {
   float acc[4][NCH];   // plane accumulators, parity slots
   float accl[2][NCH];  // line accumulators, parity slots
@@ -191,8 +194,11 @@ struct RecWalker {
     for (int k = 0; k < NCH; ++k) any = any || JT_FLUSH_COND(a[k]);
     if (any) {
 #pragma unroll
-      for (int k = 0; k < NCH; ++k)
-        if (live[k]) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (off + ck[k])), a[k]);
+      for (int k = 0; k < NCH; ++k) {
+        if (!live[k]) continue;
+        if (LDSL == 2) atomicAdd(reinterpret_cast<double*>(reinterpret_cast<char*>(base) + 2u * (off + ck[k])), (double)a[k]);
+        else atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (off + ck[k])), a[k]);
+      }
     }
 #pragma unroll
     for (int k = 0; k < NCH; ++k) a[k] = 0.f;
