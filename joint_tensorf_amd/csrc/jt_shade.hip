@@ -757,6 +757,155 @@ __global__ __launch_bounds__(WAVES * 64) void k_shade_scatter(Dev D, MlpDev M, J
   }
 }
 
+// ---- pose-only backward: the coordinate gradients without walkers ---------------------------------------------------------
+// Test-time pose optimisation (model/bat.py:265-292) wants nothing but the rays' gradient.  k_shade_bwd<SPLIT> leaves the feature
+// gradients GF of every tile in the records; this kernel forms basis^T GF one M tile (32 channels of a plane) at a time and takes
+// the coordinate gradient of every plane from its taps GATHERED ONCE MORE in the forward's layout: the product gradients of an M
+// tile land in the lane half that gathers those channel quads, so the sum over the channels is lane-local -- no walkers, no step
+// records, no scatter tile.  On its own (not behind the chain in one kernel: the chain's 190 registers plus the taps in flight
+// spill, jt_fused.hip) it needs 18 KB of LDS for basis_mat and runs at its own occupancy.
+template <class C>
+__global__ __launch_bounds__(256, 3) void k_pose_gather(Dev D, MlpDev M, const int* __restrict__ offset, int R,
+                                                     float* __restrict__ g_xyz, const float* __restrict__ rec, int chunk_start,
+                                                     int chunk_cap, int cap) {
+  typedef BwdCfg<C> B;
+  __shared__ float smem[32 * C::LDB];
+  const int total = min(offset[R], cap);
+  const int n_chunk = min(total - chunk_start, chunk_cap);
+  const int ntiles = (n_chunk + 31) >> 5;
+  const int nblk = min((int)gridDim.x, (ntiles + 3) / 4);
+  if ((int)blockIdx.x >= nblk) return;
+  {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int a = wv; a < 32; a += 4) {  // basis [APP][NC] -> [32][LDB], rows >= APP and the pad column zero
+      const bool row = a < C::APP;
+      for (int c = lane; c < C::LDB; c += 64) smem[C::O_BASIS + a * C::LDB + c] = (row && c < C::NC) ? M.basis[a * C::NC + c] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const XcdShare xs = xcd_share(ntiles, nblk);
+  for (int tile = xs.lo + xs.rank * 4 + wv; tile < xs.hi; tile += xs.peers * 4) {
+    int j = lane & 31, h = lane >> 5;
+    asm volatile("" : "+v"(j), "+v"(h));
+    const int l0 = tile * 32;
+    const int e = chunk_start + l0 + j;
+    const int nlive = min(32, n_chunk - l0);
+    const bool on = j < nlive;
+    const int jj = on ? j : nlive - 1;
+    const float* rt = rec + (size_t)tile * B::REC_FLOATS * 32;
+    f32x16 gf;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = rec_ld(rec_at(rt, B::R_GF + rowmap(r, 0), 4u * (unsigned)jj + 512u * (unsigned)h));
+      gf[r] = on ? v : 0.f;
+    }
+    // ---- basis^T one M tile (32 channels of a plane) at a time, then the plane's position gradient from its taps ----
+    constexpr int PT = B::PT;
+    // (no register ARRAYS indexed by the plane: a rolled loop that indexed n[] / the sums dynamically went through scratch
+    //  memory and came back wrong for one axis in jt_fused.hip -- the plane's operands are picked with selects)
+    const float n0 = rec_ld(rec_at(rt, B::R_GEO + 0, 4u * (unsigned)jj)), n1 = rec_ld(rec_at(rt, B::R_GEO + 1, 4u * (unsigned)jj)),
+                n2 = rec_ld(rec_at(rt, B::R_GEO + 2, 4u * (unsigned)jj));
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll 1
+    for (int pl = 0; pl < 3; ++pl) {
+      // matMode / vecMode: plane 0 (x, y | z), plane 1 (x, z | y), plane 2 (y, z | x)
+      const float nx = pl == 2 ? n1 : n0, ny = pl == 0 ? n1 : n2, nl = pl == 0 ? n2 : (pl == 1 ? n1 : n0);
+      const int PH = pl == 0 ? D.ph[0] : (pl == 1 ? D.ph[1] : D.ph[2]), PW = pl == 0 ? D.pw[0] : (pl == 1 ? D.pw[1] : D.pw[2]),
+                LLn = pl == 0 ? D.ll[0] : (pl == 1 ? D.ll[1] : D.ll[2]);
+      const PlaneTaps tq = plane_taps(nx, ny, PH, PW, C::CA);
+      const Axis l = axis_taps(nl, LLn);
+      const float* P = pl == 0 ? D.aP[0] : (pl == 1 ? D.aP[1] : D.aP[2]);
+      const float* L = pl == 0 ? D.aL[0] : (pl == 1 ? D.aL[1] : D.aL[2]);
+      const unsigned hb = 16u * (unsigned)h;
+      const unsigned b00 = 4u * (unsigned)tq.o00 + hb, b10 = 4u * (unsigned)tq.o10 + hb, b01 = 4u * (unsigned)tq.o01 + hb,
+                     b11 = 4u * (unsigned)tq.o11 + hb, bl0 = 4u * (unsigned)(l.c0 * C::CA) + hb,
+                     bl1 = 4u * (unsigned)(l.c1 * C::CA) + hb;
+      const float m00 = tq.ax.m0 * tq.ay.m0, m10 = tq.ax.m1 * tq.ay.m0, m01 = tq.ax.m0 * tq.ay.m1,
+                  m11 = tq.ax.m1 * tq.ay.m1;
+      const float fx = tq.ax.f, fy = tq.ay.f;
+      float sx = 0.f, sy = 0.f, sl = 0.f;
+      const bool oor = __builtin_amdgcn_ballot_w64(m00 * m10 * m01 * m11 * l.m0 * l.m1 == 0.f) != 0ull;  // (wave-uniform)
+#pragma unroll
+      for (int TT = 0; TT < PT; ++TT) {
+        f32x16 gpt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gpt[r] = 0.f;
+        {
+          const int ch = TT * 32 + j;
+          const int col = (ch < C::CA) ? pl * C::CA + ch : C::NC;  // (NC: the zero pad column)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int arow = rowmap(r, 0) + 4 * h;
+            const float av = smem[C::O_BASIS + arow * C::LDB + col];
+            gpt = __builtin_amdgcn_mfma_f32_32x32x2f32(av, gf[r], gpt, 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 4 * TT; m < C::NSLOT && m < 4 * TT + 4; ++m) {
+          const int q = 2 * m + h;
+          const bool live = q * 4 < C::CA;
+          float4 a, b, c, d, u, v;
+          if (C::CA % 8 == 0 || m + 1 < C::NSLOT) {
+            a = ld4q(P, b00, 2 * m), b = ld4q(P, b10, 2 * m), c = ld4q(P, b01, 2 * m), d = ld4q(P, b11, 2 * m);
+            u = ld4q(L, bl0, 2 * m), v = ld4q(L, bl1, 2 * m);
+          } else {  // last slot of an odd quad count: half 1 has no quad there (its gradients are zero)
+            a = ld4q(P, b00 - hb, 2 * m), b = ld4q(P, b10 - hb, 2 * m), c = ld4q(P, b01 - hb, 2 * m);
+            d = ld4q(P, b11 - hb, 2 * m), u = ld4q(L, bl0 - hb, 2 * m), v = ld4q(L, bl1 - hb, 2 * m);
+          }
+          const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, cv[4] = {c.x, c.y, c.z, c.w},
+                      dv[4] = {d.x, d.y, d.z, d.w}, uv[4] = {u.x, u.y, u.z, u.w}, vv[4] = {v.x, v.y, v.z, v.w};
+          if (!oor) {
+            // every tap inside its factor (all but samples exactly on a far border): the interpolations in their nested form,
+            // 16 vector instructions per channel instead of 26
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const float gpr = live ? gpt[4 * (m & 3) + kk] : 0.f;
+              const float ba = bv[kk] - av[kk], dc = dv[kk] - cv[kk], vu = vv[kk] - uv[kk];
+              const float top = av[kk] + fx * ba, bot = cv[kk] + fx * dc;
+              const float dpy = bot - top;
+              const float pv = top + fy * dpy;
+              const float dpx = ba + fy * (dc - ba);
+              const float lv = uv[kk] + l.f * vu;
+              const float gl = gpr * lv;
+              sx += gl * dpx;
+              sy += gl * dpy;
+              sl += (gpr * pv) * vu;
+            }
+          } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              // product gradient of channel 8 m + 4 h + kk of this plane: row rowmap(4 (m & 3) + kk, h) of M tile m >> 2
+              const float gpr = live ? gpt[4 * (m & 3) + kk] : 0.f;
+              const float am = av[kk] * m00, bm = bv[kk] * m10, cm = cv[kk] * m01, dm = dv[kk] * m11;
+              const float um = uv[kk] * l.m0, vm = vv[kk] * l.m1;
+              const float pv = tq.w00 * av[kk] + tq.w10 * bv[kk] + tq.w01 * cv[kk] + tq.w11 * dv[kk];
+              const float lv = l.w0 * uv[kk] + l.w1 * vv[kk];
+              const float gl = gpr * lv;
+              sx += gl * ((1.f - fy) * (bm - am) + fy * (dm - cm));
+              sy += gl * ((1.f - fx) * (cm - am) + fx * (dm - bm));
+              sl += gpr * pv * (vm - um);
+            }
+          }
+          if (m & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      const float vx = sx * tq.ax.scale, vy = sy * tq.ay.scale, vl = sl * l.scale;
+      g0 += pl == 2 ? vl : vx;
+      g1 += pl == 0 ? vy : (pl == 1 ? vl : vx);
+      g2 += pl == 0 ? vl : vy;
+    }
+    // the two lane halves hold the sums over their own channel quads of the same sample
+    g0 += __shfl_xor(g0, 32), g1 += __shfl_xor(g1, 32), g2 += __shfl_xor(g2, 32);
+    if (on && h == 0) {
+      float* o = g_xyz + (size_t)e * 3;
+      o[0] = g0 * D.inv[0], o[1] = g1 * D.inv[1], o[2] = g2 * D.inv[2];
+    }
+
+  }
+}
+
 }  // namespace jt (jt_tile.h opens its own)
 #include "jt_tile.h"
 namespace jt {
@@ -1562,6 +1711,11 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   const TileWs TW = tile_ws_carve(reinterpret_cast<char*>(ws) + W::main_bytes(cap), cap, chunk);
   // fused: one kernel per chunk.  Split: the chain (launch_bwd) and the scatter (launch_scatter) -- the weight-gradient GEMMs only
   // need the chain's records, so they are forked BEHIND THE CHAIN and run next to the atomic-bound scatter.
+  // nothing but the rays wants a gradient (no factor gradients, no weight gradients): the walker-free kernel
+  // (JT_POSE_BWD=0, read once: the fused kernel with its scatter switched to "no targets", as before round 5)
+  static const bool pose_env = [] { const char* e = getenv("JT_POSE_BWD"); return !e || atoi(e) != 0; }();
+  const bool pose_only = pose_env && !det && !G.app_plane[0] && !G.app_line[0] && (flags & kNoGradRecords) && (ablate & 4);
+  if (pose_only) split = 16;  // the chain alone (k_shade_bwd<SPLIT>: GF rows out), then k_pose_gather in the scatter's place
   auto launch_bwd = [&](int ci) -> int {
     const int start = ci * chunk, ccap = std::min(chunk, cap - start);
     long tiles = ((long)ccap + 31) / 32;
@@ -1607,6 +1761,13 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     if (!split || (ablate & 1)) return JT_OK;
     const int start = ci * chunk, ccap = std::min(chunk, cap - start);
     const float* rc = recs + W::rec_floats_per_chunk() * ci;
+    if (pose_only) {
+      const long tiles = ((long)ccap + 31) / 32;
+      const int pblocks = (int)std::min<long>((tiles + 3) / 4, 2048L);
+      hipLaunchKernelGGL((k_pose_gather<C>), dim3(pblocks), dim3(256), 0, st, D, M, offset, R, g_xyz, rc, start, ccap, cap);
+      JT_LAUNCH_CHECK();
+      return JT_OK;
+    }
     if (tile) {
       int rc_ = (tile_cfg == 1) ? TS::template launch<1>(D, M, G, TW, offset, R, g_xyz, rc, start, ccap, cap, tile_line_len, st)
                                 : TS::template launch<0>(D, M, G, TW, offset, R, g_xyz, rc, start, ccap, cap, tile_line_len, st);
