@@ -736,8 +736,27 @@ def main():
     rays_timed = rays_total
     all_timers, jops_t.STEP_TIMERS = jops_t.STEP_TIMERS, None
     timers = all_timers[n_untimed:] if all_timers is not None else None
+    # JT_BENCH_CHECKSUM=1 (validation of the N > 1 sharding paths against each other): the parameters as the TIMED steps left
+    # them -- taken here, in front of the no-collectives leg below, which lets the ranks' parameters drift apart -- and whether
+    # every rank holds the same ones (the optimizer step is replicated: identical reduced gradients, identical parameters)
+    param_checksum = None
+    if os.environ.get("JT_BENCH_CHECKSUM") == "1":
+        with torch.no_grad():
+            tf = model.graph.nerf.tensorf
+            param_checksum = {
+                "density": float(sum(p.double().abs().sum() for p in tf.density_plane)),
+                "app": float(sum(p.double().abs().sum() for p in tf.app_plane)),
+                "mlp": float(sum(p.double().abs().sum() for p in tf.renderModule.weights())),
+                "se3": float(model.graph.se3_refine.weight.double().abs().sum())}
+            if world > 1 or FORCE_DIST:
+                import torch.distributed as dist
+                mine = torch.tensor([param_checksum[k] for k in ("density", "app", "mlp", "se3")], device=dev, dtype=torch.float64)
+                every = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(every, mine)
+                param_checksum["identical_on_every_rank"] = bool(all(torch.equal(e, every[0]) for e in every))
+                param_checksum["ranks_compared"] = len(every)
     # how much of the gradient exchange the backward hid: the same K steps once more with every collective switched off
-    # (after the timed region; the ranks' parameters drift apart from here on, nothing below reads them)
+    # (after the timed region and the checksum; the ranks' parameters drift apart from here on, nothing below reads them)
     dt_nocoll = None
     if world > 1 or FORCE_DIST:
         jops_t._DP["no_collectives"] = True
@@ -858,11 +877,7 @@ def main():
             with torch.no_grad():
                 tf = model.graph.nerf.tensorf
                 out["grad_checksum_first_step"] = grad_sums[0] if grad_sums else None
-                out["param_checksum"] = {
-                    "density": float(sum(p.double().abs().sum() for p in tf.density_plane)),
-                    "app": float(sum(p.double().abs().sum() for p in tf.app_plane)),
-                    "mlp": float(sum(p.double().abs().sum() for p in tf.renderModule.weights())),
-                    "se3": float(model.graph.se3_refine.weight.double().abs().sum())}
+                out["param_checksum"] = param_checksum
         if not args.no_roofline:
             try:
                 from joint_tensorf_amd.options import Opt

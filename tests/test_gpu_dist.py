@@ -121,6 +121,39 @@ def test_bench_gpus2_starts_its_own_ranks():
     assert abs(line["allreduce_overlap_ms"] - (line["ms_per_step"] - line["ms_per_step_no_collectives"])) < 1e-6
 
 
+@pytest.mark.parametrize("shard", ["pixel", "view"])
+def test_bench_gpus8_single_device(shard):
+    """`python bench.py --gpus 8` functionally: eight fresh ranks, all on GPU 0 over gloo, share ONE
+    configs[3] iteration (65 536 nominal = 62 500 lattice rays: 25 x 25 points on each of 100 views).  pixel shards: every rank
+    takes 78 or 79 of a view's 625 lattice points (7 800 / 7 900 rays); view shards: 12 or 13 whole views (7 500 / 8 125 rays).
+    After the timed steps every rank holds the SAME parameters (replicated optimizer step on all-reduced gradients), and the
+    line names the single-GPU figure it scales from.  No scaling number is asserted: eight ranks on one device say nothing
+    about xGMI."""
+    env = dict(os.environ, JT_BENCH_SINGLE_DEVICE="1", JT_DIST_BACKEND="gloo", JT_BENCH_CHECKSUM="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--shard", shard, "--no-probe", "--no-cpu-baseline", "--no-torch-baseline", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong"
+    rk = line["ranks"]
+    assert rk["world_size"] == 8 and rk["backend"] == "gloo" and rk["rccl_ranks"] == 0 and rk["shard"] == shard
+    per = [int(round(v)) for v in rk["rays_per_iter_per_rank"]]
+    assert len(per) == 8 and sum(per) == 62500, per
+    if shard == "pixel":
+        assert sorted(set(per)) == [7800, 7900] and per.count(7900) == 625 - 8 * 78, per   # 79 / 78 points x 100 views
+    else:
+        assert sorted(set(per)) == [7500, 8125] and per.count(8125) == 100 - 8 * 12, per   # 13 / 12 views x 625 points
+    pc = line["param_checksum"]
+    assert pc["ranks_compared"] == 8 and pc["identical_on_every_rank"] is True, pc
+    assert all(pc[k] > 0 for k in ("density", "app", "mlp")), pc
+    assert "strong_scaling_n1" in line and "--gpus 1 --total-rays 65536" in line["strong_scaling_n1"]["workload"]
+    assert len(line["allreduce_ms"]) == 3
+
+
 def test_bench_gpus_mismatch_is_an_error():
     """--gpus 4 inside a process group of one rank: refuse instead of printing a line for another N"""
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
