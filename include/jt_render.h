@@ -29,7 +29,11 @@
 extern "C" {
 #endif
 
-#define JT_VERSION 1003
+/* Bumped whenever a struct layout, an argument list or what an argument must point to changes (round 4 added
+ * JtScene.near_plane_dev and grew the regulariser scratch to 640 floats without bumping it: a caller built against the old
+ * header would have handed over a shorter struct).  jt_version() returns the value the LIBRARY was built with; the Python
+ * binding refuses to load a library whose version differs from this header's. */
+#define JT_VERSION 1100
 
 #define JT_OK 0
 #define JT_ERR_ARG 1         /* null pointer / bad size */
@@ -413,7 +417,7 @@ int jt_loss_sum_backward_dyn(const float* g_total, const float* w4, float* g_ren
 
 /* All regularisers of one scene in one call (replaces the loop bodies of model/tensorf.py:127-130):
  *   out3 = { density_L1(), TV_loss_density(TVLoss()), TV_loss_app(TVLoss()) }   (tensoRF.py:212-228).
- * plane_hw_line[9] = {H_i, W_i, L_i} for i = 0..2; scratch36 (forward): 640 floats of device scratch that must be ZERO when the
+ * plane_hw_line[9] = {H_i, W_i, L_i} for i = 0..2; scratch640 (forward): 640 floats of device scratch that must be ZERO when the
  * first call sees them and are left zero by every call (the one launch sums into them and its last workgroup combines and resets
  * them: no zero fill and no combine launch per iteration); not to be shared by calls that run concurrently.
  * with_tv_density / with_tv_app == 0: that TV term has weight zero in the run; it is not evaluated and out3
@@ -421,11 +425,11 @@ int jt_loss_sum_backward_dyn(const float* g_total, const float* w4, float* g_ren
  * backward: g3 = dL/d out3 on the device; writes (accumulate == 0) or adds (accumulate != 0) the gradients of
  * the density planes + lines, and of the appearance planes when with_tv_app != 0, into g_factors. */
 int jt_reg_losses_forward(const JtFactors* factors, const int32_t* plane_hw_line, int n_comp_density,
-                          int n_comp_app, int with_tv_density, int with_tv_app, float* scratch36, float* out3,
+                          int n_comp_app, int with_tv_density, int with_tv_app, float* scratch640, float* out3,
                           void* stream);
 int jt_reg_losses_backward(const JtFactors* factors, const int32_t* plane_hw_line, int n_comp_density,
                            int n_comp_app, const float* g3, int with_tv_density, int with_tv_app,
-                           const JtFactors* g_factors, int accumulate, float* scratch36, void* stream);
+                           const JtFactors* g_factors, int accumulate, float* scratch640, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense Adam step over all tensors of an optimizer in one launch.  Replaces torch.optim.Adam.step of the

@@ -137,6 +137,13 @@ class JtError(RuntimeError):
     pass
 
 
+def header_version():
+    """JT_VERSION of include/jt_render.h (the header this binding's SIGNATURES / struct mirrors were written against)"""
+    import re
+    src = open(os.path.join(os.path.dirname(HERE), "include", "jt_render.h")).read()
+    return int(re.search(r"^#define\s+JT_VERSION\s+(\d+)", src, flags=re.M).group(1))
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -147,6 +154,12 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # a library built from another revision of the header (a stale .so, a JT_LIB_PATH variant of an older tree) would be
+    # handed structs and scratch buffers of the wrong size: refuse it here instead of inside a kernel
+    want, got = header_version(), lib.jt_version()
+    if want != got:
+        raise ImportError("joint_tensorf_amd: %s reports ABI version %d, include/jt_render.h is %d -- rebuild with "
+                          "`python joint_tensorf_amd/build.py --force`" % (LIB_PATH, got, want))
     return lib
 
 

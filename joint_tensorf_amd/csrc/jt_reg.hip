@@ -352,12 +352,12 @@ static int reg_set(const JtFactors* f, const JtFactors* g, const int32_t* hw, in
 }
 
 extern "C" int jt_reg_losses_forward(const JtFactors* factors, const int32_t* plane_hw_line, int n_comp_density,
-                                     int n_comp_app, int with_tv_density, int with_tv_app, float* scratch36,
+                                     int n_comp_app, int with_tv_density, int with_tv_app, float* scratch640,
                                      float* out3, void* stream) {
   RegSet S;
   int rc = reg_set(factors, nullptr, plane_hw_line, n_comp_density, n_comp_app, &S);
   if (rc) return rc;
-  if (!scratch36 || !out3) return JT_ERR_ARG;
+  if (!scratch640 || !out3) return JT_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   RegBatch B;
   B.n = 0;
@@ -379,18 +379,18 @@ extern "C" int jt_reg_losses_forward(const JtFactors* factors, const int32_t* pl
   }
   RegDims Dm;
   for (int i = 0; i < 9; ++i) Dm.H[i] = S.t[i].H, Dm.W[i] = S.t[i].W, Dm.C[i] = S.t[i].C;
-  hipLaunchKernelGGL(k_reg_batch_fwd, dim3(nblk), dim3(256), 0, st, B, Dm, scratch36, out3);
+  hipLaunchKernelGGL(k_reg_batch_fwd, dim3(nblk), dim3(256), 0, st, B, Dm, scratch640, out3);
   JT_LAUNCH_CHECK();
   return JT_OK;
 }
 
 extern "C" int jt_reg_losses_backward(const JtFactors* factors, const int32_t* plane_hw_line, int n_comp_density,
                                       int n_comp_app, const float* g3, int with_tv_density, int with_tv_app,
-                                      const JtFactors* g_factors, int accumulate, float* scratch36, void* stream) {
+                                      const JtFactors* g_factors, int accumulate, float* scratch640, void* stream) {
   RegSet S;
   int rc = reg_set(factors, g_factors, plane_hw_line, n_comp_density, n_comp_app, &S);
   if (rc) return rc;
-  if (!g3 || !scratch36 || !g_factors) return JT_ERR_ARG;
+  if (!g3 || !scratch640 || !g_factors) return JT_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   RegBatch B;
   B.n = 0;

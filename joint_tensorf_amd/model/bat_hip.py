@@ -1059,16 +1059,25 @@ class Model(torch.nn.Module):
         over its own rays -- so V of them run as ONE iteration: a [V, 6] parameter under one Adam (element-wise: every row is
         the serial run's state), every view's rays on ITS lattice (ragged: the lattice size depends on the offsets)
         concatenated into one ray batch through the pose-only backward, one photometric mean PER VIEW, summed.  The host
-        draws are taken up front in the reference's order (view by view, iteration by iteration: two lattice offsets and the
-        density-blur scale), so every view sees exactly the draws of the serial run and the process's random stream ends where
-        the serial run leaves it.  Returns the views (dicts) with se3_refine_test [1, 6] / pose_refine_test as the serial
+        draws are taken up front view by view, iteration by iteration (two lattice offsets and the density-blur scale): every
+        view sees the draws of serial OPTIMISATIONS run back to back, and the random stream ends where those leave it.  (The
+        reference's evaluate_full interleaves an eval render after each view's optimisation, and that render draws nothing
+        while the blur is off -- the only case this routine takes; with a blur possible it falls back to the serial loop.)
+        Returns the views (dicts) with se3_refine_test [1, 6] / pose_refine_test as the serial
         routine leaves them -- pose_refine_test from the top of the LAST iteration (the reference's quirk, model/bat.py:284).
         Falls back to the serial routine when a factor blur is active at test time (per-view blur scales cannot share a
         render) or for a single view."""
         g = self.graph
         V, T, dev = len(views), int(opt.optim.test_iter), opt.device
+        # could ANY call of resolve_blur during the optimisation or the eval renders come back with a kernel?  The schedule's
+        # value alone ("vis"), the density value under the LARGEST random scale (a pool value above 1 lifts a density parameter
+        # that is below the 1e-3 cut-off on its own over it), LLFF's test-time kernel schedule
         blur_possible = g.resolve_blur(opt, "vis")[2] is not None or (
             opt.data.dataset == "llff" and max(float(v) for v in opt.optim.test_kernel_schedule) >= 0.001)
+        if not blur_possible and opt.model in ("bat", "bat_hip") and opt.c2f_mode != "None" and \
+                _has(opt, "c2f_random_density_blur") and opt.c2f_random_density_blur:
+            pd = interp_schedule(g.nerf.progress_host, opt.c2f_schedule_density)
+            blur_possible = pd * max(float(v) for v in opt.c2f_random_density_scale_pool) >= 0.001
         if V <= 1 or blur_possible or opt.nerf.ray_sampling_strategy != "all_view_rand_grid" or \
                 (_has(opt.optim, "test_fused") and opt.optim.test_fused):
             return [self.evaluate_test_time_photometric_optim(opt, v) for v in views]

@@ -40,10 +40,17 @@ FINITE_POSE, FINITE_RENDER, FINITE_LOSS, FINITE_GRAD = 1, 2, 4, 8
 _STATUS = {}
 
 
+def device_key(dev):
+    """index of a CUDA device however it is spelt: "cuda", "cuda:0", torch.device("cuda", 0) are one device -- the key of every
+    per-device cache of this package (status word, regulariser scratch, VMAdam's coefficient buffer: a cache keyed by the
+    spelling is filled under "cuda" before a hipGraph capture and missed under "cuda:0" inside it)"""
+    d = torch.device(dev)
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
 def status_word(dev):
     """the device's status word (int32[1], zero until a check finds a NaN / infinity)"""
-    d = torch.device(dev)
-    key = d.index if d.index is not None else torch.cuda.current_device()  # "cuda" and "cuda:0" are one device
+    key = device_key(dev)
     if key not in _STATUS:
         _STATUS[key] = torch.zeros(1, device=torch.device("cuda", key), dtype=torch.int32)
         # the library reports dropped fixed-point addends / out-of-range sums of its gradient scatters here (FINITE_GRAD)
@@ -182,11 +189,11 @@ _REG_SCRATCH = {}
 def _reg_scratch(dev):
     """jt_reg_losses_forward's 640 floats of device scratch: zero when the first call sees them, left zero by every call (the
     kernel's last workgroup resets them) -- one persistent buffer per device instead of a zero fill per iteration"""
-    key = str(dev)
+    key = device_key(dev)
     if key not in _REG_SCRATCH:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("the regularisers' scratch must exist before a hipGraph capture")
-        _REG_SCRATCH[key] = torch.zeros(640, device=dev, dtype=torch.float32)
+        _REG_SCRATCH[key] = torch.zeros(640, device=torch.device("cuda", key), dtype=torch.float32)
     return _REG_SCRATCH[key]
 
 

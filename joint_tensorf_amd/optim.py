@@ -67,9 +67,10 @@ class VMAdam(torch.optim.Optimizer):
 
     def _dyn_buffer(self, dev, n_items):
         d = self.__dict__.setdefault("_dyn", {})
-        key = str(dev)
+        from .ops import device_key
+        key = device_key(dev)   # ("cuda" before a capture, "cuda:0" inside it: one buffer)
         if key not in d or d[key].numel() < 2 * n_items:
-            d[key] = torch.zeros(2 * max(n_items, 32), device=dev, dtype=torch.float32)
+            d[key] = torch.zeros(2 * max(n_items, 32), device=torch.device("cuda", key), dtype=torch.float32)
             self._dyn_gen = getattr(self, "_dyn_gen", 0) + 1  # a captured graph holding the old buffer is stale
         return d[key]
 

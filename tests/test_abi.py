@@ -28,7 +28,8 @@ def test_header_vs_ctypes_vs_library():
     so = ctypes.CDLL(_lib.LIB_PATH)
     for name in funcs:
         assert hasattr(so, name), name
-    assert so.jt_version() >= 1001
+    # the library and the header agree on the ABI revision (a mismatch is an ImportError in _lib._load as well)
+    assert so.jt_version() == _lib.header_version() >= 1100
 
 
 def test_product_library_has_no_test_only_entry_points():

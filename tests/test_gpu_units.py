@@ -272,6 +272,31 @@ def test_reg_losses_vs_oracle():
     assert all(dev[i].grad is None for i in range(9, 12))
 
 
+def test_reg_losses_scratch_is_left_zero_and_values_repeat():
+    """The one-launch regulariser forward sums into a persistent per-device scratch that its last workgroup reads AND resets
+    with returning atomics behind relaxed tickets (csrc/jt_reg.hip: no release fence, the sums are memory-side atomics).  A
+    partial sum that landed behind the reset would stay in the scratch and poison every later value of the process
+    (ADVICE r4): after many calls on a large factor set (thousands of workgroups per call) the scratch is exactly zero and
+    every call returned bit-identical values in deterministic mode / values within float-sum noise otherwise."""
+    from joint_tensorf_amd import ops
+    g = torch.Generator().manual_seed(5)
+    grid = [96, 107, 96]
+    p = O.init_params(grid, density_n_comp=(16, 16, 16), app_n_comp=(20, 20, 20), app_dim=20, featureC=32,
+                      shadingMode="MLP_Fea_WeakView", scale=0.3, bias=-0.1, generator=g)
+    dev = [ops.factor_logical(ops.factor_storage(t.detach()).to(DEV))
+           for grp in ("density_plane", "density_line", "app_plane", "app_line") for t in p[grp]]
+    outs = []
+    with torch.no_grad():
+        for _ in range(200):
+            outs.append(ops.reg_losses(dev[0:3], dev[3:6], dev[6:9], dev[9:12], True, True))
+    torch.cuda.synchronize()
+    scratch = ops._reg_scratch(dev[0].device)
+    assert int((scratch.view(torch.int32) != 0).sum()) == 0, "residue in the regularisers' scratch"
+    vals = torch.stack(outs).double().cpu()
+    ref = vals[0]
+    assert torch.all((vals - ref).abs() <= 2e-6 * ref.abs()), (vals.min(0).values, vals.max(0).values)
+
+
 def test_upsample_volume_grid_vs_golden():
     """BAT_VMSplit.upsample_volume_grid (channel-last parameters) against the reference's up_sampling_VM."""
     import joint_tensorf_amd as jt
