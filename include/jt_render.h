@@ -430,6 +430,14 @@ int jt_reg_losses_forward(const JtFactors* factors, const int32_t* plane_hw_line
 int jt_reg_losses_backward(const JtFactors* factors, const int32_t* plane_hw_line, int n_comp_density,
                            int n_comp_app, const float* g3, int with_tv_density, int with_tv_app,
                            const JtFactors* g_factors, int accumulate, float* scratch640, void* stream);
+/* Value AND gradient in ONE launch (round 5): out3 as jt_reg_losses_forward, and the gradients that jt_reg_losses_backward
+ * (accumulate == 0) would WRITE for the upstream gradients w3 = dL/d out3 -- in a training step the loss weights of
+ * Model.summarize_loss (model/tensorf.py:31-47), known before the forward: three host floats (w3_host) or, when w3_host is
+ * NULL, three floats in device memory (w3_dev: a replayed hipGraph reads this iteration's weights from there).  Every factor
+ * is read once instead of twice.  scratch640 as for the forward.  JT_ERR_UNSUPPORTED in deterministic mode. */
+int jt_reg_losses_fused(const JtFactors* factors, const int32_t* plane_hw_line, int n_comp_density, int n_comp_app,
+                        int with_tv_density, int with_tv_app, const float* w3_host, const float* w3_dev,
+                        const JtFactors* g_factors, float* scratch640, float* out3, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense Adam step over all tensors of an optimizer in one launch.  Replaces torch.optim.Adam.step of the

@@ -117,6 +117,7 @@ SIGNATURES = {
     "jt_loss_sum_backward_dyn": (I, [P, P, P, P, P]),
     "jt_reg_losses_forward": (I, [FP, P, I, I, I, I, P, P, P]),
     "jt_reg_losses_backward": (I, [FP, P, I, I, P, I, I, FP, I, P, P]),
+    "jt_reg_losses_fused": (I, [FP, P, I, I, I, I, P, P, FP, P, P, P]),
     "jt_adam_step": (I, [P, I, F, F, F, P]),
     "jt_adam_step_dyn": (I, [P, I, F, F, F, P, P]),
     "jt_adam_step_coefs": (I, [P, I, F, F, F, P, P]),

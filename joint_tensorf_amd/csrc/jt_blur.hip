@@ -311,6 +311,141 @@ __global__ __launch_bounds__(kLineThreads) void k_blur_line(LineBatch B, int npa
   }
 }
 
+
+// ---- the pass on the matrix cores (round 5) ----------------------------------------------------------------------------------
+// A 65-tap correlation of a line is a banded Toeplitz product: out[p] = sum_q T[p][q] in[q], T[p][q] = taps[q - p + r].  For a
+// block of 16 outputs the band is 16 + 64 = 80 inputs wide: twenty v_mfma_f32_16x16x4_f32 with A = the block's slice of T
+// (THE SAME for every block of every line: twenty registers per lane, built once per tap vector), B = 16 channels of four
+// consecutive input positions straight from the LDS chunk, D = 16 outputs x 16 channels.  k_blur_line does the same sums as
+// 16 packed FMAs per input on the vector pipe (98 us per pass at 400^3: vector-issue bound, 2.5 TB/s of the 6.3 TB/s streaming
+// roof); here the vector pipe only moves data.  fp32 inputs, fp32 products, fp32 accumulation: the same precision.
+// A workgroup of four waves stages one line chunk (all positions + halo x 16 channels: 30 KB at n = 400) and its waves take
+// pairs of output blocks (two independent accumulator chains per wave).  Taps <= kMfmaTaps (the factor blur's 65; the 201-tap
+// 2-D blur of the supervising images keeps the vector kernel).
+constexpr int kMfmaTaps = 65;
+constexpr int kMfmaK = (16 + kMfmaTaps - 1 + 3) / 4;   // K steps of a block: 20
+typedef float blur_f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool ADJ>
+__global__ __launch_bounds__(256) void k_blur_mfma(LineBatch B, int npos) {
+  extern __shared__ __align__(16) float s_dyn[];
+  float* s_in = s_dyn;                       // [npos][16]: position -r + idx, channels of the chunk
+  float* s_cum = s_dyn + (size_t)npos * 16;  // [ntaps + 1] prefix sums of the taps (adjoint borders)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, nn = lane & 15;
+  const int per = (B.total + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int c_begin = (int)blockIdx.x * per, c_end = min(c_begin + per, B.total);
+  const float* cur_taps = nullptr;
+  int cur_ntaps = 0;
+  float a[kMfmaK];
+#pragma unroll
+  for (int kk = 0; kk < kMfmaK; ++kk) a[kk] = 0.f;
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    int it = 0;
+#pragma unroll 1
+    for (int i = 1; i < B.n; ++i)
+      if (chunk >= B.p[i].chunk0) it = i;
+    const LinePass& P = B.p[it];
+    const float* taps = P.taps;
+    const long pos_stride = P.pos_stride;
+    const int ntaps = P.ntaps, r = ntaps / 2, n = P.n;
+    const int C4 = P.C / 4, cpl = (C4 + kLineQ - 1) / kLineQ;
+    const int local = chunk - P.chunk0;
+    const int line = local / cpl, cq = local - line * cpl;
+    const int nch = 4 * min(kLineQ, C4 - cq * kLineQ);          // live channels of the chunk (16, or a partial last chunk)
+    const float* src = P.in + (long)line * P.line_stride + cq * (kLineQ * 4);
+    float* dst = P.out + (long)line * P.line_stride + cq * (kLineQ * 4);
+    const int nblocks = (n + 15) >> 4;
+    const int npos_c = nblocks * 16 + 4 * kMfmaK - 16;          // positions -r .. : what the last block's band reaches
+    __syncthreads();                                            // the previous chunk's readers are done with the LDS
+    if (taps != cur_taps || ntaps != cur_ntaps) {
+      cur_taps = taps, cur_ntaps = ntaps;
+      // A: row = output j of the block (lane & 15), K step kk, slice g  <->  input qi = 4 kk + g of the band (position p0 - r + qi)
+#pragma unroll
+      for (int kk = 0; kk < kMfmaK; ++kk) {
+        const int qi = 4 * kk + g;
+        const int t = ADJ ? 2 * r - (qi - nn) : qi - nn;
+        a[kk] = (t >= 0 && t < ntaps) ? taps[t] : 0.f;
+      }
+      if (ADJ && threadIdx.x < 64) {   // inclusive prefix of the taps by one wave: s_cum[t] = sum of taps[0 .. t-1]
+        float carry = 0.f;
+        for (int t0 = 0; t0 < ntaps; t0 += 64) {
+          const int t = t0 + (int)threadIdx.x;
+          float v = t < ntaps ? taps[t] : 0.f;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const float u = __shfl_up(v, o);
+            if ((int)threadIdx.x >= o) v += u;
+          }
+          if (t < ntaps) s_cum[t + 1] = carry + v;
+          carry += __shfl(v, 63);
+        }
+        if (threadIdx.x == 0) s_cum[0] = 0.f;
+      }
+    }
+    // stage: forward = replicate padding, adjoint = zeros outside; idle channels of a partial chunk are zero.  Eight loads in
+    // flight per thread before the first LDS write (as a plain loop every load waited for the one before it)
+    for (int base = 0; base < npos_c * 4; base += 256 * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * 256 + (int)threadIdx.x;
+        const int q = idx & 3, pos = (idx >> 2) - r;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < npos_c * 4 && 4 * q < nch && (!ADJ || (pos >= 0 && pos < n)))
+          v[u] = ld4(src + (long)min(max(pos, 0), n - 1) * pos_stride + q * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * 256 + (int)threadIdx.x;
+        if (idx < npos_c * 4) *reinterpret_cast<float4*>(s_in + (size_t)(idx >> 2) * 16 + (idx & 3) * 4) = v[u];
+      }
+    }
+    __syncthreads();
+    // adjoint: what the forward's replicate padding read from texel 0 / n - 1 comes back to them (k_blur_line's two sums),
+    // per channel: the four lane groups take every fourth x
+    float e0 = 0.f, e1 = 0.f;
+    if (ADJ) {
+      for (int x = g; x < min(r, n); x += 4) e0 += s_cum[r - x] * s_in[(size_t)(x + r) * 16 + nn];
+      for (int x = max(n - r, 0) + g; x < n; x += 4)
+        e1 += (s_cum[ntaps] - s_cum[min(max(n - x + r, 0), ntaps)]) * s_in[(size_t)(x + r) * 16 + nn];
+      e0 += __shfl_xor(e0, 16), e0 += __shfl_xor(e0, 32);
+      e1 += __shfl_xor(e1, 16), e1 += __shfl_xor(e1, 32);
+    }
+    for (int b0 = 2 * wv; b0 < nblocks; b0 += 8) {
+      const bool two = b0 + 1 < nblocks;
+      blur_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      const float* bp = s_in + (size_t)(16 * b0 + g) * 16 + nn;   // B: K slice g = position p0 - r + 4 kk + g, column = channel
+#if JT_BLUR_ABL & 4   // profiling knob: one K step per block pair (what the matrix products and their LDS reads cost)
+#pragma unroll
+      for (int kk = 0; kk < 1; ++kk) {
+#else
+#pragma unroll
+      for (int kk = 0; kk < kMfmaK; ++kk) {
+#endif
+        const float v0 = bp[kk * 64];
+        const float v1 = two ? bp[kk * 64 + 256] : 0.f;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], v0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], v1, acc1, 0, 0, 0);
+      }
+      // D: register i of lane (g, channel) is output p0 + 4 g + i
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p0 = 16 * b0 + 4 * g + i, p1 = p0 + 16;
+        float o0 = acc0[i], o1 = acc1[i];
+        if (ADJ) {
+          if (p0 == 0) o0 += e0;
+          if (p0 == n - 1) o0 += e1;
+          if (p1 == n - 1) o1 += e1;
+        }
+        if (nn < nch) {
+          if (p0 < n) dst[(long)p0 * pos_stride + nn] = o0;
+          if (two && p1 < n) dst[(long)p1 * pos_stride + nn] = o1;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace jt
 
 using namespace jt;
@@ -395,6 +530,24 @@ static bool launch_line_batch(const BlurPass* passes, int n, hipStream_t st) {
     max_taps = std::max(max_taps, P.ntaps);
   }
   L.total = total;
+  // the matrix-core pass where its tap count and LDS chunk fit (JT_BLUR_MFMA=0, read once: the vector kernel below)
+  static const bool mfma_on = [] { const char* e = getenv("JT_BLUR_MFMA"); return !e || atoi(e) != 0; }();
+  if (mfma_on && max_taps <= kMfmaTaps) {
+    const int npos = (max_n + 15) / 16 * 16 + 4 * kMfmaK - 16;
+    const size_t lds_m = ((size_t)npos * 16 + kMfmaTaps + 1) * sizeof(float);
+    if (lds_m <= 64 * 1024) {
+      static bool mattr[2] = {false, false};
+      if (!mattr[ADJ]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_blur_mfma<ADJ>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  64 * 1024);
+        mattr[ADJ] = true;
+      }
+      const int per_cu_m = std::max(1, std::min(5, (int)(160 * 1024 / (lds_m + 512))));
+      const int blocks_m = std::min(total, 256 * per_cu_m);
+      hipLaunchKernelGGL(k_blur_mfma<ADJ>, dim3(blocks_m), dim3(256), lds_m, st, L, npos);
+      return true;
+    }
+  }
   // [quad][npad] with npad = 2 mod 16 float4s: the four quads of a 16-lane LDS group land on different bank quarters
   int npad = (max_n + kLineP - 1) / kLineP * kLineP + max_taps;
   npad += (18 - (npad % 16)) % 16;

@@ -271,6 +271,151 @@ __global__ __launch_bounds__(256) void k_reg_batch_fwd(RegBatch B, RegDims S, fl
   }
 }
 
+// ---- value AND gradient in one pass (round 5) ---------------------------------------------------------------------------------
+// The gradient of a regulariser does not depend on its value, and the upstream gradients dL/d{L1, TV_density, TV_color} of a
+// training step are the loss weights, which the caller knows BEFORE the forward (host floats, or device memory under hipGraph
+// replay): one launch reads every texel once (plus its neighbours for TV), adds the partial sums AND writes the gradient --
+// k_reg_batch_fwd + k_reg_batch_bwd streamed the same factors back to back (LLFF final grid: 285 MB twice, 107 + 151 us).
+// The gradient is WRITTEN (the render backward's atomics land on top of it: ops.RenderRays, "reg_first").
+template <bool TV>
+__device__ inline void factor_reg_fused_body(const float* __restrict__ x, int H, int W, int C, const float coef[3],
+                                             float* __restrict__ g, float* __restrict__ out, int bid, int nblocks) {
+  __shared__ float red[4][3];
+  const float c0 = coef[0], c1 = coef[1], c2 = coef[2];
+  const unsigned C4 = C / 4;
+  const unsigned total = (unsigned)H * W * C4;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  if (TV && H >= 2 * kRegSeg) {
+    const unsigned nseg = ((unsigned)H + kRegSeg - 1) / kRegSeg, per_row = (unsigned)W * C4, items = nseg * per_row;
+    const size_t rstride = (size_t)W * C;
+    for (unsigned it = bid * blockDim.x + threadIdx.x; it < items; it += (unsigned)nblocks * blockDim.x) {
+      const unsigned seg = it / per_row, q = it - seg * per_row;
+      const int xx = (int)(q / C4);
+      const int y0 = (int)(seg * kRegSeg), y1 = min(y0 + kRegSeg, H);
+      size_t off = (size_t)y0 * rstride + (size_t)q * 4;
+      float4 up = ld4z(x + off - rstride, y0 > 0), v = ld4(x + off);
+      const float ml = xx > 0 ? 1.f : 0.f, mr = xx + 1 < W ? 1.f : 0.f;
+#pragma unroll 2
+      for (int yy = y0; yy < y1; ++yy) {
+        const float4 dn = ld4z(x + off + rstride, yy + 1 < H);
+        const float4 lf = ld4z(x + off - C, xx > 0), rt = ld4z(x + off + C, xx + 1 < W);
+        const float mu = yy > 0 ? 1.f : 0.f, md = yy + 1 < H ? 1.f : 0.f;
+        s0 += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
+        const float dx = md * (dn.x - v.x), dy = md * (dn.y - v.y), dz = md * (dn.z - v.z), dw = md * (dn.w - v.w);
+        const float rx = mr * (rt.x - v.x), ry = mr * (rt.y - v.y), rz = mr * (rt.z - v.z), rw = mr * (rt.w - v.w);
+        s1 += dx * dx + dy * dy + dz * dz + dw * dw;
+        s2 += rx * rx + ry * ry + rz * rz + rw * rw;
+        float4 r;
+        r.x = c0 * ((v.x > 0.f) - (v.x < 0.f)) + 2.f * (c1 * (mu * (v.x - up.x) - dx) + c2 * (ml * (v.x - lf.x) - rx));
+        r.y = c0 * ((v.y > 0.f) - (v.y < 0.f)) + 2.f * (c1 * (mu * (v.y - up.y) - dy) + c2 * (ml * (v.y - lf.y) - ry));
+        r.z = c0 * ((v.z > 0.f) - (v.z < 0.f)) + 2.f * (c1 * (mu * (v.z - up.z) - dz) + c2 * (ml * (v.z - lf.z) - rz));
+        r.w = c0 * ((v.w > 0.f) - (v.w < 0.f)) + 2.f * (c1 * (mu * (v.w - up.w) - dw) + c2 * (ml * (v.w - lf.w) - rw));
+        *reinterpret_cast<float4*>(g + off) = r;
+        up = v;
+        v = dn;
+        off += rstride;
+      }
+    }
+  } else {
+    for (unsigned idx = bid * blockDim.x + threadIdx.x; idx < total; idx += (unsigned)nblocks * blockDim.x) {
+      int xx = 0, yy = 0;
+      if (TV) {
+        const unsigned tex = idx / C4;
+        yy = (int)(tex / (unsigned)W);
+        xx = (int)(tex - (unsigned)yy * W);
+      }
+      const long off = (long)idx * 4;
+      const float4 v = ld4(x + off);
+      s0 += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
+      float4 r;
+      r.x = c0 * ((v.x > 0.f) - (v.x < 0.f));
+      r.y = c0 * ((v.y > 0.f) - (v.y < 0.f));
+      r.z = c0 * ((v.z > 0.f) - (v.z < 0.f));
+      r.w = c0 * ((v.w > 0.f) - (v.w < 0.f));
+      if (TV) {
+        const float4 up = ld4z(x + off - (long)W * C, yy > 0), dn = ld4z(x + off + (long)W * C, yy + 1 < H);
+        const float4 lf = ld4z(x + off - C, xx > 0), rt = ld4z(x + off + C, xx + 1 < W);
+        const float mu = yy > 0 ? 1.f : 0.f, md = yy + 1 < H ? 1.f : 0.f, ml = xx > 0 ? 1.f : 0.f,
+                    mr = xx + 1 < W ? 1.f : 0.f;
+        const float dx = md * (dn.x - v.x), dy = md * (dn.y - v.y), dz = md * (dn.z - v.z), dw = md * (dn.w - v.w);
+        const float rx = mr * (rt.x - v.x), ry = mr * (rt.y - v.y), rz = mr * (rt.z - v.z), rw = mr * (rt.w - v.w);
+        s1 += dx * dx + dy * dy + dz * dz + dw * dw;
+        s2 += rx * rx + ry * ry + rz * rz + rw * rw;
+        r.x += 2.f * (c1 * (mu * (v.x - up.x) - dx) + c2 * (ml * (v.x - lf.x) - rx));
+        r.y += 2.f * (c1 * (mu * (v.y - up.y) - dy) + c2 * (ml * (v.y - lf.y) - ry));
+        r.z += 2.f * (c1 * (mu * (v.z - up.z) - dz) + c2 * (ml * (v.z - lf.z) - rz));
+        r.w += 2.f * (c1 * (mu * (v.w - up.w) - dw) + c2 * (ml * (v.w - lf.w) - rw));
+      }
+      *reinterpret_cast<float4*>(g + off) = r;
+    }
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[wv][0] = s0;
+    red[wv][1] = s1;
+    red[wv][2] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    atomicAdd(out + k, red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+  }
+}
+
+struct RegWeights {
+  float w[3];          // dL/d{L1, TV_density, TV_color} as host values ...
+  const float* dev;    // ... or (non-NULL) three floats in device memory
+};
+
+__global__ __launch_bounds__(256) void k_reg_batch_fused(RegBatch B, RegDims S, RegWeights Wt, float* __restrict__ scratch,
+                                                         float* __restrict__ out3) {
+  int it = 0;
+#pragma unroll 1
+  for (int i = 1; i < B.n; ++i)
+    if ((int)blockIdx.x >= B.t[i].block0) it = i;
+  const RegBatchItem& T = B.t[it];
+  const int bid = blockIdx.x - T.block0;
+  const int i = T.slot;  // 0-2 density planes, 3-5 density lines, 6-8 appearance planes
+  const float g0 = Wt.dev ? Wt.dev[0] : Wt.w[0], g1 = Wt.dev ? Wt.dev[1] : Wt.w[1], g2 = Wt.dev ? Wt.dev[2] : Wt.w[2];
+  float coef[3] = {0.f, 0.f, 0.f};
+  if (i < 6) coef[0] = g0 / ((float)T.H * T.W * T.C);
+  if (T.tv) {
+    const float gt = i < 3 ? g1 : g2;
+    if (T.H > 1) coef[1] = gt * 2e-2f / ((float)T.C * (T.H - 1) * T.W);
+    if (T.W > 1) coef[2] = gt * 2e-2f / ((float)T.C * T.H * (T.W - 1));
+  }
+  float* sums = scratch + (bid % kRegShards) * 36 + T.slot * 3;
+  if (T.tv)
+    factor_reg_fused_body<true>(T.x, T.H, T.W, T.C, coef, T.g, sums, bid, T.nblocks);
+  else
+    factor_reg_fused_body<false>(T.x, T.H, T.W, T.C, coef, T.g, sums, bid, T.nblocks);
+  // tickets and the combine step: as k_reg_batch_fwd
+  __shared__ int s_last;
+  __shared__ float s_sums[36];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* cnt = reinterpret_cast<unsigned*>(scratch + kRegCounters);
+    bool last = false;
+    if (atomicAdd(cnt + 1 + T.slot, 1u) == (unsigned)T.nblocks - 1u) last = atomicAdd(cnt, 1u) == (unsigned)B.n - 1u;
+    s_last = last;
+  }
+  __syncthreads();
+  if (s_last) {
+    if (threadIdx.x < 36) {
+      float a = 0.f;
+      for (int sh = 0; sh < kRegShards; ++sh) a += atomicExch(scratch + sh * 36 + threadIdx.x, 0.f);
+      s_sums[threadIdx.x] = a;
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 10) atomicExch(reinterpret_cast<unsigned*>(scratch + kRegCounters) + (threadIdx.x - 64), 0u);
+    __syncthreads();
+    if (threadIdx.x == 0) reg_combine(s_sums, S, out3);
+  }
+}
+
 // (the coefficient triple of the block's tensor from the upstream gradients g3 = dL/d{L1, TV_density, TV_color} is three
 //  divisions: every block works it out for itself instead of a launch of its own in front of this one)
 __global__ __launch_bounds__(256) void k_reg_batch_bwd(RegBatch B, const float* __restrict__ g3, int accumulate) {
@@ -409,6 +554,40 @@ extern "C" int jt_reg_losses_backward(const JtFactors* factors, const int32_t* p
     nblk += blocks;
   }
   hipLaunchKernelGGL(k_reg_batch_bwd, dim3(nblk), dim3(256), 0, st, B, g3, accumulate ? 1 : 0);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
+extern "C" int jt_reg_losses_fused(const JtFactors* factors, const int32_t* plane_hw_line, int n_comp_density, int n_comp_app,
+                                   int with_tv_density, int with_tv_app, const float* w3_host, const float* w3_dev,
+                                   const JtFactors* g_factors, float* scratch640, float* out3, void* stream) {
+  RegSet S;
+  int rc = reg_set(factors, g_factors, plane_hw_line, n_comp_density, n_comp_app, &S);
+  if (rc) return rc;
+  if (!scratch640 || !out3 || !g_factors || (!w3_host && !w3_dev)) return JT_ERR_ARG;
+  if (jt_deterministic()) return JT_ERR_UNSUPPORTED;  // (the fixed summation order lives in the two-launch form)
+  hipStream_t st = (hipStream_t)stream;
+  RegBatch B;
+  B.n = 0;
+  int nblk = 0;
+  for (int i = 0; i < 9; ++i) {
+    const bool tv = (i < 3 && with_tv_density) || (i >= 6 && with_tv_app);
+    if (i >= 6 && !tv) continue;  // appearance planes only enter TV_color
+    const RegTensor& t = S.t[i];
+    if (!t.g) return JT_ERR_ARG;
+    long total = (long)t.H * t.W * (t.C / 4);
+    if (total >= (1l << 31)) return JT_ERR_UNSUPPORTED;
+    static const long max_blocks = [] { const char* e = getenv("JT_REG_FUSED_BLOCKS"); return e ? atol(e) : 0L; }();
+    int blocks = (int)min((total + 255) / 256, max_blocks > 0 ? max_blocks : (tv ? 1024L : 256L));
+    B.t[B.n++] = {t.x, t.g, t.H, t.W, t.C, tv ? 1 : 0, i, nblk, blocks};
+    nblk += blocks;
+  }
+  RegDims Dm;
+  for (int i = 0; i < 9; ++i) Dm.H[i] = S.t[i].H, Dm.W[i] = S.t[i].W, Dm.C[i] = S.t[i].C;
+  RegWeights Wt;
+  for (int k = 0; k < 3; ++k) Wt.w[k] = w3_host ? w3_host[k] : 0.f;
+  Wt.dev = w3_host ? nullptr : w3_dev;
+  hipLaunchKernelGGL(k_reg_batch_fused, dim3(nblk), dim3(256), 0, st, B, Dm, Wt, scratch640, out3);
   JT_LAUNCH_CHECK();
   return JT_OK;
 }

@@ -447,6 +447,12 @@ class Graph(torch.nn.Module):
             opt.nerf.depth.range[0] = tf.near_far[0]
         view_pe = interp_schedule(self.nerf.progress_host, opt.c2f_view_pe_schedule) if _has(opt, "c2f_view_pe_schedule") else 1.0
         fea_pe = interp_schedule(self.nerf.progress_host, opt.c2f_fea_pe_schedule) if _has(opt, "c2f_fea_pe_schedule") else 1.0
+        # a training render: tell the scene class which weights Model.summarize_loss will put on the regularisers (the
+        # upstream gradient of their sums), so that value and gradient come out of one launch (ops.RenderRays)
+        tf.__dict__.pop("reg_weights_hint", None)
+        provider = self.__dict__.get("reg_weight_provider")
+        if mode == "train" and provider is not None:
+            tf.reg_weights_hint = provider(opt)
         rgb, depth, opacity = tf.forward(
             opt, center=center.reshape(-1, 3), ray_dir=ray.reshape(-1, 3), white_bg=opt.nerf.setbg_opaque,
             is_train=(mode == "train" and opt.nerf.sample_stratified),
@@ -561,6 +567,26 @@ class Model(torch.nn.Module):
             self.graph.pose_noise = torch.nn.Parameter(noise.detach(), requires_grad=False)
         self.graph.se3_refine = torch.nn.Embedding(n_views, 6).to(opt.device)
         torch.nn.init.zeros_(self.graph.se3_refine.weight)
+        self._install_reg_weight_provider()
+
+    def _install_reg_weight_provider(self):
+        """Graph.render_rays asks this for the regularisers' loss weights of the iteration being rendered: the device-resident
+        weight vector while a hipGraph is captured / replayed (ops.LOSS_WEIGHTS_STATIC, poked in front of every replay), the
+        host values of fused_loss_weights otherwise -- exactly what summarize_loss will multiply the sums by."""
+        import weakref
+        me = weakref.ref(self)
+
+        def provider(opt):
+            m = me()
+            if m is None or not _has(opt, "loss_weight") or opt.loss_weight.render is None:
+                return None
+            if ops.LOSS_WEIGHTS_STATIC is not None:
+                return ops.LOSS_WEIGHTS_STATIC[1:4]
+            try:
+                return tuple(m.fused_loss_weights(opt)[1:])
+            except (AttributeError, KeyError, TypeError):
+                return None
+        self.graph.__dict__["reg_weight_provider"] = provider
 
     def setup_optimizer(self, opt):
         nerf = self.graph.nerf

@@ -197,6 +197,23 @@ def _reg_scratch(dev):
     return _REG_SCRATCH[key]
 
 
+# value + gradient of the regularisers in one launch at forward time (RenderRays; JT_FUSE_REG=0 turns it off)
+FUSE_REG_GRADIENT = os.environ.get("JT_FUSE_REG", "1") != "0"
+REG_FUSION_STATS = {"trusted": 0, "rewritten": 0}
+
+
+def _reg_hint_holds(g_reg, hint):
+    """Is the upstream gradient of reg3 that arrived in the backward the one the forward was told to expect?  A device
+    hint (hipGraph replay: the loss-weight vector in static device memory): the same three floats by ADDRESS.  Host floats:
+    LossSum.backward tags the gradient it returns for a unit upstream gradient with the weights it was built from."""
+    if g_reg is None or hint is None:
+        return False
+    if torch.is_tensor(hint):
+        return g_reg.numel() == 3 and g_reg.data_ptr() == hint.data_ptr() and g_reg.is_contiguous()
+    tag = getattr(g_reg, "_jt_w", None)
+    return tag is not None and tuple(float(v) for v in tag) == tuple(float(v) for v in hint)
+
+
 def _zeros_flat(groups, with_flat=False, unzeroed=()):
     """Zero tensors shaped like the tensors of `groups` (a list of lists), carved out of ONE flat buffer: one fill
     launch instead of one per tensor (19 per backward).  Offsets are rounded up to 16 bytes.  with_flat: also
@@ -497,9 +514,32 @@ class RenderRays(torch.autograd.Function):
             Cd, Ca = sdp[0].shape[2], sap[0].shape[2]
             scratch = _reg_scratch(dev)
             reg3 = torch.empty(3, **f32)
-            check(lib.jt_reg_losses_forward(fac, (ctypes.c_int32 * 9)(*hw), Cd, Ca, int(bool(flags[0])),
-                                            int(bool(flags[1])), ptr(scratch), ptr(reg3), st), "jt_reg_losses_forward")
             ctx.reg = (hw, Cd, Ca, bool(flags[0]), bool(flags[1]))
+            ctx.pre = None
+            hint = getattr(cfg, "reg_weights", None)   # dL/d reg3 as this step's loss weights will make it, if the caller knows
+            nig = ctx.needs_input_grad
+            if (hint is not None and FUSE_REG_GRADIENT and all(nig[5:14]) and _DP["world"] <= 1 and not _DP["force"]
+                    and not bool(lib.jt_set_deterministic(-1))):
+                # value AND gradient in one launch (jt_reg_losses_fused): the gradient buffers of this node's backward are
+                # created HERE, the regularisers' gradient is written into them (it covers every element of the density
+                # factors and, with TV on the colours, of the appearance planes: no zero fill for those), and the backward
+                # lets the render gradient's atomics land on top -- provided dL/d reg3 then IS the hint (checked there;
+                # otherwise the two-launch backward overwrites what was written here)
+                want_mlp = any(nig[17:24])
+                skip = (0, 1, 2) if ctx.reg[4] else (0, 1)
+                groups = [sdp, sdl, sap, sal] + ([mlp_t] if want_mlp else [])
+                outs, gflat, spans = _zeros_flat(groups, with_flat=True, unzeroed=skip)
+                gfac = _factors_struct(*outs[:4])
+                if torch.is_tensor(hint):
+                    w_host, w_dev = None, ptr(hint)
+                else:
+                    w_host, w_dev = (ctypes.c_float * 3)(*[float(v) for v in hint]), None
+                check(lib.jt_reg_losses_fused(fac, (ctypes.c_int32 * 9)(*hw), Cd, Ca, int(ctx.reg[3]), int(ctx.reg[4]), w_host,
+                                              w_dev, gfac, ptr(scratch), ptr(reg3), st), "jt_reg_losses_fused")
+                ctx.pre = (outs, gflat, spans, hint, want_mlp)
+            else:
+                check(lib.jt_reg_losses_forward(fac, (ctypes.c_int32 * 9)(*hw), Cd, Ca, int(bool(flags[0])),
+                                                int(bool(flags[1])), ptr(scratch), ptr(reg3), st), "jt_reg_losses_forward")
         return rgb, depth, opacity, reg3
 
     @staticmethod
@@ -538,6 +578,22 @@ class RenderRays(torch.autograd.Function):
             gfac_float = _factors_struct(gdp, gdl, gap, gal)
             fused_mlp_zero = False
             g_mlp_z = None
+        elif want_fac and getattr(ctx, "pre", None) is not None and ctx.pre[4] == fused_mlp_zero:
+            # the forward created the buffers and wrote the regularisers' gradient for the weights it was told (ctx.pre)
+            outs, gflat, spans, hint, _ = ctx.pre
+            gdp, gdl, gap, gal = outs[:4]
+            g_mlp_z = outs[4] if fused_mlp_zero else None
+            gfac = _factors_struct(gdp, gdl, gap, gal)
+            reg_first = True
+            if not _reg_hint_holds(g_reg, hint):
+                # dL/d reg3 is not what the forward assumed (or nobody used reg3): the two-launch form overwrites it
+                hw, Cd, Ca, wd, wa = ctx.reg
+                g3c = torch.zeros(3, **f32) if g_reg is None else g_reg.contiguous().float()
+                check(lib.jt_reg_losses_backward(fac, (ctypes.c_int32 * 9)(*hw), Cd, Ca, ptr(g3c), int(wd), int(wa), gfac, 0,
+                                                 ptr(torch.empty(36, **f32)), st), "jt_reg_losses_backward")
+                REG_FUSION_STATS["rewritten"] += 1
+            else:
+                REG_FUSION_STATS["trusted"] += 1
         elif want_fac:
             # gradient buffers (channel-last storage; the kernels accumulate with atomics).  Single process with the
             # regularisers in this node: their gradient covers every element of the density factors (L1) and, with TV on
@@ -986,6 +1042,8 @@ class LossSum(torch.autograd.Function):
         g_render = torch.empty(1, device=gc.device, dtype=torch.float32)
         g_reg = torch.empty(3, device=gc.device, dtype=torch.float32)
         check(lib.jt_loss_sum_backward(ptr(gc), *ctx.w, ptr(g_render), ptr(g_reg), _stream()), "jt_loss_sum_backward")
+        if unit:
+            g_reg._jt_w = ctx.w[1:]   # "these ARE the weights": RenderRays' fused regulariser gradient checks it (_reg_hint_holds)
         if unit and not torch.cuda.is_current_stream_capturing():
             LossSum._last = ((ctx.w, str(g.device)), g_render, g_reg)
         return g_render.reshape(ctx.render_shape), g_reg, None, None, None, None, None, None

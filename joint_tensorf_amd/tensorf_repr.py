@@ -511,6 +511,9 @@ class BAT_VMSplit(torch.nn.Module):
                     and all(p.requires_grad for p in dP + dL + aP))
         if fuse_reg:
             cfg.reg_flags = (float(lw.get("TV_density", 0) or 0) != 0.0, float(lw.get("TV_color", 0) or 0) != 0.0)
+            # what dL/d(L1, TV_density, TV_color) of THIS call is going to be, if the caller said so (bat_hip.Graph.render_rays
+            # from Model.fused_loss_weights): lets the render node write the regularisers' gradient in its forward launch
+            cfg.reg_weights = self.__dict__.pop("reg_weights_hint", None)
         rgb, depth, opacity = ops.render_rays(cfg, center, ray_dir, jitter, zvals, dP, dL, aP, aL,
                                               self.basis_mat.weight, self.renderModule.weights())
         self.last_render_cfg = cfg  # the scene description of the last forward (incl. cfg.shade_lists)

@@ -382,19 +382,16 @@ def _oracle_rendered(model, opt):
     return tf
 
 
-@pytest.mark.skipif(__import__("os").environ.get("JT_LONG_TESTS") != "1", reason="ten minutes: set JT_LONG_TESTS=1")
-def test_llff_full_schedule_with_the_oracle_render_ends_where_the_hip_path_ends():
-    """Round-3 verdict item 3, the alternative it allows: "or commit the oracle-side curve showing the reference algorithm fails
-    identically".  The WHOLE compressed bat_llff_VM_MLP schedule (5 000 iterations, five grid stages) on LLFF_SCENE twice from
-    the same seed: once through the HIP renderer, once with the renderer replaced by the oracle's stock torch ops + torch
-    autograd (`_oracle_rendered`).  Both runs are chaotic in their details (Adam amplifies round-off over 5 000 steps), so the
-    assertion is on where they END: camera-centre recovery within a factor two of each other, held-out PSNR within 6 dB,
-    neither reaching the 5 x the verdict asked of the scene."""
+def _hip_and_oracle_rendered_runs(scene_args, every):
+    """The same compressed bat_llff_VM_MLP run twice from the same seed: through the HIP renderer, and with `BAT_VMSplit.forward`
+    replaced by the oracle's stock torch ops + torch autograd (`_oracle_rendered`).  Returns {"hip": ..., "oracle": ...} with
+    the start / end pose errors, the pose-error curve every `every` iterations, the held-out PSNR (evaluated through the
+    product path on both sides) and the final grid."""
     import json
     cv = _converge()
     out = {}
     for name in ("hip", "oracle"):
-        opt, model = cv.build(_args(graph=False, **LLFF_SCENE), device=DEV)
+        opt, model = cv.build(_args(graph=False, **scene_args), device=DEV)
         r0, t0 = cv.pose_errors(opt, model)
         tf = model.graph.nerf.tensorf
         if name == "oracle":
@@ -404,7 +401,7 @@ def test_llff_full_schedule_with_the_oracle_render_ends_where_the_hip_path_ends(
 
         def after(o, it=None, model=model, opt=opt, curve=curve, orig_after=orig_after):
             orig_after(o, it)
-            if model.it % 500 == 0:
+            if model.it % every == 0:
                 curve.append((model.it,) + tuple(round(v, 4) for v in cv.pose_errors(opt, model)))
         model.after_iteration = after
         model.train(opt)
@@ -414,12 +411,42 @@ def test_llff_full_schedule_with_the_oracle_render_ends_where_the_hip_path_ends(
             del tf.forward                      # evaluation of the trained state through the product path on both sides
         res = model.evaluate_full(opt)
         out[name] = dict(rot_deg=(round(r0, 3), round(r1, 3)), rot_rel_deg_end=round(rrel, 3), trans=(round(t0, 4), round(t1, 4)),
-                         trans_gain=round(t0 / t1, 2), psnr=round(res.psnr, 2), grid=tf.gridSize.tolist(), curve=curve)
+                         trans_gain=round(t0 / t1, 2), psnr=round(res.psnr, 2), grid=tf.gridSize.tolist(), curve=curve,
+                         iterations=model.it)
         print(name, json.dumps(out[name]), flush=True)
         del model
         torch.cuda.empty_cache()
+    return out
+
+
+@pytest.mark.skipif(__import__("os").environ.get("JT_LONG_TESTS") != "1", reason="twenty minutes: set JT_LONG_TESTS=1")
+def test_llff_full_schedule_with_the_oracle_render_ends_where_the_hip_path_ends():
+    """Round-3 verdict item 3, the alternative it allows: "or commit the oracle-side curve showing the reference algorithm fails
+    identically".  The WHOLE compressed bat_llff_VM_MLP schedule (5 000 iterations, five grid stages) on LLFF_SCENE twice from
+    the same seed: once through the HIP renderer, once with the renderer replaced by the oracle's stock torch ops + torch
+    autograd (`_oracle_rendered`).  Both runs are chaotic in their details (Adam amplifies round-off over 5 000 steps), so the
+    assertion is on where they END: camera-centre recovery within a factor two of each other, held-out PSNR within 6 dB,
+    neither reaching the 5 x the verdict asked of the scene."""
+    out = _hip_and_oracle_rendered_runs(LLFF_SCENE, 500)
     h, o = out["hip"], out["oracle"]
     assert h["grid"] == o["grid"] == [771, 859, 771]
     assert 0.5 < h["trans_gain"] / o["trans_gain"] < 2.0
     assert abs(h["psnr"] - o["psnr"]) < 6.0
     assert o["trans_gain"] < 5.0
+
+
+def test_llff_short_schedule_with_the_oracle_render_ends_where_the_hip_path_ends():
+    """The same comparison in a form the default suite can afford: the schedule compressed a hundred times
+    (500 iterations through all five grid stages, the final grid capped at 2 M voxels so that the stock-op renderer stays in
+    seconds), 20 views of 120 pixels.  At this length neither run recovers much; what is asserted is that the two renderers
+    take the joint optimisation to the same place: camera-centre error within 25 % of each other at the end and at every
+    recorded point of the curve, relative rotations within a degree, held-out PSNR within 3 dB."""
+    scene = dict(LLFF_SCENE, views=20, image_size=120, compress=100.0, n_voxel_final=2000000)
+    out = _hip_and_oracle_rendered_runs(scene, 100)
+    h, o = out["hip"], out["oracle"]
+    assert h["iterations"] == o["iterations"] == 500 and h["grid"] == o["grid"]
+    assert abs(h["trans"][1] - o["trans"][1]) <= 0.25 * o["trans"][1], (h, o)
+    for (ih, rh, th), (io, ro, to) in zip(h["curve"], o["curve"]):
+        assert ih == io and abs(th - to) <= 0.25 * to + 0.002, (h["curve"], o["curve"])
+    assert abs(h["rot_rel_deg_end"] - o["rot_rel_deg_end"]) <= 1.0, (h, o)
+    assert abs(h["psnr"] - o["psnr"]) < 3.0, (h, o)

@@ -272,6 +272,59 @@ def test_reg_losses_vs_oracle():
     assert all(dev[i].grad is None for i in range(9, 12))
 
 
+@pytest.mark.parametrize("tv", [(True, True), (False, False), (True, False)])
+@pytest.mark.parametrize("dev_weights", [False, True])
+def test_reg_losses_fused_equals_forward_plus_backward(tv, dev_weights):
+    """jt_reg_losses_fused (value and gradient of L1 / TV_density / TV_color in ONE launch, round 5) against the two-launch form
+    it replaces in a training step, on LLFF-shaped factors (non-square planes of 16 / 20 channels, TV row walk and the short
+    general loop): the three sums to float-sum noise, every gradient to 2e-6 of the tensor's maximum (the same expression per
+    element up to the compiler's choice of fused multiply-adds), with the
+    upstream gradients as host floats and as three floats in device memory."""
+    import ctypes
+    from joint_tensorf_amd import ops
+    from joint_tensorf_amd._lib import lib, ptr, check
+    g = torch.Generator().manual_seed(21)
+    grid = [40, 45, 38]
+    p = O.init_params(grid, density_n_comp=(16, 16, 16), app_n_comp=(20, 20, 20), app_dim=20, featureC=32,
+                      shadingMode="MLP_Fea_WeakView", scale=0.3, bias=-0.1, generator=g)
+    st = [[ops.factor_storage(t.detach() - 0.05).to(DEV).contiguous() for t in p[grp]]
+          for grp in ("density_plane", "density_line", "app_plane", "app_line")]
+    fac = ops._factors_struct(*st)
+    hw = []
+    for i in range(3):
+        H, W, _ = st[0][i].shape
+        hw += [H, W, st[1][i].shape[0]]
+    hw_arr = (ctypes.c_int32 * 9)(*hw)
+    w3 = [0.37, 1.9 if tv[0] else 0.0, 0.6 if tv[1] else 0.0]   # (a term that is not evaluated has weight zero in the run)
+    stream = ops._stream()
+    scratch = ops._reg_scratch(st[0][0].device)
+    # two launches
+    ga = [[torch.full_like(t, 7.0) for t in grp] for grp in st]
+    out_a = torch.empty(3, device=DEV)
+    check(lib.jt_reg_losses_forward(fac, hw_arr, 16, 20, int(tv[0]), int(tv[1]), ptr(scratch), ptr(out_a), stream), "fwd")
+    g3 = torch.tensor(w3, device=DEV)
+    check(lib.jt_reg_losses_backward(fac, hw_arr, 16, 20, ptr(g3), int(tv[0]), int(tv[1]), ops._factors_struct(*ga), 0,
+                                     ptr(torch.empty(36, device=DEV)), stream), "bwd")
+    # one launch
+    gb = [[torch.full_like(t, 7.0) for t in grp] for grp in st]
+    out_b = torch.empty(3, device=DEV)
+    w_host = None if dev_weights else (ctypes.c_float * 3)(*w3)
+    w_dev = ptr(g3) if dev_weights else None
+    check(lib.jt_reg_losses_fused(fac, hw_arr, 16, 20, int(tv[0]), int(tv[1]), w_host, w_dev, ops._factors_struct(*gb),
+                                  ptr(scratch), ptr(out_b), stream), "fused")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out_b.cpu().numpy(), out_a.cpu().numpy(), rtol=2e-6)
+    for grp in range(4):
+        for i in range(3):
+            touched = grp < 2 or (grp == 2 and tv[1])
+            if touched:
+                # (a density plane without TV: the backward's element expression is the L1 term alone in both forms)
+                assert _rel(gb[grp][i].cpu().numpy(), ga[grp][i].cpu().numpy()) < 2e-6, (grp, i)
+            else:
+                assert torch.all(gb[grp][i] == 7.0) and torch.all(ga[grp][i] == 7.0)
+    assert int((scratch.view(torch.int32) != 0).sum()) == 0
+
+
 def test_reg_losses_scratch_is_left_zero_and_values_repeat():
     """The one-launch regulariser forward sums into a persistent per-device scratch that its last workgroup reads AND resets
     with returning atomics behind relaxed tickets (csrc/jt_reg.hip: no release fence, the sums are memory-side atomics).  A
