@@ -115,7 +115,8 @@ class NeRF(torch.nn.Module):
     def _find_resolution(self, opt, n_voxels):
         lo, hi = self.bbox[0], self.bbox[1]
         voxel = ((hi - lo).prod() / n_voxels).pow(1 / 3)
-        scale = torch.tensor(opt.train_schedule.resolution_scale_init)
+        # (the box follows the AABB shrink of an alpha-mask update onto the device: the yaml's per-axis scale goes where it is)
+        scale = torch.as_tensor(opt.train_schedule.resolution_scale_init, dtype=lo.dtype, device=lo.device)
         return ((hi - lo) / voxel * scale).long().tolist()
 
     def _find_n_samples(self, opt, resolution):

@@ -382,7 +382,7 @@ def _oracle_rendered(model, opt):
     return tf
 
 
-def _hip_and_oracle_rendered_runs(scene_args, every):
+def _hip_and_oracle_rendered_runs(scene_args, every, no_alpha_mask=False):
     """The same compressed bat_llff_VM_MLP run twice from the same seed: through the HIP renderer, and with `BAT_VMSplit.forward`
     replaced by the oracle's stock torch ops + torch autograd (`_oracle_rendered`).  Returns {"hip": ..., "oracle": ...} with
     the start / end pose errors, the pose-error curve every `every` iterations, the held-out PSNR (evaluated through the
@@ -392,6 +392,13 @@ def _hip_and_oracle_rendered_runs(scene_args, every):
     out = {}
     for name in ("hip", "oracle"):
         opt, model = cv.build(_args(graph=False, **scene_args), device=DEV)
+        if no_alpha_mask:
+            # (a final grid below 256^3 would trigger the alpha-mask update + AABB shrink of model/tensorf.py:480-489, which the
+            #  BAT yamls' own schedules never reach and the stock-op stand-in does not carry: keep the first entry -- the L1
+            #  weight switches there -- and move the updates themselves past the end of the run)
+            first = opt.train_schedule.update_alphamask_iters[0]
+            opt.train_schedule.update_alphamask_iters = [first] + [10 ** 9]
+            model.graph.nerf._update_alphamask = lambda *a, **k: None
         r0, t0 = cv.pose_errors(opt, model)
         tf = model.graph.nerf.tensorf
         if name == "oracle":
@@ -436,15 +443,17 @@ def test_llff_full_schedule_with_the_oracle_render_ends_where_the_hip_path_ends(
 
 
 def test_llff_short_schedule_with_the_oracle_render_ends_where_the_hip_path_ends():
-    """The same comparison in a form the default suite can afford: the schedule compressed a hundred times
-    (500 iterations through all five grid stages, the final grid capped at 2 M voxels so that the stock-op renderer stays in
-    seconds), 20 views of 120 pixels.  At this length neither run recovers much; what is asserted is that the two renderers
+    """The same comparison in a form the default suite can afford: the schedule compressed fifty times
+    (1 000 iterations through all five grid stages, 2 048 nominal rays, the final grid capped at 2 M voxels so that the stock-op
+    renderer stays in seconds; the alpha-mask updates such a small grid would trigger are switched off on both sides), 20 views
+    of 120 pixels.  Measured at compress 40 / schedule rays: camera-centre error 0.1787 (HIP) / 0.1773 (oracle render), every
+    point of the two curves within 2 %, relative rotations 1.7 / 1.4 degrees, 18.7 / 19.8 dB.  At this length neither run recovers much; what is asserted is that the two renderers
     take the joint optimisation to the same place: camera-centre error within 25 % of each other at the end and at every
     recorded point of the curve, relative rotations within a degree, held-out PSNR within 3 dB."""
-    scene = dict(LLFF_SCENE, views=20, image_size=120, compress=100.0, n_voxel_final=2000000)
-    out = _hip_and_oracle_rendered_runs(scene, 100)
+    scene = dict(LLFF_SCENE, views=20, image_size=120, compress=50.0, n_voxel_final=2000000, n_rays=2048)
+    out = _hip_and_oracle_rendered_runs(scene, 250, no_alpha_mask=True)
     h, o = out["hip"], out["oracle"]
-    assert h["iterations"] == o["iterations"] == 500 and h["grid"] == o["grid"]
+    assert h["iterations"] == o["iterations"] == 1000 and h["grid"] == o["grid"]
     assert abs(h["trans"][1] - o["trans"][1]) <= 0.25 * o["trans"][1], (h, o)
     for (ih, rh, th), (io, ro, to) in zip(h["curve"], o["curve"]):
         assert ih == io and abs(th - to) <= 0.25 * to + 0.002, (h["curve"], o["curve"])
