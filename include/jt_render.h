@@ -311,28 +311,8 @@ int jt_shade_backward(const JtScene* scene, const JtFactors* factors, const JtMl
                       void* workspace, size_t workspace_bytes, int flags, void* stream, void* aux_stream,
                       void* ev_fork, void* ev_join);
 
-/* ---------------------------------------------------------------------------------------------
- * Single-launch render + photometric loss + backward to the rays (csrc/jt_fused.hip) -- test-time pose optimisation,
- * model/bat.py:265-292: per iteration Graph.forward(mode "test-optim") -> compute_loss -> loss.all.backward() with only a
- * 6-vector trained (scene frozen).  Replaces, for that mode, tensorf.Graph.render_rays + BatBase.forward
- * (model/tensorf.py:169-267, batBase.py:44-165), the render term of compute_loss (model/tensorf.py:96-124 with
- * base.py:259-261's mean over the 3 R colour values) and autograd's walk back to (center, ray_dir): one wave owns one ray
- * from its first sample to its gradient, nothing is recorded between forward and backward.
- *   rays_o / rays_d [R][3]; zvals [S] for NDC scenes (no jitter at test time); image [views][3][image_pixels] and
- *   ray_idx [rays_per_view] (int64): ray r looks at pixel ray_idx[r % rays_per_view] of view r / rays_per_view.
- *   loss_scale = 1 / (3 R) times whatever weight the caller wants folded in.  Values are assumed finite (the mean is
- *   over all 3 R values; the reference's nanmean would drop NaNs -- the caller's non-finite guard reports those).
- *   out: rgb [R][3], depth [R], opacity [R], sqerr [R] (per-ray sum of squared colour differences), loss [1] =
- *   loss_scale * sum(sqerr), g_rays_o / g_rays_d [R][3] = d loss / d rays (plain stores: bit-reproducible).
- *   workspace: jt_pose_fused_workspace_bytes(scene) bytes, ZERO before the first launch that uses it (its head holds the
- *   loss accumulator and an arrival counter, which every launch leaves zeroed again); contents otherwise scratch.
- * No blur (the caller blurs factors itself if a schedule asks for it and hands the blurred ones), alpha mask honoured. */
-size_t jt_pose_fused_workspace_bytes(const JtScene* scene);
-int jt_pose_fused(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp, const float* rays_o,
-                  const float* rays_d, const float* zvals, int n_rays, const float* image, const int64_t* ray_idx,
-                  int rays_per_view, int image_pixels, float loss_scale, float* rgb, float* depth, float* opacity,
-                  float* sqerr, float* loss, float* g_rays_o, float* g_rays_d, void* workspace, size_t workspace_bytes,
-                  void* stream);
+/* (The single-launch test-time kernel jt_pose_fused lives in an OPTIONAL module of its own since round 5: include/jt_fused.h,
+ * libjt_fused.so -- it is slower than the staged kernels it would replace and no default path uses it.) */
 
 /* ---------------------------------------------------------------------------------------------
  * Regularisers over one channel-last factor [H][W][C] (a line is W = 1) in a single pass.

@@ -128,14 +128,38 @@ SIGNATURES = {
     "jt_factor_reg_forward": (I, [P, I, I, I, P, P]),
     "jt_factor_reg_backward": (I, [P, I, I, I, P, P, I, P]),
     "jt_shade_forward": (I, [SP, FP, MP, P, P, P, P, P, P, I, P, P, P, P, I, P, ctypes.c_size_t, I, P]),
-    "jt_pose_fused_workspace_bytes": (ctypes.c_size_t, [SP]),
-    "jt_pose_fused": (I, [SP, FP, MP, P, P, P, I, P, P, I, I, F, P, P, P, P, P, P, P, P, ctypes.c_size_t, P]),
     "jt_shade_backward": (I, [SP, FP, MP, P, P, P, P, P, P, I, P, P, P, P, P, FP, MP, P, I, P, ctypes.c_size_t, I, P, P, P, P]),
 }
 
 
+# the OPTIONAL module include/jt_fused.h declares (libjt_fused.so: the single-launch test-time kernel, loaded on demand)
+FUSED_SIGNATURES = {
+    "jt_pose_fused_workspace_bytes": (ctypes.c_size_t, [SP]),
+    "jt_pose_fused": (I, [SP, FP, MP, P, P, P, I, P, P, I, I, F, P, P, P, P, P, P, P, P, ctypes.c_size_t, P]),
+}
+FUSED_LIB_PATH = os.path.join(HERE, "lib", "libjt_fused.so")
+_FUSED = []
+
+
 class JtError(RuntimeError):
     pass
+
+
+def fused_lib():
+    """libjt_fused.so, loaded the first time somebody asks for the single-launch kernel (opt.optim.test_fused).  A library
+    variant that still carries the two symbols itself (tools/build_variant.py builds every source into one object) serves them."""
+    if not _FUSED:
+        src = lib if hasattr(lib, "jt_pose_fused") else None
+        if src is None:
+            if not os.path.exists(FUSED_LIB_PATH):
+                raise ImportError("joint_tensorf_amd: %s is missing -- `python joint_tensorf_amd/build.py` builds it" % FUSED_LIB_PATH)
+            src = ctypes.CDLL(FUSED_LIB_PATH)
+        for name, (res, args) in FUSED_SIGNATURES.items():
+            fn = getattr(src, name)
+            fn.restype = res
+            fn.argtypes = args
+        _FUSED.append(src)
+    return _FUSED[0]
 
 
 def header_version():

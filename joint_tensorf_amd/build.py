@@ -10,8 +10,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "lib", "libjt_render.so")
-SRCS = sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")))
-HDRS = sorted(glob.glob(os.path.join(HERE, "csrc", "*.h"))) + [os.path.join(ROOT, "include", "jt_render.h")]
+# the single-launch test-time kernel is an OPTIONAL module of its own (include/jt_fused.h): slower than the staged kernels, used
+# by no default path, and 0.8 MB of code objects that the product library does not carry any more
+FUSED_SRC = os.path.join(HERE, "csrc", "jt_fused.hip")
+FUSED_LIB = os.path.join(HERE, "lib", "libjt_fused.so")
+SRCS = [p for p in sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip"))) if p != FUSED_SRC]
+HDRS = sorted(glob.glob(os.path.join(HERE, "csrc", "*.h"))) + [os.path.join(ROOT, "include", "jt_render.h"),
+                                                               os.path.join(ROOT, "include", "jt_fused.h")]
 # test infrastructure, NOT part of the product library: the staged appearance path's two entry points
 # (tests/csrc/jt_app.hip -> tests/lib/libjt_test_staged.so), loaded by tests/staged_path.py only
 TEST_LIB = os.path.join(ROOT, "tests", "lib", "libjt_test_staged.so")
@@ -27,7 +32,9 @@ def hipcc():
 
 
 def needs_build():
-    if not os.path.exists(LIB) or (TEST_SRCS and not os.path.exists(TEST_LIB)):
+    if not os.path.exists(LIB) or not os.path.exists(FUSED_LIB) or (TEST_SRCS and not os.path.exists(TEST_LIB)):
+        return True
+    if any(os.path.getmtime(p) > os.path.getmtime(FUSED_LIB) for p in [FUSED_SRC] + HDRS):
         return True
     t = os.path.getmtime(LIB)
     if any(os.path.getmtime(p) > t for p in SRCS + HDRS + [os.path.abspath(__file__)]):
@@ -58,6 +65,14 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    if force or not os.path.exists(FUSED_LIB) or any(os.path.getmtime(p) > os.path.getmtime(FUSED_LIB)
+                                                     for p in [FUSED_SRC] + HDRS + [os.path.abspath(__file__)]):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-shared",
+               "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-Wall", "-Wno-unused-function",
+               "-o", FUSED_LIB, FUSED_SRC]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     if TEST_SRCS:
         os.makedirs(os.path.dirname(TEST_LIB), exist_ok=True)
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-shared",

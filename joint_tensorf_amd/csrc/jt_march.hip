@@ -907,21 +907,25 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
     return b;
   };
   {
-    // eight-wave workgroups only where two of them fit a CU (otherwise sixteen waves: four per SIMD either way)
+    // eight-wave workgroups only where two of them fit a CU (otherwise sixteen waves: four per SIMD either way).  A shape that
+    // keeps the prefix table of the rays' item counts beats one that does not (without it the items come from a global counter,
+    // twice as slow): doubles with the table, floats with the table, then the same without it
     const int modes[2] = {2, 1};
     bool found = false;
-    for (int mi = 0; mi < 2 && !found; ++mi) {
-      const int lm = modes[mi];
-      if (det || lline_env == 0 || (lline_env > 0 && lline_env != lm)) continue;
-      for (int w = 8; w <= 16 && !found; w += 8) {
-        if (waves_env == 8 || waves_env == 16) {
-          if (w != waves_env) continue;
+    const bool want_prefix = n_rays <= kWalkPrefixRays;
+    for (int need_pre = want_prefix ? 1 : 0; need_pre >= 0 && !found; --need_pre)
+      for (int mi = 0; mi < 2 && !found; ++mi) {
+        const int lm = modes[mi];
+        if (det || lline_env == 0 || (lline_env > 0 && lline_env != lm)) continue;
+        for (int w = 8; w <= 16 && !found; w += 8) {
+          if (waves_env == 8 || waves_env == 16) {
+            if (w != waves_env) continue;
+          }
+          int pre = 0;
+          const size_t b = shape(lm, w, w == 8 && waves_env != 8, &pre);
+          if (b && pre >= need_pre) nw = w, lline = lm, prefix = pre, wlds = b, found = true;
         }
-        int pre = 0;
-        const size_t b = shape(lm, w, w == 8 && waves_env != 8, &pre);
-        if (b) nw = w, lline = lm, prefix = pre, wlds = b, found = true;
       }
-    }
     if (!found) {
       for (int w = 8; w <= 16 && !found; w += 8) {
         if ((waves_env == 8 || waves_env == 16) && w != waves_env) continue;

@@ -380,8 +380,8 @@ class Graph(torch.nn.Module):
             # the single-launch kernel exists for the two BAT shading configurations only (jt_pose_fused_workspace_bytes
             # returns 0 otherwise): any other scene takes the staged path instead of raising; asked once per
             # scene object, BEFORE any host draw is consumed
-            from .._lib import lib
-            tf._pose_fused_ok = lib.jt_pose_fused_workspace_bytes(
+            from .._lib import fused_lib
+            tf._pose_fused_ok = fused_lib().jt_pose_fused_workspace_bytes(
                 tf._render_cfg(self.nerf.n_samples, bool(opt.camera.ndc), bool(opt.nerf.setbg_opaque)).scene()) > 0
         if not tf._pose_fused_ok:
             return None

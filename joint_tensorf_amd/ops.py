@@ -767,7 +767,7 @@ class RenderPoseFused(torch.autograd.Function):
         scene = cfg.scene()
         fac = _factors_struct(*sd, cfg.alpha_mask[0] if cfg.alpha_mask is not None else None)
         mlp = _mlp_struct(*mlp_t)
-        nbytes = lib.jt_pose_fused_workspace_bytes(scene)
+        nbytes = _lib.fused_lib().jt_pose_fused_workspace_bytes(scene)
         key = (str(dev), "pose_fused")
         ws = _WS.get(key)
         if ws is None or ws.numel() < nbytes:
@@ -780,7 +780,7 @@ class RenderPoseFused(torch.autograd.Function):
         buf = torch.empty(R * 12 + 1, **f32)   # rgb 3 | depth | opacity | sqerr | g_o 3 | g_d 3 | loss: one allocation
         rgb, depth, opacity, sqerr = buf[0:3 * R].view(R, 3), buf[3 * R:4 * R], buf[4 * R:5 * R], buf[5 * R:6 * R]
         g_o, g_d, loss = buf[6 * R:9 * R].view(R, 3), buf[9 * R:12 * R].view(R, 3), buf[12 * R:12 * R + 1]
-        check(lib.jt_pose_fused(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(zvals), R, ptr(img), ptr(idx),
+        check(_lib.fused_lib().jt_pose_fused(scene, fac, mlp, ptr(rays_o), ptr(rays_d), ptr(zvals), R, ptr(img), ptr(idx),
                                 int(rays_per_view), int(img.shape[2] * img.shape[3]), 1.0 / (3.0 * R), ptr(rgb), ptr(depth),
                                 ptr(opacity), ptr(sqerr), ptr(loss), ptr(g_o), ptr(g_d), ptr(ws), nbytes, _stream()),
               "jt_pose_fused")

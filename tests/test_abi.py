@@ -7,8 +7,8 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_functions():
-    src = open(os.path.join(ROOT, "include", "jt_render.h")).read()
+def _header_functions(name="jt_render.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
     for m in re.finditer(r"\b(int|size_t)\s+(jt_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
@@ -30,6 +30,22 @@ def test_header_vs_ctypes_vs_library():
         assert hasattr(so, name), name
     # the library and the header agree on the ABI revision (a mismatch is an ImportError in _lib._load as well)
     assert so.jt_version() == _lib.header_version() >= 1100
+
+
+def test_optional_fused_module():
+    """include/jt_fused.h <-> _lib.FUSED_SIGNATURES <-> libjt_fused.so; and the product library no longer carries the
+    single-launch kernel (slower than what it would replace -- out of libjt_render.so)."""
+    funcs = _header_functions("jt_fused.h")
+    from joint_tensorf_amd import _lib
+    assert set(funcs) == set(_lib.FUSED_SIGNATURES) == {"jt_pose_fused", "jt_pose_fused_workspace_bytes"}
+    for name, nargs in funcs.items():
+        assert len(_lib.FUSED_SIGNATURES[name][1]) == nargs, (name, nargs)
+    so = ctypes.CDLL(_lib.FUSED_LIB_PATH)
+    main = ctypes.CDLL(_lib.LIB_PATH)
+    for name in funcs:
+        assert hasattr(so, name) and name not in _lib.SIGNATURES and name not in _header_functions()
+        if "JT_LIB_PATH" not in os.environ:
+            assert not hasattr(main, name), name
 
 
 def test_product_library_has_no_test_only_entry_points():
