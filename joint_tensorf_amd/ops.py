@@ -581,8 +581,13 @@ class RenderRays(torch.autograd.Function):
         elif want_fac and getattr(ctx, "pre", None) is not None and ctx.pre[4] == fused_mlp_zero:
             # the forward created the buffers and wrote the regularisers' gradient for the weights it was told (ctx.pre)
             outs, gflat, spans, hint, _ = ctx.pre
+            # (the node must not keep a second reference to the gradient tensors it is about to return: AccumulateGrad takes a
+            #  gradient over as the parameter's .grad only when nobody else holds it, and CLONES it otherwise -- seven copy
+            #  launches per iteration for the basis / MLP gradients)
+            ctx.pre = None
             gdp, gdl, gap, gal = outs[:4]
             g_mlp_z = outs[4] if fused_mlp_zero else None
+            del outs
             gfac = _factors_struct(gdp, gdl, gap, gal)
             reg_first = True
             if not _reg_hint_holds(g_reg, hint):
