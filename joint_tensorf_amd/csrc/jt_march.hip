@@ -39,6 +39,44 @@ __device__ inline float density_feature(const Dev& D, const float n[3]) {
   return feat;
 }
 
+// d(density feature) / d(normalised coordinates) of one point (bateRF.py:41-94 differentiated; grid_sample's coordinate
+// backward: taps outside the factor count as zero values, the fractional weights stay as they are), lane-per-sample form:
+// what the pose-only backward needs of the density path -- no walkers, no factor gradients
+__device__ inline void density_feature_grad(const Dev& D, const float n[3], float gn[3]) {
+  gn[0] = gn[1] = gn[2] = 0.f;
+  const int C = D.Cd;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const PlaneTaps t = plane_taps(n[kM0(i)], n[kM1(i)], D.ph[i], D.pw[i], C);
+    const Axis l = axis_taps(n[kV(i)], D.ll[i]);
+    const float* P = D.dP[i];
+    const float* L = D.dL[i];
+    const int l0 = l.c0 * C, l1 = l.c1 * C;
+    const float m00 = t.ax.m0 * t.ay.m0, m10 = t.ax.m1 * t.ay.m0, m01 = t.ax.m0 * t.ay.m1, m11 = t.ax.m1 * t.ay.m1;
+    const float fx = t.ax.f, fy = t.ay.f;
+    float sx = 0.f, sy = 0.f, sl = 0.f;
+    for (int q = 0; q < C; q += 4) {
+      const float4 a = ld4(P + t.o00 + q), b = ld4(P + t.o10 + q), c = ld4(P + t.o01 + q), d = ld4(P + t.o11 + q);
+      const float4 u = ld4(L + l0 + q), v = ld4(L + l1 + q);
+      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, cv[4] = {c.x, c.y, c.z, c.w},
+                  dv[4] = {d.x, d.y, d.z, d.w}, uv[4] = {u.x, u.y, u.z, u.w}, vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float am = av[k] * m00, bm = bv[k] * m10, cm = cv[k] * m01, dm = dv[k] * m11;
+        const float um = uv[k] * l.m0, vm = vv[k] * l.m1;
+        const float pv = t.w00 * av[k] + t.w10 * bv[k] + t.w01 * cv[k] + t.w11 * dv[k];
+        const float lv = l.w0 * uv[k] + l.w1 * vv[k];
+        sx += lv * ((1.f - fy) * (bm - am) + fy * (dm - cm));
+        sy += lv * ((1.f - fx) * (cm - am) + fx * (dm - bm));
+        sl += pv * (vm - um);
+      }
+    }
+    gn[kM0(i)] += sx * t.ax.scale;
+    gn[kM1(i)] += sy * t.ay.scale;
+    gn[kV(i)] += sl * l.scale;
+  }
+}
+
 // alpha_i = 1 - exp(-sigma_i * (delta_i * distance_scale))    (tensorBase.py:59, batBase.py:122)
 __device__ inline float sample_alpha(const Dev& D, float feat, bool valid, float delta, float* sigma_out) {
   float sigma = valid ? density_act(D.act, feat + D.shift) : 0.f;
@@ -261,6 +299,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd(Dev D, const int* __restr
 //   (jt_walk.h) and adds the run's coordinate gradients to g_rays_o / g_rays_d.
 // LDS of the scan kernel per wave: 3 float arrays of S entries.
 // ---------------------------------------------------------------------------------------------
+// POSE: the pose-only form (density coordinate gradients taken here, 179 registers); the training form keeps its occupancy
+template <bool POSE>
 __global__ __launch_bounds__(256) void k_march_bwd_scan(Dev D, const float* __restrict__ rays_o,
                                                         const float* __restrict__ rays_d,
                                                         const float* __restrict__ jitter,
@@ -342,6 +382,7 @@ __global__ __launch_bounds__(256) void k_march_bwd_scan(Dev D, const float* __re
   // ---- pass B (reverse) ----
   float suffix = 0.f;  // sum_{j>i} G_j w_j carried from later chunks
   float gnorm = 0.f;   // NDC: dL/d|d|
+  float pgo[3] = {0.f, 0.f, 0.f}, pgd[3] = {0.f, 0.f, 0.f};  // pose_density: this lane's share of the density path's ray gradient
   const int nchunk = (S + 63) / 64;
   for (int c = nchunk - 1; c >= 0; --c) {
     const int i = c * 64 + lane;
@@ -386,6 +427,21 @@ __global__ __launch_bounds__(256) void k_march_bwd_scan(Dev D, const float* __re
       gfeat[row + i] = g_feat;
       s_G[i] = g_feat;
     }
+    // pose-only backward: the density path's coordinate gradient of this sample right here (lane per sample, the taps gathered
+    // as in the forward march) -- the walk, whose only product would be these sums, is not launched
+    if (POSE && live && g_feat != 0.f) {
+      const float z0 = sample_z(D, r, zvals, i);
+      float p[3], nrm[3], gn[3];
+      sample_point(D, r, z0, p);
+      normalize(D, p, nrm);
+      density_feature_grad(D, nrm, gn);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float g = g_feat * gn[a] * D.inv[a];
+        pgo[a] += g;
+        pgd[a] += g * z0;
+      }
+    }
   }
   // ascending list of the samples that carry a density gradient
   int nvalid = 0;
@@ -397,7 +453,7 @@ __global__ __launch_bounds__(256) void k_march_bwd_scan(Dev D, const float* __re
     nvalid += __popcll(bal);
   }
   // ---- pass D: appearance coordinate gradients of this ray's shaded samples ----
-  float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+  float go[3] = {pgo[0], pgo[1], pgo[2]}, gd[3] = {pgd[0], pgd[1], pgd[2]};
   const int n = offset[ray + 1] - off;
   if (g_xyz_app) {
     for (int k = lane; k < n; k += 64) {
@@ -878,12 +934,24 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
   const size_t lds = (size_t)4 * 3 * Spad * sizeof(float);
   if (lds > 160 * 1024) return JT_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_bwd_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
+  // nothing but the rays wants a gradient (test-time pose optimisation): the density path's coordinate gradient is taken in the
+  // scan kernel, lane per sample, and the walk is skipped (JT_POSE_BWD=0, read once: the walk with its targets switched off)
+  static const bool pose_env = [] { const char* e = getenv("JT_POSE_BWD"); return !e || atoi(e) != 0; }();
+  const bool pose_density = pose_env && !g_factors && !det;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_bwd_scan<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-  hipLaunchKernelGGL(k_march_bwd_scan, dim3((n_rays + 3) / 4), dim3(256), lds, st, D, rays_o, rays_d, jitter, zvals,
-                     n_rays, sigma_feat, weight, tmin, shade_offset, shade_idx, rgb_s, clamp_mask, g_rgb, g_opacity,
-                     g_xyz_app, gfeat, vlist, nvalid, g_rays_o, g_rays_d, rays_fixed, Spad);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_bwd_scan<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  if (pose_density)
+    hipLaunchKernelGGL(k_march_bwd_scan<true>, dim3((n_rays + 3) / 4), dim3(256), lds, st, D, rays_o, rays_d, jitter, zvals,
+                       n_rays, sigma_feat, weight, tmin, shade_offset, shade_idx, rgb_s, clamp_mask, g_rgb, g_opacity,
+                       g_xyz_app, gfeat, vlist, nvalid, g_rays_o, g_rays_d, rays_fixed, Spad);
+  else
+    hipLaunchKernelGGL(k_march_bwd_scan<false>, dim3((n_rays + 3) / 4), dim3(256), lds, st, D, rays_o, rays_d, jitter, zvals,
+                       n_rays, sigma_feat, weight, tmin, shade_offset, shade_idx, rgb_s, clamp_mask, g_rgb, g_opacity,
+                       g_xyz_app, gfeat, vlist, nvalid, g_rays_o, g_rays_d, rays_fixed, Spad);
   JT_LAUNCH_CHECK();
+  if (pose_density) return JT_OK;  // the ray gradients are complete: no walk, no fixed-point sums to add
   unsigned* bad = jt::fixed_bad_flag();
   if (!bad) return JT_ERR_ARG;
   const int runs = ((D.S + kWalkRun - 1) / kWalkRun + 3) & ~3;  // a wave's four groups: four runs of ONE (ray, plane)
