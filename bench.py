@@ -359,8 +359,21 @@ def instep_roofline(timers, n_comp_app, n_comp_density=16):
     gradients) times the shaded samples of every launch, over the summed launch durations."""
     per = 4 * 3 * n_comp_app * 6
     out = {}
-    for kind, mult, name in (("bwd", 2, "k_shade_bwd (fused appearance backward: MLP backward on the fp32 matrix cores + "
-                                       "run-length scatter of the factor gradients), inside the timed training steps"),
+    from joint_tensorf_amd._lib import lib as _l
+    _split, _mm = _l.jt_shade_bwd_split(), _l.jt_shade_matrix_mode()
+    if _split < 0:
+        _split = 16 if (n_comp_app < 48 or (_mm & 4)) else 0
+    if _split == 0:
+        bwd_name = ("k_shade_bwd (fused appearance backward: MLP backward on the fp32 matrix cores + run-length scatter of the "
+                    "factor gradients), inside the timed training steps")
+    elif _split == 1:
+        bwd_name = ("k_shade_bwd<split> + k_tile_bin / scan / scatter / gxyz (appearance backward: MLP backward chain, then the "
+                    "TILE-OWNED scatter of the factor gradients), inside the timed training steps")
+    else:
+        bwd_name = ("k_shade_bwd<split> + k_shade_scatter (appearance backward: MLP backward chain on the %s matrix cores, then the "
+                    "run-length scatter of the factor gradients in runs of %d samples; the two launches timed together), inside "
+                    "the timed training steps" % ("bf16 (three-piece operands)" if (_mm & 4) else "fp32", _split))
+    for kind, mult, name in (("bwd", 2, bwd_name),
                              ("fwd", 1, "k_shade_fwd<train> (gather + basis + MLP + layer-input records), inside the timed "
                                         "training steps"),
                              ("march_bwd", 2, "k_march_bwd_scan + k_march_bwd_walk (density backward: transmittance suffix "
@@ -558,7 +571,10 @@ def run_extras():
              # the headline workload with the appearance gradients through the TILE-OWNED scatter of round 5 (chain kernel +
              # binning + one wave per 4 x 4-texel tile on the matrix cores) instead of the fused kernel's run-length atomics:
              # a selectable variant that does not win at this workload; k_shade_bwd_ms = chain + scatter
-             ("default_tile_owned_scatter", [], {"JT_BWD_SPLIT": "1", "JT_TILE_CFG": "1"})]
+             ("default_tile_owned_scatter", [], {"JT_BWD_SPLIT": "1", "JT_TILE_CFG": "1"}),
+             # ... and through the ONE-kernel backward of rounds 2-4 (fp32 chain + scatter fused, weight gradients on the launch
+             # stream): what the default's chain-on-bf16 + scatter + forked weight-gradient GEMMs replaced in round 5
+             ("default_fused_backward_kernel", [], {"JT_BWD_SPLIT": "0", "JT_NO_AUX": "1"})]
     out = {}
     for name, flags, env in cases:
         try:
@@ -898,10 +914,12 @@ def main():
                 "rays_per_iter_per_gpu": rays_all / args.steps / world,
                 "samples_per_ray": S,
                 "Msamples_per_s": rays_all * S / dt / 1e6,
-                "shade_impl": {0: "fp32 MFMA", 1: "bf16x3 MFMA forward chain, fp32 MFMA backward chain and weight gradients",
-                               2: "fp32 MFMA chains, bf16x3 MFMA weight gradients",
-                               3: "bf16x3 MFMA (three-piece operands, fp32-level accuracy) forward chain and weight-gradient "
-                                  "GEMMs, fp32 MFMA backward chain"}.get(__import__("joint_tensorf_amd._lib", fromlist=["lib"]).lib.jt_shade_matrix_mode() & 3),
+                "shade_impl": ({0: "fp32 MFMA", 1: "bf16x3 MFMA forward chain, fp32 MFMA backward chain and weight gradients",
+                                2: "fp32 MFMA chains, bf16x3 MFMA weight gradients",
+                                3: "bf16x3 MFMA (three-piece operands, fp32-level accuracy) forward chain and weight-gradient "
+                                   "GEMMs, fp32 MFMA backward chain"}.get(__import__("joint_tensorf_amd._lib", fromlist=["lib"]).lib.jt_shade_matrix_mode() & 3)
+                               + ("; the backward chain of the split appearance backward on bf16x3 MFMA as well"
+                                  if __import__("joint_tensorf_amd._lib", fromlist=["lib"]).lib.jt_shade_matrix_mode() & 4 else "")),
                 "launch": ("hipGraph replay (%(replayed)d replayed / %(captured)d captured / %(eager)d eager steps)"
                            % stepper.stats) if stepper is not None else "eager",
                 "abi_calls_per_step": n_calls[0] or None,

@@ -282,9 +282,11 @@ int jt_shade_chunk_entries(void);
 /* Which matrix stages of the appearance path run on the bf16 matrix cores with every fp32 operand split into three bf16
  * pieces and six products accumulated per K step (fp32-level accuracy; the reference's fp32 torch.nn.Linear chain,
  * tensorBase.py:43-131, is what both variants are held to): bit 0 the forward chain (basis product, layers 1 and 2),
- * bit 1 the weight-gradient GEMMs.  0 = everything on the fp32 matrix cores.  The environment variable JT_BF16X3 (read
- * once) overrides the build default; jt_shade_set_matrix_mode(mode) sets it for the launches that follow and returns the
- * previous value (a mode outside 0..3 only queries).  A forward and its backward may run under different modes: the
+ * bit 1 the weight-gradient GEMMs, bit 2 (round 5) layers 2 and 1 of the backward chain where the backward runs SPLIT
+ * (chain kernel + scatter: the 20-channel scene, the tile-owned variant, the pose-only backward; the fused VM-48 kernel's LDS
+ * has no room for the pre-split transposed weights).  0 = everything on the fp32 matrix cores; build default 7.  The
+ * environment variable JT_BF16X3 (read once) overrides the build default; jt_shade_set_matrix_mode(mode) sets it for the
+ * launches that follow and returns the previous value (a mode outside 0..7 only queries).  A forward and its backward may run under different modes: the
  * records they exchange are the same fp32 values in the same layout. */
 int jt_shade_matrix_mode(void);
 int jt_shade_set_matrix_mode(int mode);
@@ -293,7 +295,11 @@ int jt_shade_set_chunk_log2(int log2_entries);
  * tensorBase.py:116-126): 0 = one kernel (MLP backward chain and the factor-gradient scatter of a 32-sample tile in the same
  * wave); 8 / 16 = two launches, the chain (which leaves the feature gradients in the record rows) and a scatter kernel whose
  * 16-lane groups walk runs of that many consecutive samples and which sums the LINE gradients in a workgroup-private LDS copy;
- * -1 (the default) = chosen per scene kind (split 16 for the 20-channel WeakView scene, one kernel for VM-48).  Same gradients
+ * 1 (round 5) = the chain and the TILE-OWNED scatter (pairs counting-sorted by 4 x 4-texel tile, one wave per tile, the gradient
+ * slice accumulated in matrix-core registers; needs factor gradients, float accumulation and at most 131 072 tiles per plane,
+ * otherwise the default takes over);
+ * -1 (the default) = chosen per scene kind: split 16 whenever the chain runs on the bf16 matrix cores (matrix-mode bit 2: the
+ * build default) or the scene has fewer than 48 appearance channels, one kernel otherwise.  Same gradients
  * up to the order of the float sums.  The environment variable JT_BWD_SPLIT (read once) overrides the default; the setter
  * returns the previous value (any other argument only queries). */
 int jt_shade_bwd_split(void);

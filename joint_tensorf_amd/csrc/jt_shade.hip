@@ -25,7 +25,7 @@
 #define JT_B16_PINGPONG 1
 #endif
 #ifndef JT_BF16X3_DEFAULT
-#define JT_BF16X3_DEFAULT 3
+#define JT_BF16X3_DEFAULT 7
 #endif
 
 namespace jt {
@@ -346,9 +346,66 @@ __device__ inline void scatter_plane(const Dev& D, const JtFactors& G, int pl, c
   wk.finish_pair(grp);
 }
 
+// ---- the backward chain on the bf16 matrix cores with three-piece operands (round 5; SPLIT kernels only) ------------------
+// G1 = W2^T G2 and, per encoding slot t, gin_t = W1_t^T G1 are products of the same shape as the forward's layers with the
+// weight matrices TRANSPOSED: the A operands come from pre-split images [stage][K step][M tile][piece][lane] of 16-byte
+// vectors (jt_shade_core.h: split8 / mfma6 / load_b3), the B operands are the gradient registers of the previous stage split
+// in place -- G1's split is shared by the five slots.  120 + 24 MT bf16 MFMAs of 32 cycles replace 160 + 32 MT fp32 ones of 64.
+// LDS: W2^T 12 MT^2 KB + W1^T 15 MT... (VM-48: 24.6 + 61.4 KB) + the fp32 tail; it fits beside the eight 8 KB sin / cos stashes
+// only because the SPLIT kernel has no scatter tiles (the fused kernel: 164.2 KB against 163.8).
+template <class C>
+struct BwdB16Cfg {
+  static constexpr int NSK = 2 * C::MT;                      // K steps of 16 over the HID hidden units
+  static constexpr int V_W2T = 0;                            // [step][M tile of h1 units][piece][lane]
+  static constexpr int V_W1T = V_W2T + NSK * C::MT * 3 * 64;  // [slot t][step][piece][lane]  (one M tile: the APP <= 32 features)
+  static constexpr int V_END = V_W1T + 5 * NSK * 3 * 64;
+  static constexpr int F_W3 = 0;                             // fp32 tail (floats): W3 [IN3][4]
+  static constexpr int F_END = F_W3 + C::IN3 * 4;
+  static constexpr size_t IMG_BYTES = (size_t)V_END * 16 + (size_t)F_END * 4;
+};
+
+template <class C>
+__device__ inline void load_bwd_images_b16(unsigned char* smem, const MlpDev& M) {
+  typedef BwdB16Cfg<C> Q;
+  uint4* img = reinterpret_cast<uint4*>(smem);
+  float* tail = reinterpret_cast<float*>(smem + (size_t)Q::V_END * 16);
+  const int items = (Q::NSK * C::MT + 5 * Q::NSK) * 64;
+  for (int it = threadIdx.x; it < items; it += blockDim.x) {
+    const int lane = it & 63, blk = it >> 6, i = lane & 31, h = lane >> 5;
+    float w[8];
+    if (blk < Q::NSK * C::MT) {   // W2^T: row = h1 unit k, the K values are h2 units in the order the G2 registers hold them
+      const int st = blk / C::MT, mt = blk - st * C::MT, k = mt * 32 + i;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = 8 * st + e, mi = idx >> 4, r = idx & 15;
+        w[e] = M.w2[(mi * 32 + rowmap(r, 0) + 4 * h) * C::HID + k];
+      }
+      store_b3(img, Q::V_W2T + blk * 3 * 64, lane, w);
+    } else {                      // W1_t^T: row = feature j, the K values are h1 units in the order the G1 registers hold them
+      const int b = blk - Q::NSK * C::MT, t = b / Q::NSK, st = b - t * Q::NSK;
+      int col = C::IN1;
+      if (i < C::APP) {
+        if (C::KIND == JT_MLP_FEA) col = (t == 0) ? i : C::APP + 3 + 4 * i + (t - 1);
+        else col = (t == 0) ? i : C::APP + 4 * i + (t - 1);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int idx = 8 * st + e, mi = idx >> 4, r = idx & 15;
+        w[e] = (col < C::IN1) ? M.w1[(mi * 32 + rowmap(r, 0) + 4 * h) * C::IN1 + col] : 0.f;
+      }
+      store_b3(img, Q::V_W1T + b * 3 * 64, lane, w);
+    }
+  }
+  for (int i = threadIdx.x; i < C::IN3 * 4; i += blockDim.x) {
+    const int k = i >> 2, c = i & 3;
+    tail[Q::F_W3 + i] = (c < 3) ? M.w3[c * C::IN3 + k] : 0.f;
+  }
+}
+
 // SPLIT: the chain only -- the feature gradients leave through the GF record rows (always written then) and the scatter runs
 // as its own launch (k_shade_scatter below); the wave's LDS is then just the 8 KB sin / cos stash.
-template <class C, bool DET, bool SPLIT = false>
+// B16 (with SPLIT): layers 2 and 1 of the chain on the bf16 matrix cores (above).
+template <class C, bool DET, bool SPLIT = false, bool B16 = false>
 __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm, JtFactors G,
                                                       const int* __restrict__ offset, int R,
                                                       const float* __restrict__ rgb_s,
@@ -362,12 +419,20 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
   const int ntiles = (n_chunk + 31) >> 5;
   const int nblk = min((int)gridDim.x, (ntiles + B::NWAVE - 1) / B::NWAVE);  // the grid is sized for the worst case
   if ((int)blockIdx.x >= nblk) return;  // chunk beyond the shaded samples: nothing to do
-  load_weights_lds<C>(smem, M);
+  typedef BwdB16Cfg<C> QB;
+  static_assert(!B16 || SPLIT, "the bf16 chain exists for the split backward only");
+  const uint4* img = reinterpret_cast<const uint4*>(smem);
+  if (B16) load_bwd_images_b16<C>(reinterpret_cast<unsigned char*>(smem), M);
+  else load_weights_lds<C>(smem, M);
   __syncthreads();
   // (the wave index as a scalar: everything derived from it -- tile, record block -- stays in scalar registers)
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j_ = lane & 31, h_ = lane >> 5;
-  float* tp = smem + C::LDS_FLOATS + wv * (SPLIT ? B::STASH_FLOATS : B::WAVE_FLOATS);
+  const float* w3tab = B16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(smem) + (size_t)QB::V_END * 16)
+                           : smem + C::O_W3;
+  float* tp = B16 ? reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(smem) + ((QB::IMG_BYTES + 15) & ~(size_t)15)) +
+                        wv * B::STASH_FLOATS
+                  : smem + C::LDS_FLOATS + wv * (SPLIT ? B::STASH_FLOATS : B::WAVE_FLOATS);
   float* geo = tp + B::TP_ROWS * B::TP_LD;
   float* gxyz = geo + 32 * 4;
   const size_t RC = B::REC_FLOATS;
@@ -430,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int k = HOFF + mt * 32 + rowmap(r, 0) + 4 * h;
-        const float4 w = *reinterpret_cast<const float4*>(smem + C::O_W3 + k * 4);
+        const float4 w = *reinterpret_cast<const float4*>(w3tab + k * 4);
         float gsum = go[0] * w.x + go[1] * w.y + go[2] * w.z;
         G2.v[mt][r] = ((mask2 >> (mt * 16 + r)) & 1u) ? gsum : 0.f;
       }
@@ -441,6 +506,18 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
     for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) G1.v[mt][r] = 0.f;
+    if (B16) {
+#pragma unroll
+      for (int st = 0; st < QB::NSK; ++st) {
+        float v8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v8[e] = G2.v[(8 * st + e) >> 4][(8 * st + e) & 15];
+        const B3 bb = split8(v8);
+#pragma unroll
+        for (int mk = 0; mk < C::MT; ++mk)
+          G1.v[mk] = mfma6(load_b3(img, QB::V_W2T + (st * C::MT + mk) * 3 * 64, lane), bb, G1.v[mk]);
+      }
+    } else {
 #pragma unroll
     for (int mi = 0; mi < C::MT; ++mi) {
 #pragma unroll
@@ -454,6 +531,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
         }
       }
     }
+    }
 #pragma unroll
     for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
@@ -465,6 +543,16 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
     const float* stash = tp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) gf[r] = 0.f;
+    B3 g1s[B16 ? QB::NSK : 1];   // G1 split once, the B operand of all five slots
+    if (B16) {
+#pragma unroll
+      for (int st = 0; st < QB::NSK; ++st) {
+        float v8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v8[e] = G1.v[(8 * st + e) >> 4][(8 * st + e) & 15];
+        g1s[st] = split8(v8);
+      }
+    }
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
       // column of W1 for output row m = j of tile t (feature rows only; view-direction inputs are detached)
@@ -478,6 +566,11 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
       f32x16 gin;
 #pragma unroll
       for (int r = 0; r < 16; ++r) gin[r] = 0.f;
+      if (B16) {
+#pragma unroll
+        for (int st = 0; st < QB::NSK; ++st)
+          gin = mfma6(load_b3(img, QB::V_W1T + (t * QB::NSK + st) * 3 * 64, lane), g1s[st], gin);
+      } else {
 #pragma unroll
       for (int mi = 0; mi < C::MT; ++mi) {
 #pragma unroll
@@ -486,6 +579,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
           float av = smem[C::O_W1 + irow * C::LD1 + col];
           gin = __builtin_amdgcn_mfma_f32_32x32x2f32(av, G1.v[mi][r], gin, 0, 0, 0);
         }
+      }
       }
       // d/dx of [x, sin x m0, sin 2x m1, cos x m0, cos 2x m1]
 #pragma unroll
@@ -1386,14 +1480,15 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce4(const float* __restrict__
 using namespace jt;
 
 // which stages run on the bf16 matrix cores with three-piece operands (fp32-level accuracy, jt_shade_core.h): bit 0 the
-// forward chain (k_shade_fwd_b16), bit 1 the weight-gradient GEMMs (k_wgrad_b16).  JT_BF16X3 (read once) overrides the build
+// forward chain (k_shade_fwd_b16), bit 1 the weight-gradient GEMMs (k_wgrad_b16), bit 2 the chain of the SPLIT backward
+// (k_shade_bwd<..., SPLIT, B16>).  JT_BF16X3 (read once) overrides the build
 // default; 0 = everything on the fp32 matrix cores.
 static std::atomic<int> g_matrix_mode{-1};
 static int bf16x3_mode() {
   int m = g_matrix_mode.load(std::memory_order_relaxed);
   if (m < 0) {
     const char* e = getenv("JT_BF16X3");
-    m = (e ? atoi(e) : JT_BF16X3_DEFAULT) & 3;
+    m = (e ? atoi(e) : JT_BF16X3_DEFAULT) & 7;
     g_matrix_mode.store(m, std::memory_order_relaxed);
   }
   return m;
@@ -1435,9 +1530,11 @@ extern "C" int jt_debug_read_stamps(unsigned long long* out8) {
 #endif
 // Split appearance backward: 0 = one kernel (chain + scatter in k_shade_bwd), 8 / 16 = k_shade_bwd<SPLIT> + k_shade_scatter
 // with runs of that many samples per 16-lane group, 1 = k_shade_bwd<SPLIT> + the TILE-OWNED scatter of jt_tile.h (pairs binned
-// by plane tile, gradient slices summed in LDS), -1 = per scene kind (the default): split 16 for the 20-channel WeakView
-// scene (bat_llff_VM_MLP: its line gradients, privatised in LDS by the scatter kernel, are 40 % of the fused kernel's time:
-// 0.49 -> 0.35 ms per launch), fused for VM-48 (profiles/round4_bwd_split_ablation.txt).  JT_BWD_SPLIT (read once) overrides.
+// by plane tile, gradient slices in matrix-core registers), -1 = per scene kind (the default): split 16 for the 20-channel
+// WeakView scene (bat_llff_VM_MLP: its line gradients, privatised in LDS by the scatter kernel, are 40 % of the fused kernel's
+// time: 0.49 -> 0.35 ms per launch) and, since the chain runs on the bf16 matrix cores (round 5: 508 -> 281 us), for VM-48 as
+// well (281 + 994 against 1 365 us fused; with the fp32 chain the fused kernel wins: profiles/round4_bwd_split_ablation.txt).
+// JT_BWD_SPLIT (read once) overrides.
 static std::atomic<int> g_bwd_split{-2};
 static int bwd_split_mode() {
   int m = g_bwd_split.load(std::memory_order_relaxed);
@@ -1467,7 +1564,7 @@ extern "C" int jt_shade_chunk_entries(void) { return chunk_entries(); }
 extern "C" int jt_shade_matrix_mode(void) { return bf16x3_mode(); }
 extern "C" int jt_shade_set_matrix_mode(int mode) {
   const int prev = bf16x3_mode();
-  if (mode >= 0 && mode <= 3) g_matrix_mode.store(mode, std::memory_order_relaxed);
+  if (mode >= 0 && mode <= 7) g_matrix_mode.store(mode, std::memory_order_relaxed);
   return prev;
 }
 // returns the previous log2; values outside 16..22 only query.  The caller re-sizes its workspace afterwards
@@ -1691,7 +1788,11 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   static const bool pipe = [] { const char* e = getenv("JT_WGRAD_PIPE"); return !e || atoi(e) != 0; }();
   hipStream_t ws_st = use_aux ? aux : st;
   const int RR = B::REC_FLOATS;
-  int split = bwd_split_mode() >= 0 ? bwd_split_mode() : (C::CA < 48 ? 16 : 0);
+  // per scene kind (-1): split 16 whenever the chain runs on the bf16 matrix cores (matrix-mode bit 2) -- the 20-channel scene
+  // always did; VM-48 since round 5: chain 281 us + scatter 994 against 1 365 fused (with the fp32 chain, 508 + 994, the fused
+  // kernel wins and stays)
+  const int split_default = (C::CA < 48 || (bf16x3_mode() & 4)) ? 16 : 0;
+  int split = bwd_split_mode() >= 0 ? bwd_split_mode() : split_default;
   unsigned* bad = jt::fixed_bad_flag();
   if (!bad) return JT_ERR_ARG;
   // tile-owned scatter (split == 1): needs factor gradients to write, float accumulation, a scene whose tiles and LDS line fit
@@ -1705,7 +1806,7 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     if (TS::lds_bytes(tile_cfg, tile_line_len) > 160 * 1024) tile_cfg ^= 1;  // the other workgroup shape may still fit
     bool ok = !det && G.app_plane[0] && G.app_line[0] && TS::lds_bytes(tile_cfg, tile_line_len) <= 160 * 1024;
     for (int a = 0; a < 3 && ok; ++a) ok = TS::tiles(D.ph[a], D.pw[a]) <= kTileMaxTiles;
-    if (!ok) split = (C::CA < 48 ? 16 : 0);
+    if (!ok) split = split_default;
   }
   const bool tile = (split == 1);
   const TileWs TW = tile_ws_carve(reinterpret_cast<char*>(ws) + W::main_bytes(cap), cap, chunk);
@@ -1721,7 +1822,18 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     long tiles = ((long)ccap + 31) / 32;
     int blocks = (int)std::min<long>((tiles + B::NWAVE - 1) / B::NWAVE, 256);
     float* rc = recs + W::rec_floats_per_chunk() * ci;
-    if (split) {
+    if (split && (bf16x3_mode() & 4)) {
+      // the chain of the split backward on the bf16 matrix cores (three-piece operands): matrix-mode bit 2
+      const size_t lds_b = ((BwdB16Cfg<C>::IMG_BYTES + 15) & ~(size_t)15) + (size_t)B::NWAVE * B::STASH_FLOATS * sizeof(float);
+      static bool attr_b = false;
+      if (!attr_b) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_bwd<C, false, true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        attr_b = true;
+      }
+      hipLaunchKernelGGL((k_shade_bwd<C, false, true, true>), dim3(blocks), dim3(512), lds_b, st, D, M, pm, G, offset, R, rgb_s,
+                         g_rgb_s, g_xyz, rc, start, ccap, cap, ablate, bad);
+    } else if (split) {
       const size_t lds_c = B::LDS_FLOATS_SPLIT * sizeof(float);
       static bool attr_done = false;
       if (!attr_done) {

@@ -166,9 +166,18 @@ USE_AUX_STREAM = _AUX_ENV != "1"
 
 
 def _use_aux(cfg):
+    """The weight-gradient GEMMs on the auxiliary stream?  Where the appearance backward runs SPLIT (chain kernel, then the
+    atomic-bound scatter) they fork behind the chain and run beside the scatter: 3.12 -> 3.07 ms on VM-48 (round 5), 0.09 ms
+    on the 20-channel scene (round 4).  Beside the FUSED kernel -- VM-48 with the fp32 chain, jt_shade_set_bwd_split(0) -- they
+    cost 0.06-0.10 ms (their registers and the persistent walk keep each other off the CUs) and stay on the launch stream."""
     if not USE_AUX_STREAM:
         return False
-    return True if _AUX_ENV == "0" else cfg.n_comp_app < 48
+    if _AUX_ENV == "0":
+        return True
+    split = lib.jt_shade_bwd_split()
+    if split < 0:
+        return cfg.n_comp_app < 48 or bool(lib.jt_shade_matrix_mode() & 4)
+    return split != 0
 
 
 def _aux_stream(dev):

@@ -105,8 +105,9 @@ def replay_hip(fx, shade_impl, pin_rays=True, device="cuda"):
 # backward), the staged cross-check path, the fp32-matrix-core kernels (jt_shade_set_matrix_mode(0): VERDICT r3 "thin spot")
 # and the split backward (chain kernel + scatter kernel with runs of 16 / 8 samples, jt_shade_set_bwd_split)
 # (matrix mode, backward split; -1 = the library's per-scene default: fused for VM-48, split 16 for the 20-channel scene)
-VARIANTS = {"mfma": (3, -1), "torch": (3, -1), "mfma-fp32": (0, 0), "mfma-split16": (3, 16), "mfma-split8-fp32": (0, 8),
-            "mfma-tile": (3, 1)}
+# (matrix-mode bit 2, round 5: the chain of a SPLIT backward on the bf16 matrix cores -- 7 = the library's default)
+VARIANTS = {"mfma": (7, -1), "torch": (7, -1), "mfma-fp32": (0, 0), "mfma-split16": (7, 16), "mfma-split8-fp32": (0, 8),
+            "mfma-tile": (7, 1), "mfma-split16-fp32chain": (3, 16)}
 
 
 class kernel_variant:
