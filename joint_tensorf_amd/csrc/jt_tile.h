@@ -185,9 +185,13 @@ __global__ __launch_bounds__(1024) void k_tile_scan(TileWs W, int nt0, int nt1, 
       if (i0 + k < nt) {
         W.offs[pl * kTileMaxTiles + i0 + k] = off;
         W.cursor[pl * kTileMaxTiles + i0 + k] = off;
-        for (int j = 0; j < ni[k]; ++j) {
-          const int b0 = off + (int)(((long long)v[k] * j) / ni[k]), b1 = off + (int)(((long long)v[k] * (j + 1)) / ni[k]);
-          if (io + j < W.max_items) W.items[(size_t)pl * W.max_items + io + j] = make_int4(i0 + k, b0, b1, 0);
+        if (ni[k] == 1) {   // (the common case, without the 64-bit divisions of the general split)
+          if (io < W.max_items) W.items[(size_t)pl * W.max_items + io] = make_int4(i0 + k, off, off + v[k], 0);
+        } else {
+          for (int j = 0; j < ni[k]; ++j) {
+            const int b0 = off + (int)(((long long)v[k] * j) / ni[k]), b1 = off + (int)(((long long)v[k] * (j + 1)) / ni[k]);
+            if (io + j < W.max_items) W.items[(size_t)pl * W.max_items + io + j] = make_int4(i0 + k, b0, b1, 0);
+          }
         }
       }
       off += v[k];
