@@ -386,11 +386,25 @@ def instep_roofline(timers, n_comp_app, n_comp_density=16):
             continue
         t, n = sum(r[0] for r in rows), sum(r[1] for r in rows)
         ach = n * mult * per / t / 1e9
+        if kind == "bwd":
+            # split backward with the weight-gradient GEMMs forked behind the chain: the fork event separates the two launches
+            # (single-chunk launches only: with several chunks the event marks the LAST chunk's chain)
+            parts = {}
+            for sub in ("bwd_chain", "bwd_scatter"):
+                rs = [a.elapsed_time(b) * 1e-3 for k, a, b, off in timers if k == sub]
+                if rs and len(rs) == len(rows):
+                    parts[sub] = sum(rs) / len(rs) * 1e3
         out[kind] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                      "launch_ms": t / len(rows) * 1e3, "launches": len(rows), "samples_per_launch": n / len(rows),
                      "samples_per_launch_min_max": [min(r[1] for r in rows), max(r[1] for r in rows)],
                      "bytes_per_sample": mult * per, "timing": "HIP events on the launch stream around every launch of the "
                                                                 "timed steps"}
+        if kind == "bwd" and parts:
+            out[kind]["launch_ms_chain"] = parts.get("bwd_chain")
+            out[kind]["launch_ms_scatter"] = parts.get("bwd_scatter")
+            out[kind]["launch_ms_parts_note"] = ("the fork event behind the chain kernel splits launch_ms: chain = "
+                                                 "k_shade_bwd<split>, scatter = k_shade_scatter (the gather + gradient bytes the "
+                                                 "roofline counts all move in the scatter; the chain streams records)")
     return out
 
 

@@ -674,6 +674,13 @@ class RenderRays(torch.autograd.Function):
                 # the weight-gradient GEMMs go to the auxiliary stream: what this call leaves on the launch stream IS the
                 # per-sample backward (k_shade_bwd, or chain + scatter when split) -- its end mark is recorded behind the call
                 t_bwd_end = t1
+                # ... and the fork event the library records BEHIND THE CHAIN (split backward: the GEMMs wait for it) is a
+                # timing event of this launch's own while the step timers are on: chain and scatter are told apart
+                t_mid = torch.cuda.Event(enable_timing=True)
+                t_mid.record()  # creates the handle
+                h_aux = (h_aux[0], ctypes.c_void_p(t_mid.cuda_event), h_aux[2])
+                STEP_TIMERS.append(("bwd_chain", t0, t_mid, offset))
+                STEP_TIMERS.append(("bwd_scatter", t_mid, t1, offset))
             else:
                 # one stream: the library records the mark between the per-sample kernels and the GEMMs (jt_render.h)
                 t1.record()  # creates the handle
