@@ -1698,9 +1698,11 @@ extern "C" int jt_shade_forward(const JtScene* scene, const JtFactors* factors, 
                                    st);
 }
 
-// the tile-owned scatter (jt_tile.h) per scene kind.  Configuration 0 (default): sixteen-wave workgroups; VM-48's three channel
-// groups form two classes (groups 0..1 | group 2) because a 400 x 48 line of doubles does not fit the LDS beside anything else.
-// Configuration 1 (JT_TILE_CFG=1, read once): one class, eight-wave workgroups with the whole line.
+// the tile-owned scatter (jt_tile.h) per scene kind.  Configuration 1 (the default): ONE channel class, eight-wave workgroups
+// beside the plane's whole line of doubles (154 KB for VM-48) -- 252 registers per lane at two waves per SIMD, 1.0 ms at 400^3.
+// Configuration 0 (JT_TILE_CFG=0, read once): sixteen-wave workgroups, VM-48's three channel groups as two classes (groups
+// 0..1 | group 2, so that the class's line leaves room): the 128 registers of four waves per SIMD spill, 2.7-3.4 ms.  The
+// launcher takes the other shape when the chosen one does not fit the LDS (a longer line).
 template <class C>
 struct TileSel {
   static constexpr int NG = (C::CA + 15) / 16;
@@ -1800,8 +1802,8 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   typedef TileSel<C> TS;
   int tile_line_len = 0;
   for (int a = 0; a < 3; ++a) tile_line_len = std::max(tile_line_len, D.ll[a]);
-  static const int tile_cfg_env = [] { const char* e = getenv("JT_TILE_CFG"); return e ? atoi(e) : 0; }();
-  int tile_cfg = (tile_cfg_env == 1) ? 1 : 0;
+  static const int tile_cfg_env = [] { const char* e = getenv("JT_TILE_CFG"); return e ? atoi(e) : 1; }();
+  int tile_cfg = (tile_cfg_env == 0) ? 0 : 1;
   if (split == 1) {
     if (TS::lds_bytes(tile_cfg, tile_line_len) > 160 * 1024) tile_cfg ^= 1;  // the other workgroup shape may still fit
     bool ok = !det && G.app_plane[0] && G.app_line[0] && TS::lds_bytes(tile_cfg, tile_line_len) <= 160 * 1024;
