@@ -25,6 +25,7 @@ runs) runs through `Model.train_iteration` unchanged.  Host draws are consumed i
 switches between the two paths without changing its random streams.
 """
 import os
+import time
 
 import numpy as np
 import torch
@@ -36,6 +37,16 @@ from .options import Opt
 
 class _Entry:
     pass
+
+
+class _StageProbe:
+    """What GraphedTrainStep has measured at one grid stage (see GraphedTrainStep.__init__): state is "replay_probe" (a
+    window of consecutive replays is being timed), "eager_probe" (the same number of eager iterations is being timed) or
+    "decided" (`choice` holds for the next REPROBE iterations)."""
+
+    def __init__(self):
+        self.state, self.choice, self.n, self.t0, self.since = "replay_probe", "replay", -GraphedTrainStep.WINDOW_LEAD, 0.0, 0
+        self.t_replay = self.t_eager = None
 
 
 def has_key(o, k):
@@ -102,8 +113,27 @@ class GraphedEvalRender:
 
 
 class GraphedTrainStep:
-    def __init__(self, model, min_repeats=2, max_graphs=64):
+    WINDOW = 32        # iterations per timed window
+    WINDOW_LEAD = 4    # untimed iterations in front of each window (the first eager iterations after a run of replays refill the
+    #                    caching allocator; the first replays follow eager iterations whose launches are still queued)
+    REPROBE = 3000     # iterations a choice holds before the two windows are timed again (the workload of a stage changes as
+    #                    the scene converges and the alpha mask shrinks the box)
+    EAGER_GAIN = 0.97  # eager is chosen where its window takes less than this fraction of the replayed one
+
+    def __init__(self, model, min_repeats=2, max_graphs=64, adaptive=None):
+        """adaptive (default on; JT_GRAPH_ADAPTIVE=0 or adaptive=False: replay wherever a graph exists): replay wins where the
+        host bounds the iteration (small grids, sparse converged scenes: 1.56 ms replayed against 2.04-2.12 eager at the
+        128^3 stage), the eager launch where the GPU does (the late, large grids: the host's launches are hidden behind the
+        kernels anyway, and the eager backward runs its weight-gradient GEMMs beside the factor scatter on a second stream,
+        which a replayed graph -- fork captured or not -- does not do as well: over the same iterations, round 5, VM-48 final
+        grid 3.14 eager / 3.18 replayed / 3.22 replayed with the fork captured, LLFF final grid 2.17 / 2.28 / 2.26 ms).
+        Which regime a stage is in is MEASURED: once its graphs exist, WINDOW consecutive replays are timed between two
+        synchronisations, then WINDOW eager iterations; the faster mode runs for REPROBE iterations, then the two windows are
+        timed again.  Host draws are consumed identically on both paths, so the choice changes no random stream."""
         self.model = model
+        self.adaptive = (os.environ.get("JT_GRAPH_ADAPTIVE", "1") != "0") if adaptive is None else bool(adaptive)
+        self.policy = {}      # stage key -> _StageProbe
+        self.decisions = []   # (iteration, grid, choice, ms eager, ms replayed) per timed pair of windows (tools/converge.py)
         self.min_repeats = int(min_repeats)
         self.max_graphs = int(max_graphs)
         self.cache = {}
@@ -113,7 +143,7 @@ class GraphedTrainStep:
         self.last_var = None
         self.eager_rays = {}  # (grid, samples per ray) -> most rays an EAGER step has rendered: the persistent
         #                       workspaces fit that many, and a capture is not allowed to grow them
-        self.stats = dict(replayed=0, captured=0, eager=0)
+        self.stats = dict(replayed=0, captured=0, eager=0, eager_by_choice=0)
 
     # ------------------------------------------------------------------------------------------------------
     def _eligible(self, opt):
@@ -220,6 +250,24 @@ class GraphedTrainStep:
         if epoch != self.epoch:  # optimizer rebuilt (grid upsampled) or a workspace moved: every graph is stale
             self._drop_all()
             self.epoch = epoch
+        probe = None
+        if self.adaptive:
+            sk = epoch + (tuple(g.nerf.resolution), int(g.nerf.n_samples), int(opt.nerf.n_rays))
+            probe = self.policy.get(sk)
+            if probe is None:
+                if len(self.policy) > 64:
+                    self.policy.clear()
+                probe = self.policy[sk] = _StageProbe()
+            if probe.state == "decided":
+                probe.since += 1
+                if probe.since >= self.REPROBE:
+                    probe.state, probe.n = "replay_probe", -self.WINDOW_LEAD
+                elif probe.choice == "eager":   # nothing below is needed, not even the signature
+                    self.stats["eager"] += 1
+                    self.stats["eager_by_choice"] += 1
+                    return self._eager(opt, var)
+            if probe.state == "eager_probe":
+                return self._eager_window(probe, opt, var)
         # NumPy's state is saved (40 us) only while this iteration could still end on the eager path, i.e. until the
         # graphs of all lattice shapes of the current signature exist
         base = self._signature(opt, var, 0, 0)
@@ -249,12 +297,16 @@ class GraphedTrainStep:
             if n <= self.min_repeats or not fits:
                 np.random.set_state(np_state)
                 self.stats["eager"] += 1
+                if probe is not None:
+                    probe.n = -self.WINDOW_LEAD   # a replay window is made of replays only
                 return self._eager(opt, var, coin)
             if os.environ.get("JT_GRAPH_DEBUG") == "1" and self.cache:
                 near = min(self.cache, key=lambda k: sum(a != b for a, b in zip(k, sig)))
                 print("graphed: capture #%d at it %d, differs from the nearest graph in fields %s"
                       % (self.stats["captured"] + 1, m.it, [i for i, (a, b) in enumerate(zip(near, sig)) if a != b]),
                       flush=True)
+            if probe is not None:
+                probe.n = -self.WINDOW_LEAD
             e = self._capture(opt, var, sig, ny, nx, step, blur, coin)
             if (id(m.optim), ops.workspace_generation()) != self.epoch or e is None:
                 # capture is not allowed to move anything; if it did, start over on the eager path
@@ -275,7 +327,17 @@ class GraphedTrainStep:
             self._zvals_static(opt, tf, int(g.nerf.n_samples))   # this iteration's near plane
         ops.poke_floats(self._loss_weights(opt), list(m.fused_loss_weights(opt)))
         m.optim.prepare_step(e.stepped)
+        timing = probe is not None and probe.state == "replay_probe"
+        if timing and probe.n == 0:
+            torch.cuda.synchronize()
+            probe.t0 = time.perf_counter()
         e.graph.replay()
+        if timing:
+            probe.n += 1
+            if probe.n == self.WINDOW:
+                torch.cuda.synchronize()
+                probe.t_replay = (time.perf_counter() - probe.t0) / self.WINDOW
+                probe.state, probe.n = "eager_probe", -self.WINDOW_LEAD
         self.stats["replayed"] += 1
         pg = m.optim_pose.param_groups[0]
         if opt.optim.warmup_pose:  # model/bat.py:98-100,108-110 (a factor of one past the warm-up, which eligibility ensures)
@@ -310,6 +372,27 @@ class GraphedTrainStep:
         g.nerf.set_progress(m.it / opt.max_iter)
         self.last_var = e.var
         return e.loss
+
+    def _eager_window(self, probe, opt, var):
+        """One iteration of the timed eager window; the last one chooses the stage's launch mode (see __init__)."""
+        if probe.n == 0:
+            torch.cuda.synchronize()
+            probe.t0 = time.perf_counter()
+        self.stats["eager"] += 1
+        self.stats["eager_by_choice"] += 1
+        loss = self._eager(opt, var)
+        probe.n += 1
+        if probe.n == self.WINDOW:
+            torch.cuda.synchronize()
+            probe.t_eager = (time.perf_counter() - probe.t0) / self.WINDOW
+            probe.choice = "eager" if probe.t_eager < self.EAGER_GAIN * probe.t_replay else "replay"
+            probe.state, probe.n, probe.since = "decided", -self.WINDOW_LEAD, 0
+            nerf = self.model.graph.nerf
+            self.decisions.append((int(self.model.it), tuple(int(v) for v in nerf.resolution), probe.choice,
+                                   round(probe.t_eager * 1e3, 3), round(probe.t_replay * 1e3, 3)))
+            if os.environ.get("JT_GRAPH_DEBUG") == "1":
+                print("graphed: it %d grid %s -> %s (%.3f ms eager, %.3f ms replayed)" % self.decisions[-1], flush=True)
+        return loss
 
     @staticmethod
     def _supervision_words(var, use_edge):

@@ -918,7 +918,10 @@ class Model(torch.nn.Module):
             # the eager step is bound by the host's ~60 launches (1.8 ms eager against 1.0 ms replayed on the converged
             # synthetic scene); iterations the stepper cannot capture (sharded ranks, first iterations of a stage) run eager
             from ..graphed import GraphedTrainStep
+            # (per grid stage the stepper measures whether the replay or the eager launch is the faster one and stays with
+            #  it: the late, GPU-bound stages end up eager, with the weight-gradient GEMMs forked beside the scatter)
             stepper = GraphedTrainStep(self)
+        self.train_stepper = stepper  # its .stats / .decisions: what ran replayed, what ran eager and why
         for it in range(int(opt.max_iter)):
             self.it = it
             if _has(opt, "early_stop_iter") and opt.early_stop_iter == it:

@@ -43,7 +43,7 @@ def _build(seed=0, blur=False):
     return opt, model, var0
 
 
-def _run(use_graph, K, it0=0, blur=False, swap_images=False):
+def _run(use_graph, K, it0=0, blur=False, swap_images=False, windows=None):
     from joint_tensorf_amd.graphed import GraphedTrainStep
     from joint_tensorf_amd.options import Opt
     opt, model, var0 = _build(blur=blur)
@@ -51,6 +51,8 @@ def _run(use_graph, K, it0=0, blur=False, swap_images=False):
     model.graph.nerf.set_progress(it0 / opt.max_iter)
     np.random.seed(5)
     stepper = GraphedTrainStep(model, min_repeats=0) if use_graph else None
+    if windows is not None:  # (WINDOW, WINDOW_LEAD, REPROBE) of the per-stage launch-mode choice, shrunk to the test's length
+        stepper.WINDOW, stepper.WINDOW_LEAD, stepper.REPROBE = windows
     losses = []
     orig_randint = np.random.randint
     alt_image = (0.25 + 0.5 * var0.image).contiguous()  # a second supervising image set (another 2-D blur scale)
@@ -69,6 +71,8 @@ def _run(use_graph, K, it0=0, blur=False, swap_images=False):
         losses.append([float(loss.all.detach()), float(loss.render.detach()), float(loss.L1.detach())])
         model.after_iteration(opt)
     sd = {k: v.detach().clone() for k, v in model.graph.state_dict().items()}
+    if use_graph:
+        stepper.stats["decisions"] = list(stepper.decisions)
     return np.array(losses), sd, (stepper.stats if use_graph else None), np.random.get_state()[1][:8].copy()
 
 
@@ -333,6 +337,27 @@ def test_graph_replay_is_bit_identical_to_eager_in_deterministic_mode(it0, blur)
     finally:
         lib.jt_set_deterministic(prev)
     assert stats["replayed"] >= 8, stats
+    assert (rs_e == rs_g).all()
+    np.testing.assert_array_equal(l_g, l_e)
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_g[k]), k
+
+
+def test_launch_mode_choice_times_both_paths_and_leaves_the_trajectory_alone():
+    """GraphedTrainStep's per-stage choice between replay and eager launch (timed windows of each, graphed.py): with the
+    windows shrunk to three iterations the 40 iterations of this run pass through replay windows, eager windows, decisions
+    and re-probes -- and, in JT_DETERMINISTIC mode, end bit-identical to the plain eager loop with the same host random
+    stream, whatever was chosen."""
+    from joint_tensorf_amd._lib import lib
+    prev = lib.jt_set_deterministic(1)
+    try:
+        l_e, sd_e, _, rs_e = _run(False, 40, 9000, False)
+        l_g, sd_g, stats, rs_g = _run(True, 40, 9000, False, windows=(3, 1, 5))
+    finally:
+        lib.jt_set_deterministic(prev)
+    assert len(stats["decisions"]) >= 2, stats
+    assert all(c in ("eager", "replay") and te > 0 and tr > 0 for _, _, c, te, tr in stats["decisions"]), stats
+    assert stats["eager_by_choice"] >= 2 * 4 and stats["replayed"] >= 2 * 4, stats   # both kinds of window ran at least twice
     assert (rs_e == rs_g).all()
     np.testing.assert_array_equal(l_g, l_e)
     for k in sd_e:

@@ -141,6 +141,9 @@ def main():
                           trans_end=round(t1, 5), rot_gain=round(r0 / max(r1, 1e-9), 1),
                           trans_gain=round(t0 / max(t1, 1e-9), 1), rot_rel_deg_end=round(rrel, 4), test_psnr=round(res.psnr, 2),
                           psnr_per_view=[round(p, 2) for p in res.psnr_per_view])), flush=True)
+    st = getattr(model, "train_stepper", None)
+    if st is not None:  # which grid stages ran replayed, which eager: (iteration, grid, choice, host ms eager, GPU ms replayed)
+        print(json.dumps(dict(launch=st.stats, launch_mode_per_stage=st.decisions)), flush=True)
 
 
 if __name__ == "__main__":
