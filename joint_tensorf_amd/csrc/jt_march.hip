@@ -1004,7 +1004,10 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
     }
     if (!found) return JT_ERR_UNSUPPORTED;
   }
-  const int blocks = (int)std::min<long>(3 * ((witems + nw - 1) / nw), 255L * (16 / nw));  // 85 / 170 workgroups per plane
+  // (JT_WALK_WGS, read once: fewer workgroups -- a multiple of three -- leave CUs to whatever runs beside the walk)
+  static const int wgs_env = [] { const char* e = getenv("JT_WALK_WGS"); return e ? atoi(e) : 0; }();
+  const long wg_cap = wgs_env > 0 ? std::min<long>(wgs_env / 3 * 3, 255L * (16 / nw)) : 255L * (16 / nw);
+  const int blocks = (int)std::min<long>(3 * ((witems + nw - 1) / nw), std::max<long>(wg_cap, 3));  // 85 / 170 workgroups per plane
 #define JT_WALK_ONE(CD_, DET_, LL_, NW_)                                                                                    \
   do {                                                                                                                      \
     static bool attr = false;                                                                                               \

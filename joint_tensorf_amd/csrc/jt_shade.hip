@@ -1536,6 +1536,13 @@ extern "C" int jt_debug_read_stamps(unsigned long long* out8) {
 // well (281 + 994 against 1 365 us fused; with the fp32 chain the fused kernel wins: profiles/round4_bwd_split_ablation.txt).
 // JT_BWD_SPLIT (read once) overrides.
 static std::atomic<int> g_bwd_split{-2};
+// Workgroups of k_shade_scatter (persistent, one per CU: its LDS fills the CU).  JT_SCATTER_WGS (read once) caps them -- a
+// profiling knob: the scatter's time is inversely proportional to its workgroups (256: 0.96 ms, 192: 1.25, 128: 1.88,
+// profiles/round5_scatter_beside_gemms.txt), i.e. the float-atomic path is a PER-CU limit and leaving CUs to the forked GEMMs loses.
+static int scatter_wgs() {
+  static const int v = [] { const char* e = getenv("JT_SCATTER_WGS"); const int n = e ? atoi(e) : 0; return n > 0 ? std::min(n, 256) : 256; }();
+  return v;
+}
 static int bwd_split_mode() {
   int m = g_bwd_split.load(std::memory_order_relaxed);
   if (m < -1) {
@@ -1899,7 +1906,7 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
       attr = true;                                                                                                      \
     }                                                                                                                   \
     const long nbatch = ((long)ccap + 4 * RUN_ - 1) / (4 * RUN_);                                                       \
-    const int sblocks = (int)std::min<long>((nbatch + SW_ - 1) / SW_, 256L);                                            \
+    const int sblocks = (int)std::min<long>((nbatch + SW_ - 1) / SW_, (long)scatter_wgs());                             \
     hipLaunchKernelGGL((k_shade_scatter<C, DET_, RUN_, SW_, FL_>), dim3(sblocks), dim3(SW_ * 64), lds_s, st, D, M, G,   \
                        offset, R, g_xyz, rc, start, ccap, cap, bad, line_floats);                                       \
   }
