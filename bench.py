@@ -405,6 +405,13 @@ def instep_roofline(timers, n_comp_app, n_comp_density=16):
             out[kind]["launch_ms_parts_note"] = ("the fork event behind the chain kernel splits launch_ms: chain = "
                                                  "k_shade_bwd<split>, scatter = k_shade_scatter (the gather + gradient bytes the "
                                                  "roofline counts all move in the scatter; the chain streams records)")
+            if n_comp_app >= 48 and os.environ.get("JT_NO_AUX") != "1" and not os.environ.get("JT_SCATTER_WGS"):
+                # (jt_shade.hip: scatter_wgs) the scatter shares the chip ON PURPOSE: its launch takes 1.25 ms instead of the
+                # 0.96 ms of a 256-workgroup launch, the step 2 % less
+                out[kind]["shares_the_chip"] = ("k_shade_scatter runs on 192 of the 256 CUs (24 per XCD) while the four "
+                                                "weight-gradient GEMMs run on the other 64 from the auxiliary stream: launch_ms "
+                                                "is the duration of a launch that has 3/4 of the chip (0.96 ms scatter + chain on "
+                                                "all of it: JT_SCATTER_WGS=256, where the step is 2 % slower)")
     return out
 
 

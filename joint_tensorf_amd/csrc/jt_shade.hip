@@ -1536,12 +1536,16 @@ extern "C" int jt_debug_read_stamps(unsigned long long* out8) {
 // well (281 + 994 against 1 365 us fused; with the fp32 chain the fused kernel wins: profiles/round4_bwd_split_ablation.txt).
 // JT_BWD_SPLIT (read once) overrides.
 static std::atomic<int> g_bwd_split{-2};
-// Workgroups of k_shade_scatter (persistent, one per CU: its LDS fills the CU).  JT_SCATTER_WGS (read once) caps them -- a
-// profiling knob: the scatter's time is inversely proportional to its workgroups (256: 0.96 ms, 192: 1.25, 128: 1.88,
-// profiles/round5_scatter_beside_gemms.txt), i.e. the float-atomic path is a PER-CU limit and leaving CUs to the forked GEMMs loses.
-static int scatter_wgs() {
-  static const int v = [] { const char* e = getenv("JT_SCATTER_WGS"); const int n = e ? atoi(e) : 0; return n > 0 ? std::min(n, 256) : 256; }();
-  return v;
+// Workgroups of k_shade_scatter (persistent, one per CU: its LDS fills the CU).  The scatter's time is inversely proportional to
+// its workgroups (256: 0.96 ms, 192: 1.25, 128: 1.88): the float-atomic path is a PER-CU limit.  All the same the 48-channel
+// scatter runs on 192 CUs -- 24 per XCD -- while the weight-gradient GEMMs are forked beside it: their 262-368 registers do not
+// fit on a CU that holds a scatter workgroup, on 256 scatter workgroups they start when the scatter ends and the launch stream
+// idles ~0.39 ms at the join; with 8 CUs per XCD to themselves they are done when the longer scatter is -- 3.00 against 3.07 ms
+// per step, six alternating repeats (188 / 196 workgroups, which do not divide by the XCDs, lose 2-5 %; the 20-channel scene,
+// whose GEMMs are small, loses 2 % and keeps 256; profiles/round5_scatter_beside_gemms.txt).  JT_SCATTER_WGS (read once) overrides.
+static int scatter_wgs(bool gemms_beside) {
+  static const int v = [] { const char* e = getenv("JT_SCATTER_WGS"); const int n = e ? atoi(e) : 0; return n > 0 ? std::min(n, 256) : 0; }();
+  return v ? v : (gemms_beside ? 192 : 256);
 }
 static int bwd_split_mode() {
   int m = g_bwd_split.load(std::memory_order_relaxed);
@@ -1906,7 +1910,7 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
       attr = true;                                                                                                      \
     }                                                                                                                   \
     const long nbatch = ((long)ccap + 4 * RUN_ - 1) / (4 * RUN_);                                                       \
-    const int sblocks = (int)std::min<long>((nbatch + SW_ - 1) / SW_, (long)scatter_wgs());                             \
+    const int sblocks = (int)std::min<long>((nbatch + SW_ - 1) / SW_, (long)scatter_wgs(use_aux && C::CA >= 48));                             \
     hipLaunchKernelGGL((k_shade_scatter<C, DET_, RUN_, SW_, FL_>), dim3(sblocks), dim3(SW_ * 64), lds_s, st, D, M, G,   \
                        offset, R, g_xyz, rc, start, ccap, cap, bad, line_floats);                                       \
   }
