@@ -192,6 +192,29 @@ def _aux_stream(dev):
     return _AUX[key]
 
 
+# Early optimizer step of the appearance factors (round 5): see RenderRays.backward.  JT_ADAM_EARLY=0 switches it off.
+ADAM_EARLY = os.environ.get("JT_ADAM_EARLY", "1") != "0"
+_EARLY_GRADS = {}    # device index -> (event behind the appearance backward, addresses of the final gradient tensors, their storage)
+_EARLY_EVENTS = {}
+
+
+def _early_event(dev):
+    key = device_key(dev)
+    if key not in _EARLY_EVENTS:
+        with torch.cuda.device(key):
+            _EARLY_EVENTS[key] = torch.cuda.Event()
+    return _EARLY_EVENTS[key]
+
+
+def take_early_grads(dev):
+    """(event, addresses, flat gradient storage, auxiliary stream) of the gradients the last render backward declared final
+    early, once; None when there are none."""
+    if not _EARLY_GRADS:
+        return None
+    e = _EARLY_GRADS.pop(device_key(dev), None)
+    return None if e is None else e + (_aux_stream(dev)[0],)
+
+
 _REG_SCRATCH = {}
 
 
@@ -632,6 +655,8 @@ class RenderRays(torch.autograd.Function):
         g_xyz = torch.empty(cap_alloc, 3, **f32)
         join = None
         g_mlp = [None] * 7
+        if _EARLY_GRADS:
+            _EARLY_GRADS.pop(device_key(dev), None)  # (an earlier backward's offer nobody took)
         dp_on = _DP["world"] > 1 or _DP["force"]
         dp = dp_on and fused_mlp_zero
         if dp_on and not dp and (want_fac or want_mlp):
@@ -694,6 +719,15 @@ class RenderRays(torch.autograd.Function):
             t_bwd_end.record()
         if dp:
             reducer.reduce(2, 3)  # appearance planes + lines are final
+        elif (ADAM_EARLY and want_fac and not det and _use_aux(cfg) and (reg_first or ctx.reg is None or g_reg is None)
+              and not torch.cuda.is_current_stream_capturing()):
+            # the appearance factors' gradients are final HERE (their regulariser part was written before the render backward);
+            # what follows on this stream -- the density backward -- is bound by the float-atomic path and leaves the memory
+            # system idle: an optimizer that asks (optim.VMAdam.step -> take_early_grads) steps these tensors on the auxiliary
+            # stream, beside the density walk, and the rest behind it as before
+            ev = _early_event(dev)
+            ev.record()
+            _EARLY_GRADS[device_key(dev)] = (ev, frozenset(int(t.data_ptr()) for t in list(gap) + list(gal)), gflat)
         g_o = torch.empty(R, 3, **f32)
         g_d = torch.empty(R, 3, **f32)
         mws_bytes = lib.jt_march_backward_workspace_bytes(scene, R)

@@ -117,12 +117,20 @@ class VMAdam(torch.optim.Optimizer):
         return coefs
 
     @torch.no_grad()
-    def launch_step(self, coefs=None):
+    def launch_step(self, coefs=None, only=None, stream=None):
         """One launch over all parameter tensors that have a gradient.  coefs = None: the coefficients `prepare_step` poked
-        into device memory; a list: the same values as launch arguments (same floats, same arithmetic in the kernel)."""
+        into device memory; a list: the same values as launch arguments (same floats, same arithmetic in the kernel).
+        only = (addresses, keep): just the tensors whose GRADIENT's address is (keep = True) / is not (False) among them, with
+        their own coefficients (coefs as a list only); stream: raw handle of the stream to launch on (default: the current)."""
         keep = []
-        stream = _stream()
+        stream = _stream() if stream is None else stream
         for (b1, b2, eps), plist in self._items().items():
+            if only is not None:
+                sel = [k for k, (p, _) in enumerate(plist) if (int(p.grad.data_ptr()) in only[0]) == only[1]]
+                if not sel:
+                    continue
+                plist = [plist[k] for k in sel]
+                coefs = [c for k in sel for c in coefs[2 * k:2 * k + 2]]
             arr = (JtAdamItem * len(plist))()
             for k, (p, group) in enumerate(plist):
                 g = p.grad
@@ -153,6 +161,35 @@ class VMAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         coefs = self.prepare_step(poke=False)
-        if coefs:
+        if not coefs:
+            return loss
+        from . import ops
+        early = None
+        if ops._EARLY_GRADS and len(self._items()) == 1:
+            dev = next(p for g in self.param_groups for p in g["params"] if p.grad is not None).device
+            offer = ops._EARLY_GRADS.get(ops.device_key(dev))
+            # mine = the offered gradients that ARE the .grad of one of my tensors, in the layout the kernel walks (a gradient
+            # that autograd copied, or one that needs a layout copy first, stays on this stream; the pose optimizer has none)
+            mine = frozenset(int(p.grad.data_ptr()) for g in self.param_groups for p in g["params"]
+                             if p.grad is not None and offer is not None and int(p.grad.data_ptr()) in offer[1]
+                             and p.grad.dtype == torch.float32 and self._layout_ok(p.grad, p))
+            if mine:
+                early = ops.take_early_grads(dev)
+        if early is None:
             self.launch_step(coefs)
+            return loss
+        # The tensors whose gradients the render backward declared final behind its appearance half (ops.RenderRays.backward)
+        # are stepped on the auxiliary stream from that point on, i.e. beside the density backward, which waits on the
+        # float-atomic path while this launch streams parameters, moments and gradients; everything else on this stream as
+        # before, and this stream goes on only when both are done.
+        ev, _, storage, aux = early
+        addresses = mine
+        aux.wait_event(ev)
+        storage.record_stream(aux)
+        self.launch_step(coefs, only=(addresses, True), stream=aux.cuda_stream)
+        done = self.__dict__.setdefault("_early_done", {}).setdefault(ops.device_key(dev), torch.cuda.Event())
+        done.record(aux)
+        self.launch_step(coefs, only=(addresses, False))
+        torch.cuda.current_stream().wait_event(done)
+        self.early_steps = getattr(self, "early_steps", 0) + 1
         return loss

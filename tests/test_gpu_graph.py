@@ -73,7 +73,9 @@ def _run(use_graph, K, it0=0, blur=False, swap_images=False, windows=None):
     sd = {k: v.detach().clone() for k, v in model.graph.state_dict().items()}
     if use_graph:
         stepper.stats["decisions"] = list(stepper.decisions)
-    return np.array(losses), sd, (stepper.stats if use_graph else None), np.random.get_state()[1][:8].copy()
+    if not use_graph:
+        return np.array(losses), sd, dict(early=getattr(model.optim, "early_steps", 0)), np.random.get_state()[1][:8].copy()
+    return np.array(losses), sd, stepper.stats, np.random.get_state()[1][:8].copy()
 
 
 @pytest.mark.parametrize("it0,blur", [(0, False), (9000, False), (0, True), (9000, True)])
@@ -362,3 +364,27 @@ def test_launch_mode_choice_times_both_paths_and_leaves_the_trajectory_alone():
     np.testing.assert_array_equal(l_g, l_e)
     for k in sd_e:
         assert torch.equal(sd_e[k], sd_g[k]), k
+
+
+@pytest.mark.parametrize("it0", [0, 9000])
+def test_early_optimizer_step_of_the_appearance_factors_leaves_the_trajectory_alone(it0):
+    """ops.ADAM_EARLY: an eager iteration steps the appearance factors on the auxiliary stream as soon as the appearance backward
+    is through, beside the density backward (optim.VMAdam.step), everything else behind it as before.  Same trajectory as with
+    the one-launch step on the launch stream, within float-atomics noise (the tolerances of the replay test above), and every
+    iteration did take the early step."""
+    from joint_tensorf_amd import ops
+    K = 16
+    assert ops.ADAM_EARLY
+    l_a, sd_a, st_a, rs_a = _run(False, K, it0)
+    ops.ADAM_EARLY = False
+    try:
+        l_b, sd_b, st_b, rs_b = _run(False, K, it0)
+    finally:
+        ops.ADAM_EARLY = True
+    assert st_a["early"] == K and st_b["early"] == 0, (st_a, st_b)
+    assert (rs_a == rs_b).all()
+    np.testing.assert_allclose(l_a, l_b, rtol=2e-5, atol=1e-9)
+    for k in sd_a:
+        a, b = sd_a[k].float(), sd_b[k].float()
+        assert float((a - b).norm()) <= 1e-4 * (float(a.norm()) + 1e-12), k
+        assert float((a - b).abs().max()) <= 1e-3 * (float(a.abs().max()) + 1e-12), k
