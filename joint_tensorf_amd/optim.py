@@ -93,6 +93,7 @@ class VMAdam(torch.optim.Optimizer):
                 dev = p.device
                 st = self.state[p]
                 if len(st) == 0:
+                    self._state_created = True   # (zero fills on THIS stream just now: see step)
                     st["step"] = 0.0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
@@ -165,7 +166,10 @@ class VMAdam(torch.optim.Optimizer):
             return loss
         from . import ops
         early = None
-        if ops._EARLY_GRADS and len(self._items()) == 1:
+        # (a step that has just created moments filled them on this stream a moment ago -- behind the event the auxiliary
+        #  stream would wait for: that step stays on this stream as a whole)
+        fresh = self.__dict__.pop("_state_created", False)
+        if ops._EARLY_GRADS and not fresh and len(self._items()) == 1:
             dev = next(p for g in self.param_groups for p in g["params"] if p.grad is not None).device
             offer = ops._EARLY_GRADS.get(ops.device_key(dev))
             # mine = the offered gradients that ARE the .grad of one of my tensors, in the layout the kernel walks (a gradient
