@@ -595,7 +595,11 @@ def run_extras():
              ("default_tile_owned_scatter", [], {"JT_BWD_SPLIT": "1", "JT_TILE_CFG": "1"}),
              # ... and through the ONE-kernel backward of rounds 2-4 (fp32 chain + scatter fused, weight gradients on the launch
              # stream): what the default's chain-on-bf16 + scatter + forked weight-gradient GEMMs replaced in round 5
-             ("default_fused_backward_kernel", [], {"JT_BWD_SPLIT": "0", "JT_NO_AUX": "1"})]
+             ("default_fused_backward_kernel", [], {"JT_BWD_SPLIT": "0", "JT_NO_AUX": "1"}),
+             # ... and the default's kernels with the WHOLE chip each: the scatter on 256 CUs, the weight-gradient GEMMs behind it
+             # on the launch stream, the optimizer as one launch -- k_shade_bwd_ms here is chain + scatter ALONE on the chip
+             # (the default's launch shares it with the GEMMs: roofline.shares_the_chip), the step is what sharing buys
+             ("default_every_kernel_alone", [], {"JT_SCATTER_WGS": "256", "JT_NO_AUX": "1", "JT_ADAM_EARLY": "0"})]
     out = {}
     for name, flags, env in cases:
         try:
