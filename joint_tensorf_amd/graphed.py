@@ -44,8 +44,8 @@ class _StageProbe:
     window of consecutive replays is being timed), "eager_probe" (the same number of eager iterations is being timed) or
     "decided" (`choice` holds for the next REPROBE iterations)."""
 
-    def __init__(self):
-        self.state, self.choice, self.n, self.t0, self.since = "replay_probe", "replay", -GraphedTrainStep.WINDOW_LEAD, 0.0, 0
+    def __init__(self, lead):
+        self.state, self.choice, self.n, self.t0, self.since = "replay_probe", "replay", -int(lead), 0.0, 0
         self.t_replay = self.t_eager = None
 
 
@@ -257,7 +257,7 @@ class GraphedTrainStep:
             if probe is None:
                 if len(self.policy) > 64:
                     self.policy.clear()
-                probe = self.policy[sk] = _StageProbe()
+                probe = self.policy[sk] = _StageProbe(self.WINDOW_LEAD)
             if probe.state == "decided":
                 probe.since += 1
                 if probe.since >= self.REPROBE:
