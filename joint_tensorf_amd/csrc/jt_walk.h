@@ -230,8 +230,11 @@ struct RecWalker {
           fixed_add(reinterpret_cast<long long*>(reinterpret_cast<char*>(base) + 2 * (size_t)(off + ck[k])), a[k], bad);
         else if (k < CA / 16)
           JT_WALK_ATOMIC(t0 + 16 * k, a[k]);
-        else
+        else {
+#if !JT_ABL_WALK_TAIL   // profiling knob: the partial last channel group (20 channels: 16 + 4) is dropped -- what its atomics cost
           JT_WALK_ATOMIC(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (off + ck[k])), a[k]);
+#endif
+        }
       }
     }
 #pragma unroll
