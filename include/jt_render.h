@@ -32,8 +32,12 @@ extern "C" {
 /* Bumped whenever a struct layout, an argument list or what an argument must point to changes (round 4 added
  * JtScene.near_plane_dev and grew the regulariser scratch to 640 floats without bumping it: a caller built against the old
  * header would have handed over a shorter struct).  jt_version() returns the value the LIBRARY was built with; the Python
- * binding refuses to load a library whose version differs from this header's. */
-#define JT_VERSION 1100
+ * binding refuses to load a library whose version differs from the one it was written against (joint_tensorf_amd/_lib.py:
+ * JT_ABI_VERSION).  include/jt_render.abi holds a hash of every prototype, struct and constant of this header next to the
+ * version it was taken at: tests/test_abi.py fails when the hash changes without this number changing (round 5 added
+ * jt_reg_losses_fused, removed jt_pose_fused* and redefined matrix-mode bit 2 at version 1100; 1200 = round 6: those changes,
+ * jt_shade_lean_tape / jt_shade_set_lean_tape, the workspace no longer carries the tile lists unless that variant is selected). */
+#define JT_VERSION 1200
 
 #define JT_OK 0
 #define JT_ERR_ARG 1         /* null pointer / bad size */
@@ -304,6 +308,16 @@ int jt_shade_set_chunk_log2(int log2_entries);
  * returns the previous value (any other argument only queries). */
 int jt_shade_bwd_split(void);
 int jt_shade_set_bwd_split(int run);
+/* "Lean tape" (round 6; default 1, environment variable JT_LEAN_TAPE read once): whenever the backward is the split form with
+ * the walker scatter (jt_shade_bwd_split() 8, 16, or -1 resolving to 16), the training forward does NOT record the 3 Ca
+ * plane x line products of a shaded sample (bateRF.py:112-116) -- 576 of the 1 920 record bytes for VM-48, 240 of 1 104 for the
+ * 20-channel scene -- and dBasis (the gradient of tensoRF.py:156's basis_mat) is formed inside the scatter kernel from the
+ * products its walkers hold, instead of by a GEMM over recorded rows.  Same gradients up to the order of the float sums.
+ * jt_shade_workspace_bytes / jt_shade_record_layout follow the mode; like the chunk size and the split mode it must not change
+ * between a jt_shade_forward and its jt_shade_backward (the backward returns JT_ERR_ARG when it can tell).  The setter returns
+ * the previous value; any argument other than 0 / 1 only queries. */
+int jt_shade_lean_tape(void);
+int jt_shade_set_lean_tape(int on);
 int jt_shade_forward(const JtScene* scene, const JtFactors* factors, const JtMlp* mlp, const float* rays_o,
                      const float* rays_d, const float* jitter, const float* zvals, const float* tmin,
                      const int32_t* shade_offset, int n_rays, const int32_t* entry_ray,

@@ -105,6 +105,8 @@ SIGNATURES = {
     "jt_shade_set_chunk_log2": (I, [I]),
     "jt_shade_bwd_split": (I, []),
     "jt_shade_set_bwd_split": (I, [I]),
+    "jt_shade_lean_tape": (I, []),
+    "jt_shade_set_lean_tape": (I, [I]),
     "jt_render_loss_forward": (I, [P, P, P, P, I, I, I, F, F, P, P, P]),
     "jt_render_loss_backward": (I, [P, P, P, P, I, I, I, F, F, P, P, P, P]),
     "jt_render_loss_forward_ind": (I, [P, P, P, I, I, I, I, F, F, P, P, P]),
@@ -162,8 +164,14 @@ def fused_lib():
     return _FUSED[0]
 
 
+# the JT_VERSION of include/jt_render.h that SIGNATURES and the struct mirrors above were written against.  A constant, not a
+# read of the header at import time: a vendored copy of the package has no include/ directory beside it (tests/test_abi.py
+# holds this number, the header's and the library's together)
+JT_ABI_VERSION = 1200
+
+
 def header_version():
-    """JT_VERSION of include/jt_render.h (the header this binding's SIGNATURES / struct mirrors were written against)"""
+    """JT_VERSION of include/jt_render.h (tests only: the repo's include/ directory has to exist)"""
     import re
     src = open(os.path.join(os.path.dirname(HERE), "include", "jt_render.h")).read()
     return int(re.search(r"^#define\s+JT_VERSION\s+(\d+)", src, flags=re.M).group(1))
@@ -181,9 +189,9 @@ def _load():
         fn.argtypes = args
     # a library built from another revision of the header (a stale .so, a JT_LIB_PATH variant of an older tree) would be
     # handed structs and scratch buffers of the wrong size: refuse it here instead of inside a kernel
-    want, got = header_version(), lib.jt_version()
+    want, got = JT_ABI_VERSION, lib.jt_version()
     if want != got:
-        raise ImportError("joint_tensorf_amd: %s reports ABI version %d, include/jt_render.h is %d -- rebuild with "
+        raise ImportError("joint_tensorf_amd: %s reports ABI version %d, this binding was written against %d -- rebuild with "
                           "`python joint_tensorf_amd/build.py --force`" % (LIB_PATH, got, want))
     return lib
 

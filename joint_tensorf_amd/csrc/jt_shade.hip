@@ -32,7 +32,10 @@ namespace jt {
 
 // REC = 1 (training): besides rgb the kernel leaves the tile-blocked records of the layer inputs (see BwdCfg) so
 // that the backward does not have to gather and run the forward chain a second time.  REC = 2: only what a
-// pose-only backward reads (basis output, ReLU sign words, sample coordinates).
+// pose-only backward reads (basis output, ReLU sign words, sample coordinates).  REC = 3 (training, "lean tape", round 6):
+// as 1 without the 3 Ca product rows -- dBasis is then formed inside k_shade_scatter from the plane x line products the
+// walkers hold anyway, and a tile's record block is `rrows` = R_PROD rows instead of REC_FLOATS (1 344 instead of 1 920 bytes
+// per shaded sample for VM-48).  `rrows` is a launch argument in every kernel that addresses records.
 template <class C, int REC>
 __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm, const float* __restrict__ rays_o,
                                                       const float* __restrict__ rays_d,
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
                                                       const int* __restrict__ offset, int R,
                                                       const int* __restrict__ eray, const int* __restrict__ esmp,
                                                       const float* __restrict__ vdir, float* __restrict__ rgb_s,
-                                                      float* __restrict__ rec, int cap) {
+                                                      float* __restrict__ rec, int cap, int rrows) {
   typedef BwdCfg<C> B;
   extern __shared__ __align__(16) float smem[];
   const int total = min(offset[R], cap);
@@ -62,13 +65,13 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
     const int e = tile * 32 + j;
     const bool on = e < total;
     const int ee = on ? e : total - 1;
-    float* rt = REC ? rec + (size_t)tile * B::REC_FLOATS * 32 : nullptr;
+    float* rt = REC ? rec + (size_t)tile * (size_t)rrows * 32 : nullptr;
     EntryGeom g = entry_geom(D, rays_o, rays_d, jitter, zvals, tmin, eray, esmp, ee);
     float vd[3] = {vdir[(size_t)ee * 3], vdir[(size_t)ee * 3 + 1], vdir[(size_t)ee * 3 + 2]};
     if (REC && on && h == 0) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        if (REC == 1) rec_st(rec_at(rt, B::R_VD + c, 4u * (unsigned)j), vd[c]);
+        if (REC & 1) rec_st(rec_at(rt, B::R_VD + c, 4u * (unsigned)j), vd[c]);
         rec_st(rec_at(rt, B::R_GEO + c, 4u * (unsigned)j), g.n[c]);
       }
     }
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
 #pragma unroll
         for (int r = 0; r < 16; ++r) mask1 |= (h1.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
       if (on) rec_st(rec_at(rt, B::R_MASK, 4u * (unsigned)j + 128u * (unsigned)h), __uint_as_float(mask1));
-      if (REC == 1) rec_store<C::MT>(rt, B::R_H1, h1.v, j, h, on);
+      if (REC & 1) rec_store<C::MT>(rt, B::R_H1, h1.v, j, h, on);
     }
     Hidden<C> h2 = layer2<C>(smem, h1, j, h);
     relu_<C>(h2);
@@ -94,8 +97,8 @@ __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm
 #pragma unroll
         for (int r = 0; r < 16; ++r) mask2 |= (h2.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u;
       if (on) rec_st(rec_at(rt, B::R_MASK + 2, 4u * (unsigned)j + 128u * (unsigned)h), __uint_as_float(mask2));
-      if (REC == 1) rec_store<C::MT>(rt, B::R_MID + HOFF, h2.v, j, h, on);
-      if (REC == 1 && C::KIND != JT_MLP_FEA) {
+      if (REC & 1) rec_store<C::MT>(rt, B::R_MID + HOFF, h2.v, j, h, on);
+      if ((REC & 1) && C::KIND != JT_MLP_FEA) {
         float pe[12];
         view_pe(vd, pm, pe);
         if (on && h == 0) {
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(JT_B16_THREADS) void k_shade_fwd_b16(Dev D, MlpDev 
                                                       const int* __restrict__ offset, int R,
                                                       const int* __restrict__ eray, const int* __restrict__ esmp,
                                                       const float* __restrict__ vdir, float* __restrict__ rgb_s,
-                                                      float* __restrict__ rec, int cap) {
+                                                      float* __restrict__ rec, int cap, int rrows) {
   typedef BwdCfg<C> B;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   typedef B16Cfg<C> Q;
@@ -177,14 +180,14 @@ __global__ __launch_bounds__(JT_B16_THREADS) void k_shade_fwd_b16(Dev D, MlpDev 
     e = tile * 32 + j; \
     on = e < total; \
     const int ee = on ? e : total - 1; \
-    rt = REC ? rec + (size_t)tile * B::REC_FLOATS * 32 : nullptr; \
+    rt = REC ? rec + (size_t)tile * (size_t)rrows * 32 : nullptr; \
     EntryGeom g = entry_geom(D, rays_o, rays_d, jitter, zvals, tmin, eray, esmp, ee); \
     vd0 = vdir[(size_t)ee * 3], vd1 = vdir[(size_t)ee * 3 + 1], vd2 = vdir[(size_t)ee * 3 + 2]; \
     const float vd[3] = {vd0, vd1, vd2}; \
     if (REC && on && h == 0) { \
 _Pragma("unroll") \
       for (int c = 0; c < 3; ++c) { \
-        if (REC == 1) rec_st(rec_at(rt, B::R_VD + c, 4u * (unsigned)j), vd[c]); \
+        if (REC & 1) rec_st(rec_at(rt, B::R_VD + c, 4u * (unsigned)j), vd[c]); \
         rec_st(rec_at(rt, B::R_GEO + c, 4u * (unsigned)j), g.n[c]); \
       } \
     } \
@@ -205,7 +208,7 @@ _Pragma("unroll") \
 _Pragma("unroll") \
         for (int r = 0; r < 16; ++r) mask1 |= (h1.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u; \
       if (on) rec_st(rec_at(rt, B::R_MASK, 4u * (unsigned)j + 128u * (unsigned)h), __uint_as_float(mask1)); \
-      if (REC == 1) rec_store<C::MT>(rt, B::R_H1, h1.v, j, h, on); \
+      if (REC & 1) rec_store<C::MT>(rt, B::R_H1, h1.v, j, h, on); \
     } \
     Hidden<C> h2 = layer2_b16<C>(img, tail, h1, h, lane); \
     relu_<C>(h2); \
@@ -216,8 +219,8 @@ _Pragma("unroll") \
 _Pragma("unroll") \
         for (int r = 0; r < 16; ++r) mask2 |= (h2.v[mt][r] > 0.f) ? (1u << (mt * 16 + r)) : 0u; \
       if (on) rec_st(rec_at(rt, B::R_MASK + 2, 4u * (unsigned)j + 128u * (unsigned)h), __uint_as_float(mask2)); \
-      if (REC == 1) rec_store<C::MT>(rt, B::R_MID + HOFF, h2.v, j, h, on); \
-      if (REC == 1 && C::KIND != JT_MLP_FEA) { \
+      if (REC & 1) rec_store<C::MT>(rt, B::R_MID + HOFF, h2.v, j, h, on); \
+      if ((REC & 1) && C::KIND != JT_MLP_FEA) { \
         float pe[12]; \
         view_pe(vd, pm, pe); \
         if (on && h == 0) { \
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
                                                       const float* __restrict__ rgb_s,
                                                       const float* __restrict__ g_rgb_s, float* __restrict__ g_xyz,
                                                       float* __restrict__ rec, int chunk_start, int chunk_cap,
-                                                      int cap, int ablate, unsigned* __restrict__ bad) {
+                                                      int cap, int ablate, unsigned* __restrict__ bad, int rrows) {
   typedef BwdCfg<C> B;
   extern __shared__ __align__(16) float smem[];
   const int total = min(offset[R], cap);
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
                   : smem + C::LDS_FLOATS + wv * (SPLIT ? B::STASH_FLOATS : B::WAVE_FLOATS);
   float* geo = tp + B::TP_ROWS * B::TP_LD;
   float* gxyz = geo + 32 * 4;
-  const size_t RC = B::REC_FLOATS;
+  const size_t RC = (size_t)rrows;
   constexpr int HOFF = (C::KIND == JT_MLP_FEA) ? 0 : 12;
   const XcdShare xs = xcd_share(ntiles, nblk);  // tiles of neighbouring samples meet in one XCD's L2
   // (the two waves of a SIMD taking the chain and the scatter of their tiles in opposite order, in lock step by a workgroup
@@ -670,16 +673,29 @@ template <class C>
 struct ScatCfg {
   static constexpr int NCH = (C::CA + 15) / 16;
   static constexpr int KS = (C::APP + 3) / 4;             // K steps of the 16x16x4 product over basis_mat's rows
-  static constexpr int BT_FLOATS = 3 * NCH * KS * 64;     // basis^T operand image [plane][channel group][K step][lane]
-  static constexpr int wave_floats(int run) { return 4 * run * (4 + 4 + kRecWords); }  // geo, gxyz, step records
+  static constexpr int BT_FLOATS = NCH * KS * 64;         // basis^T operand image of ONE plane [channel group][K step][lane]
+  static constexpr int GT_FLOATS = 32 * 16;               // (dBasis) a wave's GF rows of a block, transposed: [row a][16 samples]
+  static constexpr int RED_FLOATS = 32 * C::CA;           // (dBasis) the workgroup's sum of one plane's slice [row a][channel]
+  // geo, gxyz, step records (+ the transposition tile)
+  static constexpr int wave_floats(int run, bool db) { return 4 * run * (4 + 4 + kRecWords) + (db ? GT_FLOATS : 0); }
+  static constexpr int DB_SLAB = 3 * 32 * C::CA;          // floats a workgroup leaves in its dBasis slab [plane][row a][channel]
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // FLAGS bit 0 (not with DET): the line gradients of the pass's plane are summed in a workgroup-private LDS copy of the line
 // (line_floats = the longest line x channels; LDS float atomics) and added to the real gradient once per workgroup and plane --
-// a fifth of the scatter's global atomic segments.  (Forming dBasis here as well -- the walker has the plane x line products in
-// registers -- was measured at + 0.6 ms and removed: profiles/round4_bwd_split_ablation.txt.)
+// a fifth of the scatter's global atomic segments.
+// FLAGS bit 1 (round 6, "lean tape"): dBasis is formed HERE.  dBasis[a][pl Ca + ch] = sum over samples of GF[a][s] prod[ch][s],
+// and the walker of lane (group, channel) holds prod = (plane value) x (line value) of its group's current sample: per step
+// that is the B operand of a v_mfma_f32_16x16x4_f32 whose K axis is the four groups' samples.  The A operand -- GF[a][sample of
+// group k] in lane (a, k) -- is the block's GF rows, which loadA already fetched for basis^T GF in the OTHER orientation
+// (lane = sample, K = row): they go through a 2 KB LDS tile per wave once per block (seven 4-byte writes, two 16-byte reads per
+// lane) instead of being loaded again per step -- round 4 formed dBasis here with two GF loads per step, which queue behind the
+// step's flush atomics (a wave's vector-memory operations retire in order), and paid + 0.6 ms for it.  2 NCH accumulator quads
+// per lane; a plane's slice is summed over the waves in LDS in a fixed order and left in the workgroup's slab for
+// k_dbasis_reduce.  With it the forward does not record the 3 Ca products (576 of 1 920 bytes per sample for VM-48) and the
+// dBasis GEMM (k_wgrad_b16<1, NTB, 0>, 184 us alone) is gone.
 // The plane loop is OUTSIDE the batch loop (one LDS line at a time): the coordinate gradients of a sample go to g_xyz as
 // store (plane 0) / load-add-store (planes 1, 2) by the same lane.
 template <class C, bool DET, int RUN, int WAVES, int FLAGS>
@@ -687,10 +703,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_shade_scatter(Dev D, MlpDev M, J
                                                               int R, float* __restrict__ g_xyz,
                                                               const float* __restrict__ rec, int chunk_start,
                                                               int chunk_cap, int cap, unsigned* __restrict__ bad,
-                                                              int line_floats) {
+                                                              int line_floats, int rrows, float* __restrict__ dbslab) {
   typedef BwdCfg<C> B;
   typedef ScatCfg<C> Q;
   constexpr bool LLINE = (FLAGS & 1) && !DET;
+  constexpr bool DB = (FLAGS & 2) != 0;
   constexpr int NS = 4 * RUN, NB = RUN / 4, NCH = Q::NCH, KS = Q::KS;
   extern __shared__ __align__(16) float smem[];
   const int total = min(offset[R], cap);
@@ -698,23 +715,37 @@ __global__ __launch_bounds__(WAVES * 64) void k_shade_scatter(Dev D, MlpDev M, J
   const int nbatch = (n_chunk + NS - 1) / NS;
   const int nblk = min((int)gridDim.x, (nbatch + WAVES - 1) / WAVES);  // the grid is sized for the worst case
   if ((int)blockIdx.x >= nblk) return;
-  for (int it = threadIdx.x; it < Q::BT_FLOATS; it += WAVES * 64) {
-    const int ln = it & 63, blk = it >> 6, k = blk % KS, c = (blk / KS) % NCH, pl = blk / (KS * NCH);
-    const int a = 4 * k + (ln >> 4), ch = 16 * c + (ln & 15);
-    smem[it] = (a < C::APP && ch < C::CA) ? M.basis[a * C::NC + pl * C::CA + ch] : 0.f;
-  }
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* sline = smem + Q::BT_FLOATS;                                    // [line cell][channel] of the pass's plane
-  float* geo = sline + (LLINE ? line_floats : 0) + wv * Q::wave_floats(RUN);
+  float* red = sline + (LLINE ? line_floats : 0);                        // (DB) [row a][channel]
+  float* geo = red + (DB ? Q::RED_FLOATS : 0) + wv * Q::wave_floats(RUN, DB);
   float* gxyz = geo + NS * 4;
   float* recs = gxyz + NS * 4;
-  const size_t RC = B::REC_FLOATS;
+  float* gft = recs + NS * kRecWords;                                    // (DB) [32 rows][16 samples]
+  if (DB) {  // rows past 4 KS are never written: they must read as zeros
+#pragma unroll
+    for (int i = 0; i < Q::GT_FLOATS / 64; ++i) gft[lane + 64 * i] = 0.f;
+  }
+  const size_t RC = (size_t)rrows;
   const XcdShare xs = xcd_share(nbatch, nblk);
 #pragma unroll 1
   for (int pl = 0; pl < 3; ++pl) {
+    // the plane's basis^T operand image [channel group][K step][lane]: lane (cl, grp) of step k holds basis[4 k + grp][ch]
+    for (int it = threadIdx.x; it < Q::BT_FLOATS; it += WAVES * 64) {
+      const int ln = it & 63, blk = it >> 6, k = blk % KS, c = blk / KS;
+      const int a = 4 * k + (ln >> 4), ch = 16 * c + (ln & 15);
+      smem[it] = (a < C::APP && ch < C::CA) ? M.basis[a * C::NC + pl * C::CA + ch] : 0.f;
+    }
     if (LLINE)
       for (int i = threadIdx.x; i < D.ll[pl] * C::CA; i += WAVES * 64) sline[i] = 0.f;
     __syncthreads();
+    f32x4 dB[DB ? 2 : 1][NCH];
+    if (DB) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) dB[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     for (int batch = xs.lo + xs.rank * WAVES + wv; batch < xs.hi; batch += xs.peers * WAVES) {
       int ln = lane;
       asm volatile("" : "+v"(ln));  // (keeps per-lane address math inside the loop, see k_shade_bwd)
@@ -762,7 +793,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_shade_scatter(Dev D, MlpDev M, J
 #pragma unroll
       for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int k = 0; k < KS; ++k) bop[c][k] = smem[((pl * NCH + c) * KS + k) * 64 + ln];
+        for (int k = 0; k < KS; ++k) bop[c][k] = smem[(c * KS + k) * 64 + ln];
       wave_lds_sync();
       const float* P = D.aP[pl];
       const float* Ln = D.aL[pl];
@@ -775,11 +806,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_shade_scatter(Dev D, MlpDev M, J
                              D.inv[my_axis];
       const float* rec0 = recs + (grp * RUN) * kRecWords;
       float* gx0 = gxyz + (grp * RUN) * 4 + my_axis;
-      auto step = [&](TapBuf<NCH>& tv, int q, const float* g) {
+      // (DB) gfa[m][r]: GF[cl + 16 m][the sample group grp walks at step r of the block] -- the A operand of the dBasis product
+      f32x4 gfa[2];
+      auto step = [&](TapBuf<NCH>& tv, int q, const float* g, int r) {
         const float* sr = rec0 + q * kRecWords;
         wk.advance(sr);
         float aix = 0.f, aiy = 0.f, ail = 0.f;
-        wk.add(tv, sr, g, aix, aiy, ail);
+        float prod[NCH];
+        wk.template add<DB>(tv, sr, g, aix, aiy, ail, prod);
+        if (DB) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) dB[m][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(gfa[m][r], prod[c], dB[m][c], 0, 0, 0);
+        }
         aix = row16_sum(aix);
         aiy = row16_sum(aiy);
         ail = row16_sum(ail);
@@ -797,6 +837,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_shade_scatter(Dev D, MlpDev M, J
 #pragma unroll
           for (int k = 0; k < KS; ++k) dv[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bop[c][k], dv[c], 0, 0, 0);
         }
+        if (DB) {
+          // the block's GF rows once more, transposed through the wave's LDS tile: lane (cl, grp) holds GF[4 k + grp][sample cl]
+          wave_lds_sync();  // (the previous block's reads are done)
+#pragma unroll
+          for (int k = 0; k < KS; ++k) gft[(4 * k + grp) * 16 + cl] = av[k];
+          wave_lds_sync();
+          gfa[0] = *reinterpret_cast<const f32x4*>(gft + cl * 16 + 4 * grp);
+          gfa[1] = *reinterpret_cast<const f32x4*>(gft + (cl + 16) * 16 + 4 * grp);
+        }
         if (b + 1 < NB) loadA(b + 1, av);  // the next block's rows are in flight while this block is walked
         float g[4][NCH];
 #pragma unroll
@@ -805,13 +854,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_shade_scatter(Dev D, MlpDev M, J
         }
         const int q = 4 * b;
         wk.load(bufB, P, Ln, rec0 + (q + 1) * kRecWords);
-        step(bufA, q, g[0]);
+        step(bufA, q, g[0], 0);
         wk.load(bufA, P, Ln, rec0 + (q + 2) * kRecWords);
-        step(bufB, q + 1, g[1]);
+        step(bufB, q + 1, g[1], 1);
         wk.load(bufB, P, Ln, rec0 + (q + 3) * kRecWords);
-        step(bufA, q + 2, g[2]);
+        step(bufA, q + 2, g[2], 2);
         if (b + 1 < NB) wk.load(bufA, P, Ln, rec0 + (q + 4) * kRecWords);
-        step(bufB, q + 3, g[3]);
+        step(bufB, q + 3, g[3], 3);
       };
       if (NB <= 2) {
 #pragma unroll
@@ -838,7 +887,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_shade_scatter(Dev D, MlpDev M, J
       }
       wave_lds_sync();
     }
-    if (LLINE) __syncthreads();
+    __syncthreads();
     if (LLINE) {
       float* gl = G.app_line[pl];
       if (gl != nullptr)
@@ -847,8 +896,64 @@ __global__ __launch_bounds__(WAVES * 64) void k_shade_scatter(Dev D, MlpDev M, J
           if (v != 0.f) atomicAdd(gl + i, v);
         }
     }
-    if (LLINE) __syncthreads();
+    if (DB) {
+      // the plane's dBasis slice: the waves add their accumulators into `red` one after the other (a fixed order), then the
+      // workgroup's sum goes to its slab.  dB[m][c][r] is row a = 16 m + 4 grp + r, channel 16 c + cl
+      const int grp = lane >> 4, cl = lane & 15;
+#pragma unroll 1
+      for (int w = 0; w < WAVES; ++w) {
+        if (wv == w) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int ch = 16 * c + cl;
+                if (C::CA % 16 != 0 && ch >= C::CA) continue;
+                float* t = red + (16 * m + 4 * grp + r) * C::CA + ch;
+                *t = (w == 0) ? dB[m][c][r] : *t + dB[m][c][r];
+              }
+        }
+        __syncthreads();
+      }
+      float* my = dbslab + ((size_t)blockIdx.x * 3 + pl) * Q::RED_FLOATS;
+      for (int i = threadIdx.x; i < Q::RED_FLOATS; i += WAVES * 64) my[i] = red[i];
+    }
+    __syncthreads();
   }
+}
+
+// dBasis += the slabs k_shade_scatter<..., FLAGS & 2> left: [chunk][workgroup][plane][row a][channel].  The workgroups that ran
+// are recomputed from the shaded count exactly as the scatter did (grid `sgrid`, batches of `ns` samples, `waves` per
+// workgroup); blockIdx.y strides over them, ONE y block = a fixed summation order (JT_DETERMINISTIC).
+template <class C>
+__global__ __launch_bounds__(256) void k_dbasis_reduce(const float* __restrict__ slabs, size_t chunk_stride, int chunk_entries,
+                                                       int sgrid, int ns, int waves, const int* __restrict__ offset, int R,
+                                                       int cap, float* __restrict__ dBasis) {
+  typedef ScatCfg<C> Q;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Q::DB_SLAB) return;
+  const int pl = idx / Q::RED_FLOATS, a = (idx / C::CA) % 32, ch = idx % C::CA;
+  if (a >= C::APP) return;
+  const int total = min(offset[R], cap);
+  const int nchunks = (total + chunk_entries - 1) / chunk_entries;
+  float s0 = 0.f, s1 = 0.f;
+  const int gy = gridDim.y;
+  for (int c = 0; c < nchunks; ++c) {
+    const int n_chunk = min(total - c * chunk_entries, chunk_entries);
+    const int nbatch = (n_chunk + ns - 1) / ns;
+    const int active = min(sgrid, (nbatch + waves - 1) / waves);
+    const float* base = slabs + (size_t)c * chunk_stride + idx;
+    int q = blockIdx.y;
+    for (; q + gy < active; q += 2 * gy) {
+      s0 += base[(size_t)q * Q::DB_SLAB];
+      s1 += base[(size_t)(q + gy) * Q::DB_SLAB];
+    }
+    for (; q < active; q += gy) s0 += base[(size_t)q * Q::DB_SLAB];
+  }
+  const float sum = s0 + s1;
+  if (sum != 0.f) atomicAdd(dBasis + (size_t)a * C::NC + pl * C::CA + ch, sum);
 }
 
 // ---- pose-only backward: the coordinate gradients without walkers ---------------------------------------------------------
@@ -861,7 +966,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_shade_scatter(Dev D, MlpDev M, J
 template <class C>
 __global__ __launch_bounds__(256, 3) void k_pose_gather(Dev D, MlpDev M, const int* __restrict__ offset, int R,
                                                      float* __restrict__ g_xyz, const float* __restrict__ rec, int chunk_start,
-                                                     int chunk_cap, int cap) {
+                                                     int chunk_cap, int cap, int rrows) {
   typedef BwdCfg<C> B;
   __shared__ float smem[32 * C::LDB];
   const int total = min(offset[R], cap);
@@ -887,7 +992,7 @@ __global__ __launch_bounds__(256, 3) void k_pose_gather(Dev D, MlpDev M, const i
     const int nlive = min(32, n_chunk - l0);
     const bool on = j < nlive;
     const int jj = on ? j : nlive - 1;
-    const float* rt = rec + (size_t)tile * B::REC_FLOATS * 32;
+    const float* rt = rec + (size_t)tile * (size_t)rrows * 32;
     f32x16 gf;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1543,9 +1648,12 @@ static std::atomic<int> g_bwd_split{-2};
 // idles ~0.39 ms at the join; with 8 CUs per XCD to themselves they are done when the longer scatter is -- 3.00 against 3.07 ms
 // per step, six alternating repeats (188 / 196 workgroups, which do not divide by the XCDs, lose 2-5 %; the 20-channel scene,
 // whose GEMMs are small, loses 2 % and keeps 256; profiles/round5_scatter_beside_gemms.txt).  JT_SCATTER_WGS (read once) overrides.
-static int scatter_wgs(bool gemms_beside) {
+// Round 6: with dBasis formed in the scatter itself only three GEMMs (1.7 instead of 2.5 GB of record rows) run beside it and the
+// balance moves to 224 workgroups = 28 per XCD = 7 per shader engine: 2.88 against 2.93 (192) and 2.97 ms (256) per step
+// (profiles/round6_lean_tape_ab.txt).
+static int scatter_wgs(bool gemms_beside, bool lean = false) {
   static const int v = [] { const char* e = getenv("JT_SCATTER_WGS"); const int n = e ? atoi(e) : 0; return n > 0 ? std::min(n, 256) : 0; }();
-  return v ? v : (gemms_beside ? 192 : 256);
+  return v ? v : (gemms_beside ? (lean ? 224 : 192) : 256);
 }
 static int bwd_split_mode() {
   int m = g_bwd_split.load(std::memory_order_relaxed);
@@ -1565,6 +1673,37 @@ extern "C" int jt_debug_read_tile_stamps(unsigned long long* out16) {
   return JT_OK;
 }
 #endif
+// "Lean tape" (round 6; JT_LEAN_TAPE, read once, default 1; jt_shade_set_lean_tape): when the backward is the split form with the
+// walker scatter (runs of 8 / 16), dBasis is formed inside k_shade_scatter and the training forward does not record the 3 Ca
+// plane x line products -- a tile's record block shrinks from REC_FLOATS to R_PROD rows.  Whether a render is lean is a function
+// of the library's modes alone (this switch, the split mode, matrix-mode bit 2), so the forward, the backward and the workspace
+// query agree as long as no mode changes between a forward and its backward (as for jt_shade_set_chunk_log2).
+static std::atomic<int> g_lean{-1};
+static int lean_mode() {
+  int m = g_lean.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = getenv("JT_LEAN_TAPE");
+    m = (e ? atoi(e) : 1) ? 1 : 0;
+    g_lean.store(m, std::memory_order_relaxed);
+  }
+  return m;
+}
+template <class C>
+static int split_default() { return (C::CA < 48 || (bf16x3_mode() & 4)) ? 16 : 0; }
+template <class C>
+static bool lean_tape() {
+  if (!lean_mode()) return false;
+  const int m = bwd_split_mode();
+  return m == 8 || m == 16 || (m == -1 && split_default<C>() != 0);
+}
+template <class C>
+static int rec_rows() { return lean_tape<C>() ? BwdCfg<C>::R_PROD : BwdCfg<C>::REC_FLOATS; }
+extern "C" int jt_shade_lean_tape(void) { return lean_mode(); }
+extern "C" int jt_shade_set_lean_tape(int on) {
+  const int prev = lean_mode();
+  if (on == 0 || on == 1) g_lean.store(on, std::memory_order_relaxed);
+  return prev;
+}
 extern "C" int jt_shade_bwd_split(void) { return bwd_split_mode(); }
 extern "C" int jt_shade_set_bwd_split(int run) {
   const int prev = bwd_split_mode();
@@ -1596,13 +1735,14 @@ struct WsLayout {
   typedef WgradDims<C> WD;
   static constexpr int NT3 = WD::NT3, NT1 = WD::NT1, NTB = WD::NTB;
   static constexpr size_t P3 = WD::P3, P2 = WD::P2, P1 = WD::P1, PB = WD::PB;
-  static size_t rec_floats_per_chunk() { return (size_t)B::REC_FLOATS * kChunkEntries; }
+  static size_t rec_floats_per_chunk() { return (size_t)rec_rows<C>() * kChunkEntries; }
   static size_t slab_floats_per_chunk() { return (P3 + P2 + P1 + PB) * kWgradBlocks; }
   // records of all chunks are one contiguous tile-blocked array (a chunk is a whole number of 32-sample tiles), so
   // they take what `cap` samples need, not whole chunks; the slabs follow
-  static size_t rec_floats(int cap) { return (size_t)B::REC_FLOATS * (((size_t)std::max(cap, 1) + 31) / 32 * 32); }
+  static size_t rec_floats(int cap) { return (size_t)rec_rows<C>() * (((size_t)std::max(cap, 1) + 31) / 32 * 32); }
+  // (the tile-owned scatter's lists exist only while that variant is selected: up to 0.7 GB nobody else reads)
   static size_t bytes(int cap) {
-    return main_bytes(cap) + tile_ws_bytes(cap, kChunkEntries);
+    return main_bytes(cap) + (bwd_split_mode() == 1 ? tile_ws_bytes(cap, kChunkEntries) : 0);
   }
   // records + slabs; the tile-owned scatter's lists and counters (jt_tile.h) sit behind them
   static size_t main_bytes(int cap) {
@@ -1625,9 +1765,9 @@ extern "C" int jt_shade_record_layout(const JtScene* scene, int32_t* out) {
   const int kind = shade_kind(scene);
   if (kind < 0 || !out) return JT_ERR_UNSUPPORTED;
   if (kind == 0) {
-    out[0] = BwdCfg<CfgBlender>::REC_FLOATS; out[1] = BwdCfg<CfgBlender>::R_MASK; out[2] = CfgBlender::HID;
+    out[0] = rec_rows<CfgBlender>(); out[1] = BwdCfg<CfgBlender>::R_MASK; out[2] = CfgBlender::HID;
   } else {
-    out[0] = BwdCfg<CfgLlff>::REC_FLOATS; out[1] = BwdCfg<CfgLlff>::R_MASK; out[2] = CfgLlff::HID;
+    out[0] = rec_rows<CfgLlff>(); out[1] = BwdCfg<CfgLlff>::R_MASK; out[2] = CfgLlff::HID;
   }
   out[3] = 32;
   return JT_OK;
@@ -1647,7 +1787,7 @@ static int launch_shade_fwd_t(const Dev& D, const MlpDev& M, const PeMask& pm, c
     constexpr int NW = JT_B16_THREADS / 64;
     int blocks16 = (int)std::min<long>((tiles + NW - 1) / NW, 256);
     hipLaunchKernelGGL((k_shade_fwd_b16<C, REC>), dim3(blocks16), dim3(JT_B16_THREADS), lds16, st, D, M, pm, rays_o, rays_d, jitter,
-                       zvals, tmin, offset, R, eray, esmp, vdir, rgb_s, rec, cap);
+                       zvals, tmin, offset, R, eray, esmp, vdir, rgb_s, rec, cap, rec_rows<C>());
     JT_LAUNCH_CHECK();
     return JT_OK;
   }
@@ -1656,7 +1796,7 @@ static int launch_shade_fwd_t(const Dev& D, const MlpDev& M, const PeMask& pm, c
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   int blocks = (int)std::min<long>((tiles + 3) / 4, 512);
   hipLaunchKernelGGL((k_shade_fwd<C, REC>), dim3(blocks), dim3(256), lds, st, D, M, pm, rays_o, rays_d, jitter, zvals,
-                     tmin, offset, R, eray, esmp, vdir, rgb_s, rec, cap);
+                     tmin, offset, R, eray, esmp, vdir, rgb_s, rec, cap, rec_rows<C>());
   JT_LAUNCH_CHECK();
   return JT_OK;
 }
@@ -1673,6 +1813,9 @@ static int launch_shade_fwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     if (ws_bytes < WsLayout<C>::bytes(cap)) return JT_ERR_ARG;
     if (flags & JT_SHADE_POSE_ONLY)
       return launch_shade_fwd_t<C, 2>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, offset, R, eray, esmp, vdir,
+                                      rgb_s, ws, cap, st);
+    if (lean_tape<C>())
+      return launch_shade_fwd_t<C, 3>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, offset, R, eray, esmp, vdir,
                                       rgb_s, ws, cap, st);
     return launch_shade_fwd_t<C, 1>(D, M, pm, rays_o, rays_d, jitter, zvals, tmin, offset, R, eray, esmp, vdir,
                                     rgb_s, ws, cap, st);
@@ -1800,12 +1943,12 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   const bool use_aux = aux && ev_fork && ev_join && !(ablate & 4);
   static const bool pipe = [] { const char* e = getenv("JT_WGRAD_PIPE"); return !e || atoi(e) != 0; }();
   hipStream_t ws_st = use_aux ? aux : st;
-  const int RR = B::REC_FLOATS;
+  const int RR = rec_rows<C>();   // rows of a tile's record block (lean tape: without the product rows)
   // per scene kind (-1): split 16 whenever the chain runs on the bf16 matrix cores (matrix-mode bit 2) -- the 20-channel scene
   // always did; VM-48 since round 5: chain 281 us + scatter 994 against 1 365 fused (with the fp32 chain, 508 + 994, the fused
   // kernel wins and stays)
-  const int split_default = (C::CA < 48 || (bf16x3_mode() & 4)) ? 16 : 0;
-  int split = bwd_split_mode() >= 0 ? bwd_split_mode() : split_default;
+  const int split_dflt = split_default<C>();
+  int split = bwd_split_mode() >= 0 ? bwd_split_mode() : split_dflt;
   unsigned* bad = jt::fixed_bad_flag();
   if (!bad) return JT_ERR_ARG;
   // tile-owned scatter (split == 1): needs factor gradients to write, float accumulation, a scene whose tiles and LDS line fit
@@ -1819,7 +1962,7 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     if (TS::lds_bytes(tile_cfg, tile_line_len) > 160 * 1024) tile_cfg ^= 1;  // the other workgroup shape may still fit
     bool ok = !det && G.app_plane[0] && G.app_line[0] && TS::lds_bytes(tile_cfg, tile_line_len) <= 160 * 1024;
     for (int a = 0; a < 3 && ok; ++a) ok = TS::tiles(D.ph[a], D.pw[a]) <= kTileMaxTiles;
-    if (!ok) split = split_default;
+    if (!ok) split = split_dflt;
   }
   const bool tile = (split == 1);
   const TileWs TW = tile_ws_carve(reinterpret_cast<char*>(ws) + W::main_bytes(cap), cap, chunk);
@@ -1830,6 +1973,10 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   static const bool pose_env = [] { const char* e = getenv("JT_POSE_BWD"); return !e || atoi(e) != 0; }();
   const bool pose_only = pose_env && !det && !G.app_plane[0] && !G.app_line[0] && (flags & kNoGradRecords) && (ablate & 4);
   if (pose_only) split = 16;  // the chain alone (k_shade_bwd<SPLIT>: GF rows out), then k_pose_gather in the scatter's place
+  // lean tape: the forward recorded no products, dBasis comes out of the walker scatter (k_shade_scatter FLAGS bit 1)
+  const bool lean = lean_tape<C>();
+  if (lean && (split != 8 && split != 16)) return JT_ERR_ARG;  // (a mode was changed between the forward and this backward)
+  const bool dbs = lean && !pose_only && !(ablate & 4) && GM.basis != nullptr;
   auto launch_bwd = [&](int ci) -> int {
     const int start = ci * chunk, ccap = std::min(chunk, cap - start);
     long tiles = ((long)ccap + 31) / 32;
@@ -1845,7 +1992,7 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
         attr_b = true;
       }
       hipLaunchKernelGGL((k_shade_bwd<C, false, true, true>), dim3(blocks), dim3(512), lds_b, st, D, M, pm, G, offset, R, rgb_s,
-                         g_rgb_s, g_xyz, rc, start, ccap, cap, ablate, bad);
+                         g_rgb_s, g_xyz, rc, start, ccap, cap, ablate, bad, RR);
     } else if (split) {
       const size_t lds_c = B::LDS_FLOATS_SPLIT * sizeof(float);
       static bool attr_done = false;
@@ -1855,13 +2002,13 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
         attr_done = true;
       }
       hipLaunchKernelGGL((k_shade_bwd<C, false, true>), dim3(blocks), dim3(512), lds_c, st, D, M, pm, G, offset, R, rgb_s,
-                         g_rgb_s, g_xyz, rc, start, ccap, cap, ablate, bad);
+                         g_rgb_s, g_xyz, rc, start, ccap, cap, ablate, bad, RR);
     } else if (det) {
       hipLaunchKernelGGL((k_shade_bwd<C, true>), dim3(blocks), dim3(512), lds, st, D, M, pm, G, offset, R, rgb_s,
-                         g_rgb_s, g_xyz, rc, start, ccap, cap, ablate, bad);
+                         g_rgb_s, g_xyz, rc, start, ccap, cap, ablate, bad, RR);
     } else {
       hipLaunchKernelGGL((k_shade_bwd<C, false>), dim3(blocks), dim3(512), lds, st, D, M, pm, G, offset, R, rgb_s,
-                         g_rgb_s, g_xyz, rc, start, ccap, cap, ablate, bad);
+                         g_rgb_s, g_xyz, rc, start, ccap, cap, ablate, bad, RR);
     }
     JT_LAUNCH_CHECK();
     return JT_OK;
@@ -1876,11 +2023,13 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   int sflags = split ? sflags_env : 0;
   if (det) sflags &= ~1;
   auto scatter_lds = [&](int run, int fl, int sw) {
-    return (size_t)(ScatCfg<C>::BT_FLOATS + ((fl & 1) ? line_floats : 0) + sw * ScatCfg<C>::wave_floats(run)) * sizeof(float);
+    return (size_t)(ScatCfg<C>::BT_FLOATS + ((fl & 1) ? line_floats : 0) + (dbs ? ScatCfg<C>::RED_FLOATS : 0) +
+                    sw * ScatCfg<C>::wave_floats(run, dbs)) * sizeof(float);
   };
   static const int sw_env = [] { const char* e = getenv("JT_SCATTER_WAVES"); return e ? atoi(e) : 0; }();
   int sw = 8;
-  if (C::CA < 48 && split && !tile && (sw_env == 16 || (sw_env == 0 && scatter_lds(split, sflags, 16) <= 160 * 1024))) sw = 16;
+  // (with dBasis formed in the scatter the sixteen-wave shape's 128 registers spill 44-96 bytes per lane: eight waves then)
+  if (C::CA < 48 && split && !tile && (sw_env == 16 || (sw_env == 0 && !dbs && scatter_lds(split, sflags, 16) <= 160 * 1024))) sw = 16;
   if (split && !tile && scatter_lds(split, sflags, sw) > 160 * 1024) sflags &= ~1;  // a line too long for the LDS: global atomics as before
   auto launch_scatter = [&](int ci) -> int {
     if (!split || (ablate & 1)) return JT_OK;
@@ -1889,7 +2038,7 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     if (pose_only) {
       const long tiles = ((long)ccap + 31) / 32;
       const int pblocks = (int)std::min<long>((tiles + 3) / 4, 2048L);
-      hipLaunchKernelGGL((k_pose_gather<C>), dim3(pblocks), dim3(256), 0, st, D, M, offset, R, g_xyz, rc, start, ccap, cap);
+      hipLaunchKernelGGL((k_pose_gather<C>), dim3(pblocks), dim3(256), 0, st, D, M, offset, R, g_xyz, rc, start, ccap, cap, RR);
       JT_LAUNCH_CHECK();
       return JT_OK;
     }
@@ -1910,14 +2059,18 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
       attr = true;                                                                                                      \
     }                                                                                                                   \
     const long nbatch = ((long)ccap + 4 * RUN_ - 1) / (4 * RUN_);                                                       \
-    const int sblocks = (int)std::min<long>((nbatch + SW_ - 1) / SW_, (long)scatter_wgs(use_aux && C::CA >= 48));                             \
+    const int sblocks = (int)std::min<long>((nbatch + SW_ - 1) / SW_, (long)scatter_wgs(use_aux && C::CA >= 48, dbs));                             \
     hipLaunchKernelGGL((k_shade_scatter<C, DET_, RUN_, SW_, FL_>), dim3(sblocks), dim3(SW_ * 64), lds_s, st, D, M, G,   \
-                       offset, R, g_xyz, rc, start, ccap, cap, bad, line_floats);                                       \
+                       offset, R, g_xyz, rc, start, ccap, cap, bad, line_floats, RR,                                    \
+                       slabs + (size_t)ci * cstride + (W::P3 + W::P2 + W::P1) * nb);                                    \
   }
 #define JT_SCATTER_FL(RUN_, SW_)                                                                \
   {                                                                                             \
-    if (det) JT_SCATTER_LAUNCH(RUN_, true, 0, SW_)                                              \
+    if (det && dbs) JT_SCATTER_LAUNCH(RUN_, true, 2, SW_)                                       \
+    else if (det) JT_SCATTER_LAUNCH(RUN_, true, 0, SW_)                                         \
+    else if (sflags == 1 && dbs) JT_SCATTER_LAUNCH(RUN_, false, 3, SW_)                         \
     else if (sflags == 1) JT_SCATTER_LAUNCH(RUN_, false, 1, SW_)                                \
+    else if (dbs) JT_SCATTER_LAUNCH(RUN_, false, 2, SW_)                                        \
     else JT_SCATTER_LAUNCH(RUN_, false, 0, SW_)                                                 \
   }
 #define JT_SCATTER_RUN(RUN_)                                                                    \
@@ -1950,9 +2103,11 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   hipLaunchKernelGGL((KERNEL<C::MT, NT1, XF1>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_G1, C::HID, B::R_F, C::IN1,     \
                      B::R_F, B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s1);                                  \
   JT_LAUNCH_CHECK();                                                                                                     \
+  if (!dbs) {                                                                                                            \
   hipLaunchKernelGGL((KERNEL<1, NTB, 0>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_GF, C::APP, B::R_PROD, C::NC, B::R_F, \
                      B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, sb);                                          \
-  JT_LAUNCH_CHECK();
+  JT_LAUNCH_CHECK();                                                                                                     \
+  }
     if (bf16x3_mode() & 2) {
       JT_WGRAD_LAUNCH(k_wgrad_b16)
     } else {
@@ -1974,6 +2129,14 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     }
     if (!scatter_first && (rc = launch_scatter(ci))) return rc;
   }
+  if (dbs && !(ablate & 1)) {
+    // dBasis: the sum of the scatter workgroups' slabs, on the launch stream behind the last scatter
+    const int ry = det ? 1 : 8;
+    hipLaunchKernelGGL((k_dbasis_reduce<C>), dim3((ScatCfg<C>::DB_SLAB + 255) / 256, ry), dim3(256), 0, st,
+                       slabs + (W::P3 + W::P2 + W::P1) * nb, cstride, chunk, scatter_wgs(use_aux && C::CA >= 48, dbs), 4 * split,
+                       sw, offset, R, cap, GM.basis);
+    JT_LAUNCH_CHECK();
+  }
   if (ablate & 4) return JT_OK;
   if (use_aux && !pipe) {
     if (hipEventRecord(ev_fork, st) != hipSuccess) return JT_ERR_ARG;
@@ -1990,7 +2153,8 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   }
   {
     const int ry = det ? 1 : 32;  // slab groups that add into dW atomically; ONE group = a fixed summation order
-    const int nblk = (int)((W::P3 + 255) / 256 + (W::P2 + 255) / 256 + (W::P1 + 255) / 256 + (W::PB + 255) / 256);
+    // (dBasis out of the scatter: the last range of the reduce kernel's grid, the dBasis GEMM's slabs, is left off)
+    const int nblk = (int)((W::P3 + 255) / 256 + (W::P2 + 255) / 256 + (W::P1 + 255) / 256 + (dbs ? 0 : (W::PB + 255) / 256));
     const MlpGrad gm = {GM.basis, GM.w1, GM.b1, GM.w2, GM.b2, GM.w3, GM.b3};
     hipLaunchKernelGGL((k_wgrad_reduce4<C>), dim3(nblk, ry), dim3(256), 0, ws_st, slabs, nb, cstride, chunk, offset, R, cap,
                        gm);

@@ -264,8 +264,11 @@ struct RecWalker {
   // accumulate one sample.  g[k] = dL/d(plane_c * line_c) for the lane's channels (zero for padding lanes).
   // Returns the lane's UN-reduced partials of dL/d(ix, iy, il) (grid_sampler backward w.r.t. the coordinates:
   // out-of-range taps count as zeros).
+  // PROD: also hands back the lane's plane x line products of the sample, prod[k] = pv * lv (what the forward fed basis_mat:
+  // k_shade_scatter forms dBasis from them, so the forward does not have to record them)
+  template <bool PROD = false>
   __device__ inline void add(TapBuf<NCH>& tv, const float* rec, const float g[NCH], float& aix, float& aiy,
-                             float& ail) {
+                             float& ail, float* prod = nullptr) {
 #if JT_ABL_WALK_PAD  // profiling knob: N extra vector instructions per step -- is a walker bound by instruction issue?
     {
       float pad = aix;
@@ -296,6 +299,7 @@ struct RecWalker {
     for (int k = 0; k < NCH; ++k) {
       const float pv = w.x * tv.a[k] + w.y * tv.b[k] + w.z * tv.c[k] + w.w * tv.d[k];
       const float lv = x.x * tv.u[k] + x.y * tv.v[k];
+      if (PROD) prod[k] = pv * lv;
       const float gpv = g[k] * lv, glv = g[k] * pv;
       // (unconditionally: without factor gradients -- gP == nullptr, pose-only backward -- the slots are never flushed, and
       //  a test here comes back as one select per accumulator and step, 18 of the ~80 arithmetic instructions of a step)

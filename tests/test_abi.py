@@ -29,7 +29,33 @@ def test_header_vs_ctypes_vs_library():
     for name in funcs:
         assert hasattr(so, name), name
     # the library and the header agree on the ABI revision (a mismatch is an ImportError in _lib._load as well)
-    assert so.jt_version() == _lib.header_version() >= 1100
+    assert so.jt_version() == _lib.header_version() == _lib.JT_ABI_VERSION >= 1200
+
+
+def abi_fingerprint(name="jt_render.h"):
+    """sha256 over what a caller compiles against: the header with comments and white space removed (prototypes, struct
+    members in order, constants).  Comment edits do not move it; anything a caller could observe does."""
+    import hashlib
+    src = open(os.path.join(ROOT, "include", name)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"#define\s+JT_VERSION\s+\d+", "", src)
+    return hashlib.sha256(re.sub(r"\s+", "", src).encode()).hexdigest()
+
+
+def test_abi_hash_moves_only_with_the_version():
+    """include/jt_render.abi = "<JT_VERSION> <fingerprint>" as of the last deliberate ABI change.  A prototype, struct or
+    constant edited without a JT_VERSION bump fails here (three such commits the day the number was
+    introduced); after a bump, `python tests/test_abi.py --update` rewrites the file."""
+    from joint_tensorf_amd import _lib
+    ver, fp = open(os.path.join(ROOT, "include", "jt_render.abi")).read().split()
+    cur = abi_fingerprint()
+    if cur != fp:
+        assert _lib.header_version() != int(ver), (
+            "include/jt_render.h changed what a caller sees but JT_VERSION is still %s: bump it (and _lib.JT_ABI_VERSION), "
+            "then run `python tests/test_abi.py --update`" % ver)
+        raise AssertionError("JT_VERSION was bumped to %d: run `python tests/test_abi.py --update` to record the new "
+                             "fingerprint" % _lib.header_version())
+    assert int(ver) == _lib.header_version()
 
 
 def test_optional_fused_module():
@@ -96,3 +122,12 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert _lib.lib.jt_render_loss_backward_ind(None, None, None, 0, 1, 1, 1, 1.0, 1.0, None, None, None, None) == 1
     assert _lib.lib.jt_loss_sum_forward_dyn(None, None, None, None, None) == 1
     assert _lib.lib.jt_finite_check(None, 0, None, None) == 1
+
+
+if __name__ == "__main__":
+    import sys
+    if "--update" in sys.argv:
+        sys.path.insert(0, ROOT)
+        from joint_tensorf_amd import _lib
+        open(os.path.join(ROOT, "include", "jt_render.abi"), "w").write("%d %s\n" % (_lib.header_version(), abi_fingerprint()))
+        print(open(os.path.join(ROOT, "include", "jt_render.abi")).read())

@@ -149,7 +149,7 @@ def test_blender_middle_stages_blurred(stage, grid, S):
     _train_case("blender_stage%d_blurred_%dcube" % (stage, grid), opt, model, var, it0, blur_scale=0.6)
 
 
-@pytest.mark.parametrize("variant", ["mfma", "mfma-fp32", "mfma-split16", "mfma-tile"])
+@pytest.mark.parametrize("variant", ["mfma", "mfma-fp32", "mfma-split16", "mfma-tile", "mfma-fulltape"])
 def test_blender_stage4_sharp_400cube(variant):
     """(i) the bench workload: 400^3, S = 1000, ~2 000 rays, blur off; semi-transparent field (density planes x 25:
     every in-box sample is shaded and the transmittance decays over the whole ray).  Under the default kernels, the
@@ -185,7 +185,7 @@ def test_llff_stage0_20480rays():
     _train_case("llff_stage0_20480rays", opt, model, var, it0, offsets=(2, 3), blur_scale=0.8)
 
 
-@pytest.mark.parametrize("variant", ["mfma", "mfma-fp32", "mfma-split16", "mfma-tile"])
+@pytest.mark.parametrize("variant", ["mfma", "mfma-fp32", "mfma-split16", "mfma-tile", "mfma-fulltape"])
 def test_llff_final_grid(variant):
     """(iii) the final LLFF grid 771 x 859 x 771 (planes of 2.7 M texels x 20 / 16 channels), 4 096 nominal rays; under the
     default kernels, the fp32-matrix-core kernels and the split backward."""

@@ -106,26 +106,32 @@ def replay_hip(fx, shade_impl, pin_rays=True, device="cuda"):
 # and the split backward (chain kernel + scatter kernel with runs of 16 / 8 samples, jt_shade_set_bwd_split)
 # (matrix mode, backward split; -1 = the library's per-scene default: fused for VM-48, split 16 for the 20-channel scene)
 # (matrix-mode bit 2, round 5: the chain of a SPLIT backward on the bf16 matrix cores -- 7 = the library's default)
-VARIANTS = {"mfma": (7, -1), "torch": (7, -1), "mfma-fp32": (0, 0), "mfma-split16": (7, 16), "mfma-split8-fp32": (0, 8),
-            "mfma-tile": (7, 1), "mfma-split16-fp32chain": (3, 16)}
+# (third entry, round 6: the lean tape -- no product records, dBasis out of the scatter kernel; it only takes effect where the
+#  backward is the split form with the walker scatter.  "mfma-fulltape" is round 5's default: product records + dBasis GEMM)
+VARIANTS = {"mfma": (7, -1, 1), "torch": (7, -1, 1), "mfma-fp32": (0, 0, 1), "mfma-split16": (7, 16, 1),
+            "mfma-split8-fp32": (0, 8, 1), "mfma-tile": (7, 1, 1), "mfma-split16-fp32chain": (3, 16, 1),
+            "mfma-fulltape": (7, -1, 0)}
 
 
 class kernel_variant:
     """with kernel_variant(name): the library's matrix mode / backward split for the launches inside, restored on exit"""
 
     def __init__(self, name):
-        self.mode, self.split = VARIANTS[name]
+        self.mode, self.split, self.lean = VARIANTS[name]
 
     def __enter__(self):
         from joint_tensorf_amd._lib import lib
-        self.prev = (lib.jt_shade_set_matrix_mode(self.mode), lib.jt_shade_set_bwd_split(self.split))
+        self.prev = (lib.jt_shade_set_matrix_mode(self.mode), lib.jt_shade_set_bwd_split(self.split),
+                     lib.jt_shade_set_lean_tape(self.lean))
         assert lib.jt_shade_matrix_mode() == self.mode and lib.jt_shade_bwd_split() == self.split
+        assert lib.jt_shade_lean_tape() == self.lean
         return self
 
     def __exit__(self, *exc):
         from joint_tensorf_amd._lib import lib
         lib.jt_shade_set_matrix_mode(self.prev[0])
         lib.jt_shade_set_bwd_split(self.prev[1])
+        lib.jt_shade_set_lean_tape(self.prev[2])
         return False
 
 
