@@ -470,7 +470,7 @@ def pmc_traffic_instep(roof, hidden=None, live=None):
     record of live_pmc_traffic() -- collected in this very run; otherwise the committed passes (tools/profile_cmd.sh ->
     tools/pmc_traffic_instep.py) are quoted and the source says so; null when neither exists."""
     tag = "round4" if os.path.exists(os.path.join(ROOT, "profiles", "round4_default_pmc_traffic.json")) else "round3"
-    for t in ("round5",):
+    for t in ("round5", "round6"):
         if os.path.exists(os.path.join(ROOT, "profiles", t + "_default_pmc_traffic.json")):
             tag = t
     path = os.path.join(ROOT, "profiles", tag + "_default_pmc_traffic.json")
@@ -513,6 +513,30 @@ def pmc_traffic_instep(roof, hidden=None, live=None):
         return out
     except Exception:
         return {"traffic": None}
+
+
+def gpu_clocks():
+    """sclk / mclk / power of GPU 0 as rocm-smi reports them right after the timed loop (the driver's box
+    and the builder's boxes differ by 4-8 % on the same code; the line should say what the chip was doing).  A dict of the
+    fields found, or an error string: never fatal."""
+    import shutil
+    import subprocess
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return {"error": "rocm-smi not found"}
+    try:
+        r = subprocess.run([smi, "-d", "0", "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--showtemp",
+                            "--json"], capture_output=True, text=True, timeout=30)
+        j = json.loads(r.stdout[r.stdout.index("{"):])
+        card = j.get("card0", next(iter(j.values())))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(w in kl for w in ("sclk", "mclk", "fclk", "socclk", "power", "performance level", "junction", "edge")):
+                keep[k] = v
+        return keep or {"raw": card}
+    except Exception as ex:
+        return {"error": repr(ex)[:200]}
 
 
 def torch_gpu_baseline(opt, model, var_all, steps=3):
@@ -569,12 +593,16 @@ def torch_gpu_baseline(opt, model, var_all, steps=3):
                                                      "samples per ray / views / lattice, fwd+loss+bwd+Adam, blur off")
 
 
-def run_extras():
+def run_extras(steps=20, warmup=5):
     """Secondary workloads, each a short child process of this script (its own model, 10 timed steps): numbers DESIGN.md
-    quotes, driver-visible here."""
+    quotes, driver-visible here.  The `default_*` children are the HEADLINE workload under another kernel selection: they run
+    with the parent's own --steps / --warmup, i.e. on the same host draws -- the same lattice offsets, the same ray and
+    shaded-sample counts per iteration -- so that a variant, the default as a child (`default_headline_child`) and the parent's
+    own timed loop can be compared to the per cent (the children used to run 10 steps on another lattice)."""
     import subprocess
     base = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-probe",
             "--no-torch-baseline", "--no-extras"]
+    same = ["--steps", str(steps), "--warmup", str(warmup)]   # argparse: the later occurrence wins
     cases = [("stage0_blurred", ["--stage", "0"], {}),
              ("stage0_blurred_hipgraph", ["--stage", "0"], {"JT_GRAPH": "1"}),
              ("stage2_blurred_hipgraph", ["--stage", "2"], {"JT_GRAPH": "1"}),
@@ -592,14 +620,18 @@ def run_extras():
              # the headline workload with the appearance gradients through the TILE-OWNED scatter of round 5 (chain kernel +
              # binning + one wave per 4 x 4-texel tile on the matrix cores) instead of the fused kernel's run-length atomics:
              # a selectable variant that does not win at this workload; k_shade_bwd_ms = chain + scatter
-             ("default_tile_owned_scatter", [], {"JT_BWD_SPLIT": "1", "JT_TILE_CFG": "1"}),
+             # the headline itself, as a child process: parent-vs-child is then separable from variant-vs-variant
+             ("default_headline_child", same, {}),
+             # round 5's default: the full tape (product rows recorded, dBasis by a fourth GEMM), scatter on 192 CUs
+             ("default_round5_full_tape", same, {"JT_LEAN_TAPE": "0"}),
+             ("default_tile_owned_scatter", same, {"JT_BWD_SPLIT": "1", "JT_TILE_CFG": "1"}),
              # ... and through the ONE-kernel backward of rounds 2-4 (fp32 chain + scatter fused, weight gradients on the launch
              # stream): what the default's chain-on-bf16 + scatter + forked weight-gradient GEMMs replaced in round 5
-             ("default_fused_backward_kernel", [], {"JT_BWD_SPLIT": "0", "JT_NO_AUX": "1"}),
+             ("default_fused_backward_kernel", same, {"JT_BWD_SPLIT": "0", "JT_NO_AUX": "1"}),
              # ... and the default's kernels with the WHOLE chip each: the scatter on 256 CUs, the weight-gradient GEMMs behind it
              # on the launch stream, the optimizer as one launch -- k_shade_bwd_ms here is chain + scatter ALONE on the chip
              # (the default's launch shares it with the GEMMs: roofline.shares_the_chip), the step is what sharing buys
-             ("default_every_kernel_alone", [], {"JT_SCATTER_WGS": "256", "JT_NO_AUX": "1", "JT_ADAM_EARLY": "0"})]
+             ("default_every_kernel_alone", same, {"JT_SCATTER_WGS": "256", "JT_NO_AUX": "1", "JT_ADAM_EARLY": "0"})]
     out = {}
     for name, flags, env in cases:
         try:
@@ -609,7 +641,8 @@ def run_extras():
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
             j = json.loads(line)
             out[name] = {"rays_per_s": j["value"], "ms_per_step": j["ms_per_step"], "workload": j["config"]["workload"],
-                         "launch": j["config"]["launch"]}
+                         "launch": j["config"]["launch"], "steps": j["steps"],
+                         "rays_per_iter": j["config"]["rays_per_iter_per_gpu"]}
             for k in ("shaded_samples_per_iter", "nominal_samples_per_iter", "shaded_over_nominal"):
                 if k in j["config"]:
                     out[name][k] = j["config"][k]
@@ -843,6 +876,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     rays_timed = rays_total
+    clocks = gpu_clocks() if rank == 0 else None   # right behind the timed loop: the chip is still in its working state
     all_timers, jops_t.STEP_TIMERS = jops_t.STEP_TIMERS, None
     timers = all_timers[n_untimed:] if all_timers is not None else None
     # JT_BENCH_CHECKSUM=1 (validation of the N > 1 sharding paths against each other): the parameters as the TIMED steps left
@@ -961,6 +995,7 @@ def main():
                                  if world > 1 else "1 GPU")),
             },
         }
+        out["gpu_clocks_after_timed_loop"] = clocks
         if world > 1 or FORCE_DIST:
             import torch.distributed as dist
             out["ranks"] = {"world_size": dist.get_world_size(), "backend": backend,
@@ -1046,7 +1081,7 @@ def main():
             del model
             jops_t._WS.clear()
             torch.cuda.empty_cache()
-            out["extra"] = run_extras()
+            out["extra"] = run_extras(args.steps, args.warmup)
         # the CPU baseline LAST: its sweep ends on every logical CPU of the host, and the intra-op pool it leaves behind kept
         # the host-bound eager child workloads above 10-15 % slower when it ran in front of them
         if world == 1 and not strong and not args.no_cpu_baseline:

@@ -36,8 +36,10 @@ extern "C" {
  * JT_ABI_VERSION).  include/jt_render.abi holds a hash of every prototype, struct and constant of this header next to the
  * version it was taken at: tests/test_abi.py fails when the hash changes without this number changing (round 5 added
  * jt_reg_losses_fused, removed jt_pose_fused* and redefined matrix-mode bit 2 at version 1100; 1200 = round 6: those changes,
- * jt_shade_lean_tape / jt_shade_set_lean_tape, the workspace no longer carries the tile lists unless that variant is selected). */
-#define JT_VERSION 1200
+ * jt_shade_lean_tape / jt_shade_set_lean_tape, the workspace no longer carries the tile lists unless that variant is selected;
+ * 1201: + jt_chip_geometry; 1202: + jt_shade_workspace_layout.  Additions bump the last two digits, anything a caller built against the old header would get wrong
+ * bumps the hundreds). */
+#define JT_VERSION 1202
 
 #define JT_OK 0
 #define JT_ERR_ARG 1         /* null pointer / bad size */
@@ -116,6 +118,11 @@ typedef struct JtMlp {
 } JtMlp;
 
 int jt_version(void);
+/* {compute units, XCDs} of the current device as the library sees them (hipDeviceGetAttribute, once per device).  The
+ * persistent kernels -- shade forward / backward chain / scatter, the density walk -- run one workgroup per CU or a fixed
+ * fraction of the CUs: their grids are derived from these two numbers (256 and 8 on a full MI355X; 32 and 1 on a CPX
+ * partition), not from constants. */
+int jt_chip_geometry(int32_t* out2);
 
 /* ---------------------------------------------------------------------------------------------
  * Ray generation for the SAMPLED pixels only.
@@ -256,6 +263,13 @@ size_t jt_march_backward_workspace_bytes(const JtScene* scene, int n_rays);
  * aux_stream): recorded on `stream` behind the per-sample backward kernels, in front of the weight-gradient GEMMs
  * (a timing mark). */
 size_t jt_shade_workspace_bytes(const JtScene* scene, int n_entries_max);
+/* Where the pieces of that workspace sit under the library's current modes (chunk size, split mode, lean tape): byte offsets
+ * from the workspace base and byte sizes, out23[0] = the total jt_shade_workspace_bytes reports, [1] the record array (offset
+ * 0), [2] / [3] / [4] offset of the per-chunk weight-gradient slabs, bytes per chunk, chunks, [5] rows of a tile's record block,
+ * [6] / [7] offset inside a chunk's slabs and maximal size of what the scatter's workgroups write when dBasis is formed there,
+ * [8] whether the tile-owned scatter's lists are part of the workspace and, if so, (offset, bytes) of its seven pieces in
+ * [9..22].  A diagnostic for tests (every piece must lie inside the total for any capacity); JT_ERR_ARG for n_entries_max < 1. */
+int jt_shade_workspace_layout(const JtScene* scene, int n_entries_max, int64_t* out23);
 /* Shaded samples per backward launch ("chunk": batBase.py has no counterpart, it is how the build bounds the
  * per-launch record block).  jt_shade_chunk_entries() = the current value (2^22 unless JT_SHADE_CHUNK_LOG2 says
  * otherwise); jt_shade_set_chunk_log2(l) sets 2^l for l in 16..22 and returns the previous log2 (any other l only

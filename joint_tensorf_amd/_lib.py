@@ -77,6 +77,7 @@ FP = ctypes.POINTER(JtFactors)
 MP = ctypes.POINTER(JtMlp)
 SIGNATURES = {
     "jt_version": (ctypes.c_int, []),
+    "jt_chip_geometry": (I, [P]),
     "jt_raygen_forward": (I, [P, P, P, P, I, I, I, I, F, P, P, P]),
     "jt_raygen_backward": (I, [P, P, P, P, I, I, I, I, F, P, P, P, P]),
     "jt_raygen_forward_ragged": (I, [P, P, P, P, P, I, I, I, I, F, P, P, P]),
@@ -95,6 +96,7 @@ SIGNATURES = {
     "jt_march_backward_workspace_bytes": (ctypes.c_size_t, [SP, I]),
     "jt_shade_workspace_bytes": (ctypes.c_size_t, [SP, I]),
     "jt_shade_record_layout": (I, [SP, P]),
+    "jt_shade_workspace_layout": (I, [SP, I, P]),
     "jt_finite_check": (I, [P, I, P, P]),
     "jt_set_deterministic": (I, [I]),
     "jt_status_bind": (I, [P]),
@@ -167,7 +169,7 @@ def fused_lib():
 # the JT_VERSION of include/jt_render.h that SIGNATURES and the struct mirrors above were written against.  A constant, not a
 # read of the header at import time: a vendored copy of the package has no include/ directory beside it (tests/test_abi.py
 # holds this number, the header's and the library's together)
-JT_ABI_VERSION = 1200
+JT_ABI_VERSION = 1202
 
 
 def header_version():

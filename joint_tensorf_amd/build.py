@@ -84,6 +84,45 @@ def build(force=False, verbose=True):
     return LIB
 
 
+SAN_LIB = os.path.join(ROOT, "tests", "lib", "libjt_render_asan.so")
+
+
+def asan_runtime():
+    """the shared AddressSanitizer runtime of the toolchain that builds the library (preloaded into the python that loads SAN_LIB)"""
+    clang = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc()))), "lib", "llvm", "bin", "clang")
+    if not os.path.exists(clang):
+        clang = "/opt/rocm/lib/llvm/bin/clang"
+    return subprocess.check_output([clang, "-print-file-name=libclang_rt.asan-x86_64.so"]).decode().strip()
+
+
+def build_sanitized(force=False, verbose=False):
+    """The HOST side of libjt_render.so under AddressSanitizer + UndefinedBehaviorSanitizer (test infrastructure:
+    tests/test_sanitizers.py; never shipped, never run on a GPU box -- GPU-side sanitizers are not available on this pool).
+    Device code is compiled as usual but unoptimised (-Xarch_device -O1): it only has to link."""
+    if not force and os.path.exists(SAN_LIB) and all(os.path.getmtime(SAN_LIB) > os.path.getmtime(p)
+                                                      for p in SRCS + HDRS + [os.path.abspath(__file__)]):
+        return SAN_LIB
+    import concurrent.futures
+    out_dir = os.path.join(ROOT, "tests", "lib", "asan_obj")
+    os.makedirs(out_dir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fsanitize=address,undefined",
+             "-fno-sanitize-recover=undefined", "-fno-gpu-sanitize", "-Xarch_device", "-O1", "-Xarch_device", "-g0",
+             "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc")]
+
+    def one(src):
+        obj = os.path.join(out_dir, os.path.basename(src) + ".o")
+        cmd = [hipcc()] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+    with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(one, SRCS))
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address,undefined", "-shared-libsan",
+                           "-o", SAN_LIB] + objs)
+    return SAN_LIB
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)

@@ -87,6 +87,20 @@ constexpr long long kFixedLimit = 1ll << 60;
 // device address of the sticky flag (one word per process, owned by jt_march.hip; cleared by jt_status_clear)
 unsigned* fixed_bad_flag();
 
+// Chip geometry of the CURRENT device, queried once per device (hipDeviceGetAttribute: compute units, XCDs).  The persistent
+// kernels of this library run one workgroup per CU (or a fixed fraction of the CUs while another kernel has the rest): their
+// grids come from here, not from MI355X's 256 / 8 written into the launchers (a partitioned -- CPX --
+// or differently binned part would have run wrong-sized persistent grids).  wgs(n256): the count that is n256 of 256 on a full
+// MI355X, scaled to this device's CUs and rounded down to a whole number per XCD (at least one per XCD).
+struct Chip {
+  int cus, xcds;
+  int wgs(int n256) const {
+    const int per = (int)((long)n256 * cus / 256) / (xcds > 0 ? xcds : 1);
+    return (per > 0 ? per : 1) * (xcds > 0 ? xcds : 1);
+  }
+};
+const Chip& chip();                          // defined in jt_march.hip
+
 #define JT_LAUNCH_CHECK()                      \
   do {                                         \
     hipError_t e__ = hipGetLastError();        \

@@ -780,6 +780,31 @@ extern "C" int jt_status_clear(void* stream) {
   return JT_OK;
 }
 
+// geometry of the current device (jt_common.h: Chip), queried once per device index; a failed query falls back to MI355X's
+const jt::Chip& jt::chip() {
+  static jt::Chip table[64];
+  static std::atomic<int> known[64];
+  static const jt::Chip mi355x = {256, 8};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return mi355x;
+  if (!known[dev].load(std::memory_order_acquire)) {
+    int cus = 0, xcds = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (hipDeviceGetAttribute(&xcds, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess || xcds <= 0) xcds = cus >= 64 ? 8 : 1;
+    if (cus % xcds != 0) xcds = 1;
+    table[dev] = jt::Chip{cus, xcds};     // (two threads racing here write the same values)
+    known[dev].store(1, std::memory_order_release);
+  }
+  return table[dev];
+}
+/* the persistent grids as this device gets them: {compute units, XCDs} */
+extern "C" int jt_chip_geometry(int32_t* out2) {
+  if (!out2) return JT_ERR_ARG;
+  const jt::Chip& c = jt::chip();
+  out2[0] = c.cus, out2[1] = c.xcds;
+  return JT_OK;
+}
+
 static std::atomic<int> g_deterministic{-1};  // -1: not yet read from the environment
 int jt::jt_deterministic() {
   int v = g_deterministic.load(std::memory_order_relaxed);
@@ -1006,7 +1031,9 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
   }
   // (JT_WALK_WGS, read once: fewer workgroups -- a multiple of three -- leave CUs to whatever runs beside the walk)
   static const int wgs_env = [] { const char* e = getenv("JT_WALK_WGS"); return e ? atoi(e) : 0; }();
-  const long wg_cap = wgs_env > 0 ? std::min<long>(wgs_env / 3 * 3, 255L * (16 / nw)) : 255L * (16 / nw);
+  // (one sixteen-wave / two eight-wave workgroups per CU, a multiple of three: 255 / 510 on MI355X's 256 CUs)
+  const long wg_full = (long)(chip().cus / 3 * 3) * (16 / nw);
+  const long wg_cap = wgs_env > 0 ? std::min<long>(wgs_env / 3 * 3, wg_full) : wg_full;
   const int blocks = (int)std::min<long>(3 * ((witems + nw - 1) / nw), std::max<long>(wg_cap, 3));  // 85 / 170 workgroups per plane
 #define JT_WALK_ONE(CD_, DET_, LL_, NW_)                                                                                    \
   do {                                                                                                                      \

@@ -205,7 +205,11 @@ struct RegDims {
 // out3 = {L1, TV_density, TV_color} with the reference's normalisations (tensoRF.py:212-228, tensorBase.py:21-38)
 __device__ inline void reg_combine(const float* sums, const RegDims& S, float* __restrict__ out3) {
   float l1 = 0.f, tvd = 0.f, tva = 0.f;
+  // (unrolled: S is a kernel argument, and a rolled loop indexing it dynamically made the compiler copy nine words of it into
+  //  scratch memory -- 36 bytes per lane in k_reg_batch_fused)
+#pragma unroll
   for (int i = 0; i < 6; ++i) l1 += sums[i * 3] / ((float)S.H[i] * S.W[i] * S.C[i]);
+#pragma unroll
   for (int i = 0; i < 3; ++i) {
     float ta = 0.f, tb = 0.f;
     if (S.H[i] > 1) ta += sums[i * 3 + 1] / ((float)S.C[i] * (S.H[i] - 1) * S.W[i]);
@@ -278,10 +282,9 @@ __global__ __launch_bounds__(256) void k_reg_batch_fwd(RegBatch B, RegDims S, fl
 // k_reg_batch_fwd + k_reg_batch_bwd streamed the same factors back to back (LLFF final grid: 285 MB twice, 107 + 151 us).
 // The gradient is WRITTEN (the render backward's atomics land on top of it: ops.RenderRays, "reg_first").
 template <bool TV>
-__device__ inline void factor_reg_fused_body(const float* __restrict__ x, int H, int W, int C, const float coef[3],
+__device__ inline void factor_reg_fused_body(const float* __restrict__ x, int H, int W, int C, float c0, float c1, float c2,
                                              float* __restrict__ g, float* __restrict__ out, int bid, int nblocks) {
   __shared__ float red[4][3];
-  const float c0 = coef[0], c1 = coef[1], c2 = coef[2];
   const unsigned C4 = C / 4;
   const unsigned total = (unsigned)H * W * C4;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -380,18 +383,19 @@ __global__ __launch_bounds__(256) void k_reg_batch_fused(RegBatch B, RegDims S, 
   const int bid = blockIdx.x - T.block0;
   const int i = T.slot;  // 0-2 density planes, 3-5 density lines, 6-8 appearance planes
   const float g0 = Wt.dev ? Wt.dev[0] : Wt.w[0], g1 = Wt.dev ? Wt.dev[1] : Wt.w[1], g2 = Wt.dev ? Wt.dev[2] : Wt.w[2];
-  float coef[3] = {0.f, 0.f, 0.f};
-  if (i < 6) coef[0] = g0 / ((float)T.H * T.W * T.C);
+  // (three scalars, not an array handed on by address: the array kept a 36-byte private segment alive in the kernel descriptor)
+  float cf0 = 0.f, cf1 = 0.f, cf2 = 0.f;
+  if (i < 6) cf0 = g0 / ((float)T.H * T.W * T.C);
   if (T.tv) {
     const float gt = i < 3 ? g1 : g2;
-    if (T.H > 1) coef[1] = gt * 2e-2f / ((float)T.C * (T.H - 1) * T.W);
-    if (T.W > 1) coef[2] = gt * 2e-2f / ((float)T.C * T.H * (T.W - 1));
+    if (T.H > 1) cf1 = gt * 2e-2f / ((float)T.C * (T.H - 1) * T.W);
+    if (T.W > 1) cf2 = gt * 2e-2f / ((float)T.C * T.H * (T.W - 1));
   }
   float* sums = scratch + (bid % kRegShards) * 36 + T.slot * 3;
   if (T.tv)
-    factor_reg_fused_body<true>(T.x, T.H, T.W, T.C, coef, T.g, sums, bid, T.nblocks);
+    factor_reg_fused_body<true>(T.x, T.H, T.W, T.C, cf0, cf1, cf2, T.g, sums, bid, T.nblocks);
   else
-    factor_reg_fused_body<false>(T.x, T.H, T.W, T.C, coef, T.g, sums, bid, T.nblocks);
+    factor_reg_fused_body<false>(T.x, T.H, T.W, T.C, cf0, cf1, cf2, T.g, sums, bid, T.nblocks);
   // tickets and the combine step: as k_reg_batch_fwd
   __shared__ int s_last;
   __shared__ float s_sums[36];

@@ -34,7 +34,7 @@ namespace jt {
 // that the backward does not have to gather and run the forward chain a second time.  REC = 2: only what a
 // pose-only backward reads (basis output, ReLU sign words, sample coordinates).  REC = 3 (training, "lean tape", round 6):
 // as 1 without the 3 Ca product rows -- dBasis is then formed inside k_shade_scatter from the plane x line products the
-// walkers hold anyway, and a tile's record block is `rrows` = R_PROD rows instead of REC_FLOATS (1 344 instead of 1 920 bytes
+// walkers hold anyway, and a tile's record block is `rrows` = R_LEAN rows instead of REC_FLOATS (1 088 instead of 1 920 bytes
 // per shaded sample for VM-48).  `rrows` is a launch argument in every kernel that addresses records.
 template <class C, int REC>
 __global__ __launch_bounds__(256, 2) void k_shade_fwd(Dev D, MlpDev M, PeMask pm, const float* __restrict__ rays_o,
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void k_shade_bwd(Dev D, MlpDev M, PeMask pm
         float gsum = go[0] * w.x + go[1] * w.y + go[2] * w.z;
         G2.v[mt][r] = ((mask2 >> (mt * 16 + r)) & 1u) ? gsum : 0.f;
       }
-    rec_store<C::MT>(rt, B::R_G2, G2.v, j, h, onrec);
+    rec_store<C::MT>(rt, B::R_G2, G2.v, j, h, onrec && !(ablate & 32));   // (lean tape: the dW2 GEMM derives G2)
     // ---- layer 2 backward: g_h1[k] = sum_i W2[i][k] G2[i] ; masked by relu(h1) ----
     Hidden<C> G1;
 #pragma unroll
@@ -1208,11 +1208,39 @@ __device__ inline void wgrad_epilogue(f32x16 (*acc)[NT], const float* asum, floa
   }
 }
 
-template <int MT, int NT, int XF>
+// XA = 1 (round 6, lean tape): the A operand is G2, the gradient at the second hidden layer's pre-activations, and it is NOT
+// read from records: G2[i][s] = relu'(h2[i][s]) (w3[0][i] go0[s] + w3[1][i] go1[s] + w3[2][i] go2[s]) is three fused
+// multiply-adds on what the tile already holds per sample -- the three GO rows and the layer's ReLU sign word (row
+// mask_row0 + lane half of the chain that owned the unit, bit (M tile) * 16 + r: jt_shade_record_layout) -- so the chain kernel
+// does not store the HID rows of G2 (256 of 1 344 bytes per sample for VM-48) and this GEMM streams 5 + HID rows instead of
+// 2 HID.  The four source rows are the same for all 32 units of a lane half: one fetch per tile, broadcast.
+struct G2Src {
+  const float* w3;   // [3][in3] (torch layout), the unit's column is hoff + i
+  int go_row0, mask_row0, in3, hoff;
+};
+__device__ inline void g2_load_raw(const float* tile, const G2Src& S, int m, int h, float (*raw)[16]) {
+  const int hh = (m >> 2) & 1;   // lane half of the chain wave that held unit m of an M tile (rowmap)
+#pragma unroll
+  for (int c = 0; c < 3; ++c) load_row_half(tile + (size_t)(S.go_row0 + c) * 32, true, h, raw[c]);
+  load_row_half(tile + (size_t)(S.mask_row0 + hh) * 32, true, h, raw[3]);
+}
+template <int MT>
+__device__ inline void g2_derive(const float (*raw)[16], const float (*w)[3], int m, float (*av)[16]) {
+  const int r = (m & 3) + 4 * (m >> 3);
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float gsum = raw[0][q] * w[a][0] + raw[1][q] * w[a][1] + raw[2][q] * w[a][2];
+      av[a][q] = ((__float_as_uint(raw[3][q]) >> (a * 16 + r)) & 1u) ? gsum : 0.f;
+    }
+}
+
+template <int MT, int NT, int XF, int XA = 0>
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ rec, int a_row0, int M, int b_row0, int N,
                                                int f_row0, int vd_row0, int rec_rows, PeMask pm, int APP,
                                                const int* __restrict__ offset, int R, int cap, int chunk_start,
-                                               int chunk_cap, float* __restrict__ slab) {
+                                               int chunk_cap, float* __restrict__ slab, G2Src gs) {
   __shared__ float s_red[4][16][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int m = lane & 31, h = lane >> 5;
@@ -1246,6 +1274,13 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ rec, in
     }
   };
   float av[MT][16], an[MT][16];
+  float gw[MT][3], raw[XA ? 4 : 1][16], rawn[XA ? 4 : 1][16];
+  if (XA) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gw[a][c] = (a * 32 + m < M) ? gs.w3[c * gs.in3 + gs.hoff + a * 32 + m] : 0.f;
+  }
   if (XF == 0) {
     auto loadB = [&](int t, int b, float* dst) {
       const int c = b * 32 + m;
@@ -1253,7 +1288,8 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ rec, in
     };
     float bv[16], bn[16];
     if (t_begin < t_end) {
-      loadA(t_begin, av);
+      if (XA) g2_load_raw(rec + (size_t)t_begin * tstride, gs, m, h, raw);
+      else loadA(t_begin, av);
       loadB(t_begin, 0, bv);
     }
     for (int t = t_begin; t < t_end; ++t) {
@@ -1263,10 +1299,12 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ rec, in
         if (b + 1 < NT) {
           loadB(t, b + 1, bn);
         } else if (t + 1 < t_end) {
-          loadA(t + 1, an);
+          if (XA) g2_load_raw(rec + (size_t)(t + 1) * tstride, gs, m, h, rawn);
+          else loadA(t + 1, an);
           loadB(t + 1, 0, bn);
         }
         if (b == 0) {
+          if (XA) g2_derive<MT>(raw, gw, m, av);
           if (nl < 32) {
 #pragma unroll
             for (int a = 0; a < MT; ++a) mask_tail(av[a], h, nl);
@@ -1285,10 +1323,17 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ rec, in
 #pragma unroll
         for (int q = 0; q < 16; ++q) bv[q] = bn[q];
       }
+      if (XA) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) raw[XA ? c : 0][q] = rawn[XA ? c : 0][q];
+      } else {
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int q = 0; q < 16; ++q) av[a][q] = an[a][q];
+      }
     }
   } else {
     const bool feat = m < APP, view = (XF == 1) && !feat && (m < APP + 3);
@@ -1358,11 +1403,11 @@ __device__ inline void pin16(float v[16]) {
 // per-sample data here, so both are split in registers -- (MT + NT) x 16 values per lane and tile -- and a tile's 32 samples
 // are two 16-deep K steps (lane half h feeds samples 16 h + 8 s .. + 7 to step s: the contraction order is free as long as
 // A and B agree).  Per (M tile, N tile) and tile of samples: 12 MFMAs of 32 cycles instead of 16 of 64.
-template <int MT, int NT, int XF>
+template <int MT, int NT, int XF, int XA = 0>
 __global__ __launch_bounds__(256) void k_wgrad_b16(const float* __restrict__ rec, int a_row0, int M, int b_row0, int N,
                                                    int f_row0, int vd_row0, int rec_rows, PeMask pm, int APP,
                                                    const int* __restrict__ offset, int R, int cap, int chunk_start,
-                                                   int chunk_cap, float* __restrict__ slab) {
+                                                   int chunk_cap, float* __restrict__ slab, G2Src gs) {
   __shared__ float s_red[4][16][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int m = lane & 31, h = lane >> 5;
@@ -1405,6 +1450,13 @@ __global__ __launch_bounds__(256) void k_wgrad_b16(const float* __restrict__ rec
   };
   float av[MT][16], an[MT][16];
   B3 a3[MT][2];
+  float gw[MT][3], raw[XA ? 4 : 1][16], rawn[XA ? 4 : 1][16];
+  if (XA) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gw[a][c] = (a * 32 + m < M) ? gs.w3[c * gs.in3 + gs.hoff + a * 32 + m] : 0.f;
+  }
   if (XF == 0) {
     auto loadB = [&](int t, int b, float* dst) {
       const int c = b * 32 + m;
@@ -1412,7 +1464,8 @@ __global__ __launch_bounds__(256) void k_wgrad_b16(const float* __restrict__ rec
     };
     float bv[16], bn[16];
     if (t_begin < t_end) {
-      loadA(t_begin, av);
+      if (XA) g2_load_raw(rec + (size_t)t_begin * tstride, gs, m, h, raw);
+      else loadA(t_begin, av);
       loadB(t_begin, 0, bv);
     }
     for (int t = t_begin; t < t_end; ++t) {
@@ -1425,12 +1478,19 @@ __global__ __launch_bounds__(256) void k_wgrad_b16(const float* __restrict__ rec
           loadB(t, b + 1, bn);
         } else {
           const int tn = min(t + 1, t_end - 1);
-          loadA(tn, an);
+          if (XA) g2_load_raw(rec + (size_t)tn * tstride, gs, m, h, rawn);
+          else loadA(tn, an);
           loadB(tn, 0, bn);
         }
         if (b == 0) {
+          if (XA) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pin16(raw[XA ? c : 0]);
+            g2_derive<MT>(raw, gw, m, av);
+          } else {
 #pragma unroll
           for (int a = 0; a < MT; ++a) pin16(av[a]);
+          }
           prepA(av, nl, a3);
         }
         pin16(bv);
@@ -1444,10 +1504,17 @@ __global__ __launch_bounds__(256) void k_wgrad_b16(const float* __restrict__ rec
 #pragma unroll
         for (int q = 0; q < 16; ++q) bv[q] = bn[q];
       }
+      if (XA) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) raw[XA ? c : 0][q] = rawn[XA ? c : 0][q];
+      } else {
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int q = 0; q < 16; ++q) av[a][q] = an[a][q];
+      }
     }
   } else {
     const bool feat = m < APP, view = (XF == 1) && !feat && (m < APP + 3);
@@ -1651,9 +1718,10 @@ static std::atomic<int> g_bwd_split{-2};
 // Round 6: with dBasis formed in the scatter itself only three GEMMs (1.7 instead of 2.5 GB of record rows) run beside it and the
 // balance moves to 224 workgroups = 28 per XCD = 7 per shader engine: 2.88 against 2.93 (192) and 2.97 ms (256) per step
 // (profiles/round6_lean_tape_ab.txt).
+// (the counts are those of a full MI355X -- 256 CUs in 8 XCDs --; Chip::wgs scales them to the device the library runs on)
 static int scatter_wgs(bool gemms_beside, bool lean = false) {
-  static const int v = [] { const char* e = getenv("JT_SCATTER_WGS"); const int n = e ? atoi(e) : 0; return n > 0 ? std::min(n, 256) : 0; }();
-  return v ? v : (gemms_beside ? (lean ? 224 : 192) : 256);
+  static const int v = [] { const char* e = getenv("JT_SCATTER_WGS"); const int n = e ? atoi(e) : 0; return n > 0 ? n : 0; }();
+  return v ? std::min(v, chip().cus) : chip().wgs(gemms_beside ? (lean ? 224 : 192) : 256);
 }
 static int bwd_split_mode() {
   int m = g_bwd_split.load(std::memory_order_relaxed);
@@ -1675,7 +1743,7 @@ extern "C" int jt_debug_read_tile_stamps(unsigned long long* out16) {
 #endif
 // "Lean tape" (round 6; JT_LEAN_TAPE, read once, default 1; jt_shade_set_lean_tape): when the backward is the split form with the
 // walker scatter (runs of 8 / 16), dBasis is formed inside k_shade_scatter and the training forward does not record the 3 Ca
-// plane x line products -- a tile's record block shrinks from REC_FLOATS to R_PROD rows.  Whether a render is lean is a function
+// plane x line products -- a tile's record block shrinks from REC_FLOATS to R_LEAN rows (neither are the G2 rows stored: k_wgrad XA).  Whether a render is lean is a function
 // of the library's modes alone (this switch, the split mode, matrix-mode bit 2), so the forward, the backward and the workspace
 // query agree as long as no mode changes between a forward and its backward (as for jt_shade_set_chunk_log2).
 static std::atomic<int> g_lean{-1};
@@ -1697,7 +1765,7 @@ static bool lean_tape() {
   return m == 8 || m == 16 || (m == -1 && split_default<C>() != 0);
 }
 template <class C>
-static int rec_rows() { return lean_tape<C>() ? BwdCfg<C>::R_PROD : BwdCfg<C>::REC_FLOATS; }
+static int rec_rows() { return lean_tape<C>() ? BwdCfg<C>::R_LEAN : BwdCfg<C>::REC_FLOATS; }
 extern "C" int jt_shade_lean_tape(void) { return lean_mode(); }
 extern "C" int jt_shade_set_lean_tape(int on) {
   const int prev = lean_mode();
@@ -1746,15 +1814,60 @@ struct WsLayout {
   }
   // records + slabs; the tile-owned scatter's lists and counters (jt_tile.h) sit behind them
   static size_t main_bytes(int cap) {
-    const int nchunks = (cap + kChunkEntries - 1) / kChunkEntries;
+    const int nchunks = (int)(((long)cap + kChunkEntries - 1) / kChunkEntries);
     return (rec_floats(cap) + slab_floats_per_chunk() * (size_t)std::max(nchunks, 1)) * sizeof(float);
   }
 };
 
+// Capacities above 2^30 shaded samples are refused (found by the UBSan run of tests/test_sanitizers.py: the chunk count of a
+// capacity near INT_MAX overflowed an int, and the kernels index samples with 32-bit integers; 2^30 samples would be a
+// 1.2 TB tape anyway).
+static const int kMaxEntries = 1 << 30;
 extern "C" size_t jt_shade_workspace_bytes(const JtScene* scene, int n_entries_max) {
   const int kind = shade_kind(scene);
-  if (kind < 0 || n_entries_max < 1) return 0;
+  if (kind < 0 || n_entries_max < 1 || n_entries_max > kMaxEntries) return 0;
   return (kind == 0) ? WsLayout<CfgBlender>::bytes(n_entries_max) : WsLayout<CfgLlff>::bytes(n_entries_max);
+}
+
+// Where the pieces of a shade workspace sit, for the library's CURRENT modes (tests/test_sanitizers.py: every carved piece must
+// lie inside jt_shade_workspace_bytes for boundary capacities).  Byte offsets from the workspace base / byte sizes:
+//   out[0] total (= jt_shade_workspace_bytes)   out[1] records: size (offset 0)        out[2] slabs: offset
+//   out[3] slabs: bytes per chunk                out[4] chunks                          out[5] rows of a tile's record block
+//   out[6] dBasis slab: offset inside a chunk's slabs   out[7] dBasis slab: bytes the scatter's workgroups write at most
+//   out[8] tile-owned scatter: 1 if its lists are part of the workspace, then (offset, bytes) pairs of its seven pieces
+//          list, gx, items, cnt, offs, cursor, ctl in out[9..22]
+template <class C>
+static void ws_layout(int cap, int64_t* out) {
+  typedef WsLayout<C> W;
+  const int chunk = kChunkEntries;
+  const int nchunks = std::max((int)(((long)cap + chunk - 1) / chunk), 1);
+  out[0] = (int64_t)W::bytes(cap);
+  out[1] = (int64_t)(W::rec_floats(cap) * sizeof(float));
+  out[2] = out[1];
+  out[3] = (int64_t)(W::slab_floats_per_chunk() * sizeof(float));
+  out[4] = nchunks;
+  out[5] = rec_rows<C>();
+  out[6] = (int64_t)((W::P3 + W::P2 + W::P1) * kWgradBlocks * sizeof(float));
+  out[7] = (int64_t)((size_t)chip().cus * ScatCfg<C>::DB_SLAB * sizeof(float));
+  out[8] = bwd_split_mode() == 1 ? 1 : 0;
+  for (int i = 9; i < 23; ++i) out[i] = 0;
+  if (out[8]) {
+    const TileWs t = tile_ws_carve(reinterpret_cast<void*>((uintptr_t)W::main_bytes(cap)), cap, chunk);
+    const size_t lc = (size_t)t.list_cap, mi = (size_t)t.max_items;
+    const void* ptrs[7] = {t.list, t.gx, t.items, t.cnt, t.offs, t.cursor, t.ctl};
+    const size_t sizes[7] = {3 * lc * sizeof(uint4), kTileMaxClasses * lc * sizeof(float4), 3 * mi * sizeof(int4),
+                             3 * (size_t)kTileMaxTiles * sizeof(int), 3 * (size_t)kTileMaxTiles * sizeof(int),
+                             3 * (size_t)kTileMaxTiles * sizeof(int), 64 * sizeof(int)};
+    for (int i = 0; i < 7; ++i) out[9 + 2 * i] = (int64_t)(uintptr_t)ptrs[i], out[10 + 2 * i] = (int64_t)sizes[i];
+  }
+}
+extern "C" int jt_shade_workspace_layout(const JtScene* scene, int n_entries_max, int64_t* out23) {
+  const int kind = shade_kind(scene);
+  if (kind < 0 || !out23) return JT_ERR_UNSUPPORTED;
+  if (n_entries_max < 1 || n_entries_max > kMaxEntries) return JT_ERR_ARG;
+  if (kind == 0) ws_layout<CfgBlender>(n_entries_max, out23);
+  else ws_layout<CfgLlff>(n_entries_max, out23);
+  return JT_OK;
 }
 
 // layout of the per-tile records for readers outside this file (tests pin the ReLU signs the kernels took):
@@ -1785,7 +1898,7 @@ static int launch_shade_fwd_t(const Dev& D, const MlpDev& M, const PeMask& pm, c
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_fwd_b16<C, REC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
     constexpr int NW = JT_B16_THREADS / 64;
-    int blocks16 = (int)std::min<long>((tiles + NW - 1) / NW, 256);
+    int blocks16 = (int)std::min<long>((tiles + NW - 1) / NW, chip().cus);   // one 115 KB-LDS workgroup per CU
     hipLaunchKernelGGL((k_shade_fwd_b16<C, REC>), dim3(blocks16), dim3(JT_B16_THREADS), lds16, st, D, M, pm, rays_o, rays_d, jitter,
                        zvals, tmin, offset, R, eray, esmp, vdir, rgb_s, rec, cap, rec_rows<C>());
     JT_LAUNCH_CHECK();
@@ -1840,6 +1953,7 @@ extern "C" int jt_shade_forward(const JtScene* scene, const JtFactors* factors, 
   const int kind = shade_kind(scene);
   if (kind < 0) return JT_ERR_UNSUPPORTED;
   if (n_entries_max < 1) return JT_OK;
+  if (n_entries_max > kMaxEntries) return JT_ERR_ARG;
   MlpDev M = {mlp->basis, mlp->w1, mlp->b1, mlp->w2, mlp->b2, mlp->w3, mlp->b3};
   PeMask pm = pe_masks(scene->fea_pe_progress, scene->view_pe_progress, scene->fea_pe, scene->view_pe);
   hipStream_t st = (hipStream_t)stream;
@@ -1888,7 +2002,8 @@ struct TileSel {
     }
     // workgroups: one per CU, dealt to the (plane, class) sets; a class of two channel groups gets JT_TILE_RATIO per cent of
     // its plane's share (the per-pair set-up -- list entry, GF rows, tap records -- is the same for both classes)
-    static const int nwg = [] { const char* e = getenv("JT_TILE_WGS"); const int v = e ? atoi(e) : 0; return v >= 6 ? v : 256; }();
+    static const int nwg_env = [] { const char* e = getenv("JT_TILE_WGS"); const int v = e ? atoi(e) : 0; return v >= 6 ? v : 0; }();
+    const int nwg = nwg_env ? nwg_env : std::max(chip().cus, 6);
     static const int ratio = [] { const char* e = getenv("JT_TILE_RATIO"); const int v = e ? atoi(e) : 0; return (v > 0 && v < 100) ? v : 62; }();
     TileClasses TC;
     int acc = 0;
@@ -1921,7 +2036,7 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   if (lds > 160 * 1024) return JT_ERR_UNSUPPORTED;
   if (ws_bytes < W::bytes(cap)) return JT_ERR_ARG;
   const int chunk = kChunkEntries;
-  const int nchunks = (cap + chunk - 1) / chunk;
+  const int nchunks = (int)(((long)cap + chunk - 1) / chunk);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_bwd<C, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shade_bwd<C, true>),
@@ -1933,8 +2048,9 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   // profiling knob, read ONCE per process: 1 = no scatter, 2 = no gradient records, 4 = no weight-gradient GEMMs
   static const int abl_env = [] { const char* e = getenv("JT_ABLATE"); return e ? atoi(e) : 0; }();
   const int det = jt_deterministic();  // 16: the appearance-factor gradients go to int64 shadow buffers (fixed point)
+  // (bit 5: lean tape -- the chain does not store the G2 rows)
   const int ablate = abl_env | ((flags & JT_SHADE_SKIP_WGRAD) ? 4 : 0) |
-                     ((flags & kNoGradRecords) ? 2 : 0) | (det ? 16 : 0);
+                     ((flags & kNoGradRecords) ? 2 : 0) | (det ? 16 : 0) | (lean_tape<C>() ? 32 : 0);
   constexpr int NT3 = W::NT3, NT1 = W::NT1, NTB = W::NTB;
   constexpr int XF1 = (C::KIND == JT_MLP_FEA) ? 1 : 2;
   // ---- per chunk: the per-sample backward on the main stream, its weight-gradient GEMMs on the auxiliary stream ----
@@ -1977,10 +2093,12 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   const bool lean = lean_tape<C>();
   if (lean && (split != 8 && split != 16)) return JT_ERR_ARG;  // (a mode was changed between the forward and this backward)
   const bool dbs = lean && !pose_only && !(ablate & 4) && GM.basis != nullptr;
+  // (the scatter's workgroups leave their dBasis slices where the fourth GEMM's slabs used to go)
+  if (dbs && (size_t)chip().cus * ScatCfg<C>::DB_SLAB > W::PB * (size_t)kWgradBlocks) return JT_ERR_UNSUPPORTED;
   auto launch_bwd = [&](int ci) -> int {
     const int start = ci * chunk, ccap = std::min(chunk, cap - start);
     long tiles = ((long)ccap + 31) / 32;
-    int blocks = (int)std::min<long>((tiles + B::NWAVE - 1) / B::NWAVE, 256);
+    int blocks = (int)std::min<long>((tiles + B::NWAVE - 1) / B::NWAVE, chip().cus);   // one workgroup per CU (its LDS fills it)
     float* rc = recs + W::rec_floats_per_chunk() * ci;
     if (split && (bf16x3_mode() & 4)) {
       // the chain of the split backward on the bf16 matrix cores (three-piece operands): matrix-mode bit 2
@@ -2028,8 +2146,9 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   };
   static const int sw_env = [] { const char* e = getenv("JT_SCATTER_WAVES"); return e ? atoi(e) : 0; }();
   int sw = 8;
-  // (with dBasis formed in the scatter the sixteen-wave shape's 128 registers spill 44-96 bytes per lane: eight waves then)
-  if (C::CA < 48 && split && !tile && (sw_env == 16 || (sw_env == 0 && !dbs && scatter_lds(split, sflags, 16) <= 160 * 1024))) sw = 16;
+  // (with dBasis formed in the scatter the sixteen-wave shape's 128 registers spill 44-96 bytes per lane -- and it is still the
+  //  faster shape where it fits: LLFF stage 0, 20 480 rays, 4.01 against 4.24 ms per step with eight waves)
+  if (C::CA < 48 && split && !tile && (sw_env == 16 || (sw_env == 0 && scatter_lds(split, sflags, 16) <= 160 * 1024))) sw = 16;
   if (split && !tile && scatter_lds(split, sflags, sw) > 160 * 1024) sflags &= ~1;  // a line too long for the LDS: global atomics as before
   auto launch_scatter = [&](int ci) -> int {
     if (!split || (ablate & 1)) return JT_OK;
@@ -2089,23 +2208,29 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     const int start = ci * chunk, ccap = std::min(chunk, cap - start);
     const float* rec = recs + W::rec_floats_per_chunk() * ci;
     // dW3/db3 = GO^T MID ; dW2/db2 = G2^T H1 ; dW1/db1 = G1^T X(F, d) ; dBasis = GF^T PROD
+    const G2Src gs = {M.w3, B::R_GO, B::R_MASK + 2, C::IN3, (C::KIND == JT_MLP_FEA) ? 0 : 12};
     float* s3 = slabs + (size_t)ci * cstride;
     float* s2 = s3 + W::P3 * nb;
     float* s1 = s2 + W::P2 * nb;
     float* sb = s1 + W::P1 * nb;
 #define JT_WGRAD_LAUNCH(KERNEL)                                                                                          \
   hipLaunchKernelGGL((KERNEL<1, NT3, 0>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_GO, 3, B::R_MID, C::IN3, B::R_F,      \
-                     B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s3);                                          \
+                     B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s3, gs);                                      \
   JT_LAUNCH_CHECK();                                                                                                     \
+  if (lean) {                                                                                                            \
+  hipLaunchKernelGGL((KERNEL<C::MT, C::MT, 0, 1>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_G2, C::HID, B::R_H1, C::HID, \
+                     B::R_F, B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s2, gs);                              \
+  } else {                                                                                                               \
   hipLaunchKernelGGL((KERNEL<C::MT, C::MT, 0>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_G2, C::HID, B::R_H1, C::HID,    \
-                     B::R_F, B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s2);                                  \
+                     B::R_F, B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s2, gs);                              \
+  }                                                                                                                      \
   JT_LAUNCH_CHECK();                                                                                                     \
   hipLaunchKernelGGL((KERNEL<C::MT, NT1, XF1>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_G1, C::HID, B::R_F, C::IN1,     \
-                     B::R_F, B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s1);                                  \
+                     B::R_F, B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, s1, gs);                              \
   JT_LAUNCH_CHECK();                                                                                                     \
   if (!dbs) {                                                                                                            \
   hipLaunchKernelGGL((KERNEL<1, NTB, 0>), dim3(nb), dim3(256), 0, ws_st, rec, B::R_GF, C::APP, B::R_PROD, C::NC, B::R_F, \
-                     B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, sb);                                          \
+                     B::R_VD, RR, pm, C::APP, offset, R, cap, start, ccap, sb, gs);                                      \
   JT_LAUNCH_CHECK();                                                                                                     \
   }
     if (bf16x3_mode() & 2) {
@@ -2194,7 +2319,7 @@ extern "C" int jt_shade_backward(const JtScene* scene, const JtFactors* factors,
   const int kind = shade_kind(scene);
   if (kind < 0) return JT_ERR_UNSUPPORTED;
   if (n_entries_max < 1) return JT_OK;
-  if (!workspace) return JT_ERR_ARG;
+  if (!workspace || n_entries_max > kMaxEntries) return JT_ERR_ARG;
   MlpDev M = {mlp->basis, mlp->w1, mlp->b1, mlp->w2, mlp->b2, mlp->w3, mlp->b3};
   PeMask pm = pe_masks(scene->fea_pe_progress, scene->view_pe_progress, scene->fea_pe, scene->view_pe);
   hipStream_t st = (hipStream_t)stream;

@@ -833,9 +833,10 @@ struct BwdCfg {
   // TILE-BLOCKED records: rec[tile][row][32 samples]; every accumulator register goes out as one coalesced
   // 128-byte-per-half store, no transposition (k_wgrad reads rows, one per lane).  The training forward
   // writes the layer inputs (PROD, F, VD, GEO, H1, MID, MASK), the backward adds the gradients (GO, G2, G1, GF).
+  // Round 6 ("lean tape"): the last two row groups exist only in the full layout.  A lean tile is R_LEAN rows: the products are
+  // not recorded (dBasis is formed in k_shade_scatter) and neither is G2 (the dW2 GEMM derives it from GO and the sign words).
   static constexpr int R_G1 = 0;
-  static constexpr int R_G2 = R_G1 + C::HID;
-  static constexpr int R_H1 = R_G2 + C::HID;
+  static constexpr int R_H1 = R_G1 + C::HID;
   static constexpr int R_MID = R_H1 + C::HID;
   static constexpr int R_F = R_MID + C::IN3;
   static constexpr int R_GF = R_F + 32;
@@ -843,8 +844,10 @@ struct BwdCfg {
   static constexpr int R_VD = R_GO + 4;    // view direction (3 rows + pad)
   static constexpr int R_MASK = R_VD + 4;  // ReLU sign bits of h1 / h2: row 2*layer + lane half, one word per sample
   static constexpr int R_GEO = R_MASK + 4; // normalised sample coordinates (3 rows + pad)
-  static constexpr int R_PROD = R_GEO + 4;
-  static constexpr int REC_FLOATS = R_PROD + C::NC;   // rows of one tile; a tile is [REC_FLOATS][32 samples]
+  static constexpr int R_LEAN = R_GEO + 4; // rows of a lean tile (VM-48: 272 = 1 088 bytes per sample; 20-channel scene: 188 = 752)
+  static constexpr int R_G2 = R_LEAN;
+  static constexpr int R_PROD = R_G2 + C::HID;
+  static constexpr int REC_FLOATS = R_PROD + C::NC;   // rows of a full tile (480 / 280); a tile is [rows][32 samples]
 };
 
 // record rows row0 + t*32 + rowmap(r,h) of the tile <- accumulator registers (lane = sample j)

@@ -708,16 +708,28 @@ class Model(torch.nn.Module):
         return float(opt.loss_weight.render) * render_scale, w_l1 * rs, w_tvd * rs, w_tvc * rs
 
     def train_iteration(self, opt, var):
-        """One optimisation step (model/bat.py:96-116 around model/base.py:154-172)."""
-        g = self.graph
-        g.it = self.it
+        """One optimisation step (model/bat.py:96-116 around model/base.py:154-172): the host-side engine in
+        begin_iteration / end_iteration, everything that touches the GPU in forward_backward (tests/test_engine_trace.py
+        drives the two host halves against a trace of the reference's own loop, without a GPU)."""
+        self.begin_iteration(opt)
+        loss = self.forward_backward(opt, var)
+        self.end_iteration(opt)
+        return loss
+
+    def begin_iteration(self, opt):
+        """model/bat.py:97-100 (linear warm-up of the pose learning rate) and model/base.py:118 (reproduced quirk, SURVEY
+        App. B-15: the scene gradients are zeroed at the top of EVERY iteration, so opt.optim.grad_accum_iter > 1 only thins
+        out the optimizer steps)."""
+        self.graph.it = self.it
         if opt.optim.warmup_pose:
             pg = self.optim_pose.param_groups[0]
             pg["lr_orig"] = pg["lr"]
             pg["lr"] *= min(1, self.it / opt.optim.warmup_pose)
-        # (reproduced quirk, SURVEY App. B-15: base.train_iteration zeroes the scene gradients at the top of EVERY
-        #  iteration, model/base.py:118, so opt.optim.grad_accum_iter > 1 only thins out the optimizer steps)
         self.optim.zero_grad()
+
+    def forward_backward(self, opt, var):
+        """model/base.py:157-162: forward, losses, weighted sum, backward"""
+        g = self.graph
         ops.PROFILING = bool(_has(opt, "profiling") and opt.profiling)  # roctx ranges named as model/base.py:119-153
         groups = self.tape_groups(opt)
         if groups > 1:
@@ -732,6 +744,11 @@ class Model(torch.nn.Module):
             with ops.prof_range("loss.all.backward()"):
                 loss.all.backward(gradient=self._backward_seed(loss.all))  # (a cached ones tensor: no fill launch per iteration)
         self.reduce_pose_gradients()
+        return loss
+
+    def end_iteration(self, opt):
+        """model/base.py:163-169 (scene step, the counter) and model/bat.py:103-114 (pose step on (it + 1) % period -- the
+        counter has been incremented by then, SURVEY App. B-19 --, warm-up undone, pose scheduler, progress)."""
         if (not _has(opt.optim, "grad_accum_iter")) or (self.it % opt.optim.grad_accum_iter) == 0:
             with ops.prof_range("optim.step"):
                 self.optim.step()
@@ -744,8 +761,7 @@ class Model(torch.nn.Module):
             self.optim_pose.param_groups[0]["lr"] = self.optim_pose.param_groups[0]["lr_orig"]
         if self.sched_pose is not None:
             self.sched_pose.step()
-        g.nerf.set_progress(self.it / opt.max_iter)
-        return loss
+        self.graph.nerf.set_progress(self.it / opt.max_iter)
 
     # ---- an iteration whose autograd tape would not fit a memory budget: forward + backward over ray groups -------------
     def tape_groups(self, opt):

@@ -1,0 +1,366 @@
+"""The ENGINE around the renderer, held to a trace of the reference's own training loop.
+
+tests/golden/engine_trace_{blender,llff}.npz were recorded by tools/make_engine_trace.py, which runs the reference's
+`bat.Model.train(opt)` (model/nerf.py:150-278 -> model/bat.py:96-116 -> model/base.py:154-172 -> model/tensorf.py:399-447)
+unmodified on a tiny scene under a shortened schedule of each BAT yaml: every grid upsampling, the ray-count switch, the
+pose reset, pose-gradient accumulation 8 -> 1 (on the reference's `(it + 1) %` counter), the pose-lr warm-up, the end of the
+factor blur, the edge-loss horizon, the L1 init -> rest switch, an alpha-mask update.  Per iteration the trace holds what
+the loop decided and the random draws it consumed.
+
+* `test_engine_dry_run_*` (CPU): `bat_hip.Model.train` itself -- before_iteration, select_supervision's draw,
+  begin_iteration / end_iteration, after_iteration / NeRF.update_schedule with its optimizer rebuilds -- with the one method
+  that touches the GPU (`forward_backward`) replaced by a stand-in that consumes the iteration's draws; every scheduled
+  quantity must EQUAL the reference's.
+* `test_engine_on_gpu_*` (-m gpu): the same loop with the real HIP renderer on the recorded draws; on top of the scheduled
+  quantities, the keyword arguments that reach the scene's forward and the losses / pose parameters the loop produces are
+  compared with the reference's iteration by iteration.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_trace(name):
+    d = np.load(os.path.join(HERE, "golden", "engine_trace_%s.npz" % name))
+    return {k: d[k] for k in d.files}, json.loads(bytes(d["meta"]).decode())
+
+
+class DrawQueue:
+    """np.random.randint / np.random.choice served from the recorded sequences, in order"""
+
+    def __init__(self, meta):
+        self.ints, self.choices = list(meta["np_randint"]), list(meta["np_choice"])
+        self.n_int = self.n_choice = 0
+
+    def randint(self, *a, **k):
+        v = self.ints[self.n_int]
+        self.n_int += 1
+        hi = a[0] if len(a) == 1 else a[1]
+        assert 0 <= v < hi, (v, a)      # the build asked for the same range the reference drew from
+        return v
+
+    def choice(self, pool, *a, **k):
+        v = self.choices[self.n_choice]
+        self.n_choice += 1
+        assert any(abs(float(p) - v) < 1e-12 for p in pool), (v, pool)
+        return type(pool[0])(v) if not isinstance(pool[0], (int, float)) else v
+
+    def __enter__(self):
+        self._orig = (np.random.randint, np.random.choice)
+        np.random.randint, np.random.choice = self.randint, self.choice
+        return self
+
+    def __exit__(self, *exc):
+        np.random.randint, np.random.choice = self._orig
+        return False
+
+
+def build(arr, meta, device):
+    from joint_tensorf_amd.data import DictDataset
+    from joint_tensorf_amd.model import bat_hip
+    from joint_tensorf_amd.options import make_options, Opt
+    over = json.loads(json.dumps(meta["overrides"]))
+    over.setdefault("data", {}).update(image_size=[meta["H"], meta["W"]], num_views=meta["n_views"])
+    opt = make_options(meta["yaml"], device=device, **over)
+    opt.train_graph = False
+    opt.freq = Opt(scalar=0, val=0, ckpt=0)
+    opt.output_path = None
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = bat_hip.Model(opt)
+    views = Opt(idx=torch.tensor(arr["in.idx"]), pose=torch.tensor(arr["in.pose_gt"]), intr=torch.tensor(arr["in.intr"]),
+                intr_inv=torch.tensor(arr["in.intr_inv"]), image=torch.tensor(arr["in.image"]))
+    model.train_data = DictDataset(opt, Opt({k: v.to(device) for k, v in views.items()}))
+    model.n_train_views = meta["n_views"]
+    return opt, model
+
+
+def load_init_state(model, arr):
+    sd = {k[len("init."):]: torch.tensor(arr[k]) for k in arr if k.startswith("init.")}
+    missing, unexpected = model.graph.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(("pose_eye" in k) or ("test_time" in k) for k in missing), missing
+
+
+class EngineRecorder:
+    """The same quantities tools/make_engine_trace.py records, taken at the same points of the build's loop."""
+
+    def __init__(self, opt, model):
+        self.opt, self.model, self.rows, self.cur = opt, model, [], {}
+        m = model
+        self._begin, self._end = m.begin_iteration, m.end_iteration
+        m.begin_iteration = self.begin
+        m.end_iteration = self.end
+        self._pose_step = m.optim_pose.step
+        m.optim_pose.step = self.pose_step
+        nerf = m.graph.nerf
+        self._update = nerf.update_schedule
+        nerf.update_schedule = self.update
+
+    def begin(self, opt):
+        m, nerf = self.model, self.model.graph.nerf
+        self.cur = dict(it=int(m.it), n_rays=int(opt.nerf.n_rays), progress=float(nerf.progress_host),
+                        lr_groups=[float(g["lr"]) for g in m.optim.param_groups], lr_pose=float(m.optim_pose.param_groups[0]["lr"]),
+                        pose_grad_accum_iter=int(opt.optim.pose_grad_accum_iter) if "pose_grad_accum_iter" in opt.optim else 1,
+                        grid=[int(x) for x in nerf.tensorf.gridSize.tolist()], n_samples=int(nerf.n_samples),
+                        TV_density_weight=float(opt.loss_weight.TV_density), TV_color_weight=float(opt.loss_weight.TV_color),
+                        pose_step=False, L1_weight=float(m.fused_loss_weights(opt)[1]),
+                        ray_sampling_strategy=str(opt.nerf.ray_sampling_strategy))
+        return self._begin(opt)
+
+    def pose_step(self, *a, **k):
+        self.cur["pose_step"] = True
+        self.cur["lr_pose_at_step"] = float(self.model.optim_pose.param_groups[0]["lr"])
+        return self._pose_step(*a, **k)
+
+    def end(self, opt):
+        out = self._end(opt)
+        m = self.model
+        self.cur["lr_pose_after"] = float(m.optim_pose.param_groups[0]["lr"])
+        self.cur["progress_after"] = float(m.graph.nerf.progress_host)
+        self.cur["graph_it"] = int(m.graph.it)
+        self.rows.append(self.cur)
+        return out
+
+    def update(self, opt, it):
+        self._update(opt, it)
+        m, nerf = self.model, self.model.graph.nerf
+        self.rows[-1]["after_update"] = dict(
+            it_arg=int(it), grid=[int(x) for x in nerf.tensorf.gridSize.tolist()], n_samples=int(nerf.n_samples),
+            lr_groups=[float(g["lr"]) for g in m.optim.param_groups], lr_basis=float(nerf.lr_basis), lr_index=float(nerf.lr_index),
+            TV_density_weight=float(opt.loss_weight.TV_density), TV_color_weight=float(opt.loss_weight.TV_color),
+            has_alpha_mask=nerf.tensorf.alphaMask is not None,
+            resolution_scale_init=[float(x) for x in opt.train_schedule.resolution_scale_init])
+
+
+SCHEDULED = ("it", "n_rays", "pose_grad_accum_iter", "grid", "n_samples", "pose_step", "graph_it", "ray_sampling_strategy")
+SCHEDULED_F = ("progress", "lr_pose", "lr_pose_after", "progress_after", "TV_density_weight", "TV_color_weight", "L1_weight")
+
+
+def compare_schedule(rows, ref_rows, alpha_mask=True):
+    assert len(rows) == len(ref_rows)
+    for got, ref in zip(rows, ref_rows):
+        it = ref["it"]
+        for k in SCHEDULED:
+            assert got[k] == ref[k], (it, k, got[k], ref[k])
+        for k in SCHEDULED_F:
+            np.testing.assert_allclose(got[k], ref[k], rtol=2e-6, atol=1e-12, err_msg="it %d %s" % (it, k))
+        np.testing.assert_allclose(got["lr_groups"], ref["lr_groups"], rtol=2e-6, err_msg="it %d lr_groups" % it)
+        if ref["pose_step"]:
+            np.testing.assert_allclose(got["lr_pose_at_step"], ref["lr_pose_at_step"], rtol=2e-6, err_msg="it %d" % it)
+        a, b = got["after_update"], ref["after_update"]
+        for k in ("it_arg", "grid", "n_samples", "resolution_scale_init") + (("has_alpha_mask",) if alpha_mask else ()):
+            assert a[k] == b[k], (it, k, a[k], b[k])
+        for k in ("lr_groups", "lr_basis", "lr_index", "TV_density_weight", "TV_color_weight"):
+            np.testing.assert_allclose(a[k], b[k], rtol=2e-6, err_msg="it %d after_update %s" % (it, k))
+
+
+# -------------------------------------------------------------------------------------------------------------------------
+# CPU: the loop without the renderer
+# -------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["blender", "llff"])
+def test_engine_dry_run_matches_the_reference_loop(name):
+    from joint_tensorf_amd.model import bat_hip
+    from joint_tensorf_amd.options import Opt
+    arr, meta = load_trace(name)
+    ref_rows = meta["iterations"]
+    opt, model = build(arr, meta, "cpu")
+    # build_networks draws the pose noise through the HIP pose kernel: the dry run takes the recorded initial state instead
+    g = model.graph = bat_hip.Graph(opt)
+    g.se3_refine = torch.nn.Embedding(meta["n_views"], 6)
+    if "init.pose_noise" in arr:
+        g.pose_noise = torch.nn.Parameter(torch.tensor(arr["init.pose_noise"]), requires_grad=False)
+    load_init_state(model, arr)
+    model.setup_optimizer(opt)
+    rec = EngineRecorder(opt, model)
+    q = DrawQueue(meta)
+    se3 = torch.tensor(arr["trace.se3_after"])
+    state = dict(sc=None)
+
+    # ---- stand-ins for everything that needs the GPU (and nothing else) -------------------------------------------------
+    def forward_backward(opt_, var):
+        # the host draws of Graph.forward / render_rays, in the loop's order: two lattice offsets, then the density blur scale
+        step = g.lattice_step(opt_, len(var.idx))
+        np.random.randint(step), np.random.randint(step)
+        blur = g.resolve_blur(opt_, "train")
+        ref = ref_rows[len(rec.rows)]
+        fk = ref["forward_kwargs"]
+        if fk["c2f_parameter_density"] is None:
+            assert blur[0] is None and blur[2] is None
+        else:
+            np.testing.assert_allclose([blur[0], blur[1]], [fk["c2f_parameter_density"], fk["c2f_parameter_color"]], rtol=2e-6)
+            assert (blur[2], blur[3]) == (fk["c2f_mode"], fk["c2f_kernel_size"])
+        assert state["sc"] == ref["image_is_scale"], (ref["it"], state["sc"], ref["image_is_scale"])
+        return Opt(all=torch.zeros(()))
+
+    def select_supervision(opt_, images=None):   # the cache itself is the blur kernel's (test_gpu_units); the DRAW is the engine's
+        state["sc"] = float(np.random.choice(opt_.c2f_alternate_2D_scale_pool))
+        return images, None, state["sc"]
+
+    def end_with_recorded_poses(opt_):
+        out = rec.end(opt_)
+        with torch.no_grad():   # (the optimizers do not step here: the pose parameters follow the reference's trace)
+            g.se3_refine.weight.copy_(se3[len(rec.rows) - 1])
+        return out
+
+    model.forward_backward = forward_backward
+    model.select_supervision = select_supervision
+    model.end_iteration = end_with_recorded_poses
+    model.validate = lambda *a, **k: None
+    model.check_finite = lambda *a, **k: None
+    model.optim_pose.step = lambda *a, **k: rec.cur.update(pose_step=True, lr_pose_at_step=float(model.optim_pose.param_groups[0]["lr"]))
+    nerf = g.nerf
+    nerf._update_alphamask = lambda it: None     # jt_dense_alpha is a HIP kernel (tests/test_gpu_lifecycle.py); its SCHEDULE is below
+    make_optim = nerf._get_optimizer
+
+    def get_optimizer(*a, **k):
+        o = make_optim(*a, **k)
+        o.step = lambda *aa, **kk: None
+        return o
+
+    nerf._get_optimizer = get_optimizer
+    model.optim.step = lambda *a, **k: None
+    resets = []
+    orig_interrupt = model.interrupt_pose
+    model.interrupt_pose = lambda o: (resets.append(model.it), orig_interrupt(o))[1]
+    with q:
+        model.train(opt)
+    assert q.n_int == len(meta["np_randint"]) and q.n_choice == len(meta["np_choice"])   # every recorded draw was consumed
+    compare_schedule(rec.rows, ref_rows, alpha_mask=False)
+    ts = opt.train_schedule
+    if "reset_pose_on_iter" in ts:
+        assert resets == [ts.reset_pose_on_iter]
+    assert nerf.tensorf.gridSize.tolist() == meta["final_grid"]
+
+
+def test_the_trace_covers_every_scheduled_event():
+    """what the shortened schedules were chosen to contain (a regenerated fixture that lost an event fails here)"""
+    for name in ("blender", "llff"):
+        arr, meta = load_trace(name)
+        rows = meta["iterations"]
+        grids = [tuple(r["grid"]) for r in rows]
+        assert len(set(grids)) == 5                                        # four upsamplings
+        assert len({r["n_rays"] for r in rows}) == 2                       # the ray-count switch
+        assert len({round(r["L1_weight"], 9) for r in rows}) == 2          # L1 init -> rest
+        assert any(r["forward_kwargs"]["c2f_mode"] is None for r in rows) and rows[0]["forward_kwargs"]["c2f_mode"] is not None
+        assert any(r["after_update"]["has_alpha_mask"] for r in rows)
+        assert len({r["image_is_scale"] for r in rows}) >= 4               # the 2-D supervision scale is drawn per iteration
+    arr, meta = load_trace("llff")
+    rows = meta["iterations"]
+    assert {r["pose_grad_accum_iter"] for r in rows} == {8, 1}
+    fired = [r["it"] for r in rows if r["pose_step"]]
+    assert fired[:3] == [7, 15, 23]                                        # (it + 1) % 8 == 0: the off-by-one of SURVEY App. B-19
+    assert rows[3]["lr_pose_at_step" if rows[3]["pose_step"] else "lr_pose"] > 0
+    assert any(abs(r["lr_pose_at_step"] - r["lr_pose"]) > 1e-9 for r in rows if r["pose_step"] and r["it"] < 10)   # warm-up seen
+    se3 = arr["trace.se3_after"]
+    assert np.abs(se3[11]).max() > 0 and np.abs(se3[12]).max() == 0   # the pose reset at iteration 12 (first pose step: it 7)
+    assert len({tuple(r["near_far"]) for r in rows}) > 3                   # the near-plane schedule moves
+    assert len(meta["coin"]) == len(rows)                                  # the white-background coin, once per training call
+
+
+# -------------------------------------------------------------------------------------------------------------------------
+# GPU: the loop with the HIP renderer, on the reference's draws
+# -------------------------------------------------------------------------------------------------------------------------
+def _run_on_gpu(name):
+    arr, meta = load_trace(name)
+    ref_rows = meta["iterations"]
+    opt, model = build(arr, meta, "cuda")
+    model.build_networks(opt, n_views=meta["n_views"])
+    load_init_state(model, arr)
+    model.setup_optimizer(opt)
+    rec = EngineRecorder(opt, model)
+    q = DrawQueue(meta)
+    g = model.graph
+    jit = [torch.tensor(arr["draw.jitter.%d" % i]) for i in range(meta["n_jitter"])]
+    coins = list(meta["coin"])
+    losses, kwargs = [], []
+    orig_fb = model.forward_backward
+
+    def forward_backward(opt_, var):
+        tf = g.nerf.tensorf
+        k = len(rec.rows)
+        j = jit[k].to("cuda")
+        tf.jitter_override = j if meta["llff"] else j.view(-1, 1)
+        tf.coin_override = coins[k] if coins else None
+        orig_forward = tf.forward
+
+        def spy(opt__, **kw):
+            kwargs.append({a: (list(v.shape) if torch.is_tensor(v) else v) for a, v in kw.items()})
+            kwargs[-1]["near_far"] = [float(tf.near_far[0]), float(tf.near_far[1])]
+            return orig_forward(opt__, **kw)
+
+        tf.forward = spy
+        try:
+            loss = orig_fb(opt_, var)
+        finally:
+            tf.forward = orig_forward
+            tf.jitter_override = tf.coin_override = None
+        losses.append({a: float(v.detach()) for a, v in loss.items() if torch.is_tensor(v)})
+        return loss
+
+    model.forward_backward = forward_backward
+    se3_after = []
+    orig_end = model.end_iteration
+
+    def end(opt_):
+        out = orig_end(opt_)
+        se3_after.append(g.se3_refine.weight.detach().cpu().clone())
+        return out
+
+    model.end_iteration = end
+    with q:
+        model.train(opt)
+    assert q.n_int == len(meta["np_randint"]) and q.n_choice == len(meta["np_choice"])
+    compare_schedule(rec.rows, ref_rows)
+    # what reached the scene's forward
+    for kw, ref in zip(kwargs, ref_rows):
+        fk, it = ref["forward_kwargs"], ref["it"]
+        assert kw["center"] == fk["center.shape"] and kw["ray_dir"] == fk["ray_dir.shape"], (it, kw["center"], fk["center.shape"])
+        for a in ("white_bg", "is_train", "is_test_optim", "ndc_ray", "N_samples", "c2f_mode", "c2f_kernel_size"):
+            assert kw[a] == fk[a], (it, a, kw[a], fk[a])
+        for a in ("c2f_parameter_density", "c2f_parameter_color", "fea_pe_progress", "view_pe_progress"):
+            if fk[a] is None:
+                assert kw[a] is None, (it, a)
+            else:
+                np.testing.assert_allclose(kw[a], fk[a], rtol=2e-6, err_msg="it %d %s" % (it, a))
+        np.testing.assert_allclose(kw["near_far"], ref["near_far"], rtol=2e-6, err_msg="it %d near_far" % it)
+    return arr, meta, ref_rows, losses, torch.stack(se3_after).numpy(), model
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["blender", "llff"])
+def test_engine_on_gpu_follows_the_reference_loop(name):
+    arr, meta, ref_rows, losses, se3, model = _run_on_gpu(name)
+    ref_se3 = arr["trace.se3_after"]
+    worst = dict(render=0.0, all=0.0, L1=0.0, se3=0.0)
+    for k, (got, ref) in enumerate(zip(losses, ref_rows)):
+        for key in ("render", "L1", "all"):
+            worst[key] = max(worst[key], abs(got[key] - ref["loss"][key]) / max(abs(ref["loss"][key]), 1e-12))
+        worst["se3"] = max(worst["se3"], float(np.abs(se3[k] - ref_se3[k]).max()))
+    print("\n[engine trace] %s: worst relative loss deviation render %.2e  L1 %.2e  all %.2e; worst |se3 - ref| %.2e over %d "
+          "iterations (final |se3| %.3e)" % (name, worst["render"], worst["L1"], worst["all"], worst["se3"], len(losses),
+                                            float(np.abs(ref_se3[-1]).max())))
+    # iteration 0 is a pure forward + loss comparison from the same state on the same draws
+    # (a regulariser whose weight is zero -- the TV terms of bat_blender_VM -- is not evaluated by the build at all; the reference
+    #  computes it for its log)
+    keys = ["render", "L1", "all"] + [k for k in ("TV_density", "TV_color") if ref_rows[0][k + "_weight"] > 0]
+    for key in keys:
+        np.testing.assert_allclose(losses[0][key], ref_rows[0]["loss"][key], rtol=5e-5, atol=1e-9, err_msg=key)
+    # later iterations carry everything both engines did in between (six Adam groups + the pose Adam, upsamplings through
+    # two different interpolation kernels, optimizer rebuilds): Adam turns round-off in a near-zero gradient into a full
+    # +-lr step of that element, so the two runs separate slowly; tolerances = ~4x what MI355X measured
+    tol = TOL[name]
+    assert worst["render"] <= tol["render"] and worst["all"] <= tol["render"] and worst["L1"] <= tol["L1"], worst
+    assert worst["se3"] <= tol["se3"], worst
+    # the pose trajectory is the reference's: same direction of travel, view by view, at the end of the run
+    a, b = se3[-1].reshape(-1), ref_se3[-1].reshape(-1)
+    cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+    assert cos > 0.995, cos
+
+
+TOL = dict(blender=dict(render=2e-2, L1=2e-3, se3=2e-3), llff=dict(render=2e-2, L1=2e-3, se3=2e-3))

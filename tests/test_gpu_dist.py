@@ -160,3 +160,27 @@ def test_bench_gpus_mismatch_is_an_error():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 3 and "--gpus 4" in r.stderr
+
+
+def test_rccl_process_group_of_one_rank():
+    """The collectives of the N > 1 path ON RCCL (every other test in this file rendezvous over gloo): a
+    process group of one rank on the "nccl" backend (= RCCL on ROCm), `init_process_group("nccl", device_id=...)`, the three
+    asynchronous all-reduces on slices of the flat gradient buffer inside the renderer's backward with their record_stream
+    bookkeeping, the pose all-reduce behind it, the barrier + max-over-ranks timing of the bench line.  One rank is all a
+    one-GPU box allows; what it proves is that this code path initialises and runs on RCCL at all before the driver's 8-GPU
+    node is the first to try."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               JT_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("JT_DIST_BACKEND", None)
+    env.pop("JT_BENCH_SINGLE_DEVICE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--no-probe", "--no-cpu-baseline", "--no-torch-baseline", "--no-extras", "--no-live-pmc"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    rk = line["ranks"]
+    assert rk["backend"] == "nccl" and rk["rccl_ranks"] == 1 and rk["world_size"] == 1, rk
+    assert rk["devices"] == "one GPU per rank"
+    assert len(line["allreduce_ms"]) == 3 and all(v > 0 for v in line["allreduce_ms"].values()), line["allreduce_ms"]
+    assert np.isfinite(line["value"]) and line["value"] > 0 and line["ms_per_step"] > 0
+    assert line["ms_per_step_no_collectives"] > 0
