@@ -802,7 +802,10 @@ def main():
                     "mlp": float(sum(p.grad.double().abs().sum() for p in tf.renderModule.weights())),
                     "basis": float(tf.basis_mat.weight.grad.double().abs().sum()),
                     "se3": float(model.graph.se3_refine.weight.grad.double().abs().sum())})
-        model.optim.step()
+        if getattr(model.optim, "supports_early_step", False):
+            model.optim.step(early_ok=True)   # as Model.end_iteration: nothing touches .grad between backward and step
+        else:
+            model.optim.step()
         model.optim.zero_grad()
         it = model.it
         model.it += 1

@@ -47,6 +47,16 @@ class _StageProbe:
     def __init__(self, lead):
         self.state, self.choice, self.n, self.t0, self.since = "replay_probe", "replay", -int(lead), 0.0, 0
         self.t_replay = self.t_eager = None
+        # host time the CALLER spent between the iterations of the window being timed: a window that contains a
+        # validation render, a checkpoint or a status read is thrown away instead of deciding the next REPROBE iterations
+        self.gaps, self.t_exit, self.discarded = [], None, 0
+
+    def window_is_clean(self):
+        """no gap between two iterations of the window above max(2 ms, 10 x the median gap)"""
+        if not self.gaps:
+            return True
+        med = sorted(self.gaps)[len(self.gaps) // 2]
+        return max(self.gaps) <= max(2e-3, 10.0 * med)
 
 
 def has_key(o, k):
@@ -133,6 +143,7 @@ class GraphedTrainStep:
         self.model = model
         self.adaptive = (os.environ.get("JT_GRAPH_ADAPTIVE", "1") != "0") if adaptive is None else bool(adaptive)
         self.policy = {}      # stage key -> _StageProbe
+        self._timed = None    # the probe whose window is being timed right now (train_iteration notes the caller's gaps in it)
         self.decisions = []   # (iteration, grid, choice, ms eager, ms replayed) per timed pair of windows (tools/converge.py)
         self.min_repeats = int(min_repeats)
         self.max_graphs = int(max_graphs)
@@ -233,7 +244,19 @@ class GraphedTrainStep:
 
     # ------------------------------------------------------------------------------------------------------
     def train_iteration(self, opt, var, force_eager=False):
-        """Drop-in for Model.train_iteration (same state transitions, same host draws)."""
+        """Drop-in for Model.train_iteration (same state transitions, same host draws).  Around the real work: the time the
+        caller spent since the previous iteration returned, noted while a launch-mode window is being timed."""
+        pr = self._timed
+        if pr is not None and pr.n > 0 and pr.t_exit is not None:
+            pr.gaps.append(time.perf_counter() - pr.t_exit)
+        try:
+            return self._train_iteration(opt, var, force_eager)
+        finally:
+            pr = self._timed
+            if pr is not None:
+                pr.t_exit = time.perf_counter()
+
+    def _train_iteration(self, opt, var, force_eager=False):
         m, g = self.model, self.model.graph
         if force_eager or not self._eligible(opt):
             self.stats["eager"] += 1
@@ -331,13 +354,19 @@ class GraphedTrainStep:
         if timing and probe.n == 0:
             torch.cuda.synchronize()
             probe.t0 = time.perf_counter()
+            probe.gaps, probe.t_exit, self._timed = [], None, probe
         e.graph.replay()
         if timing:
             probe.n += 1
             if probe.n == self.WINDOW:
                 torch.cuda.synchronize()
-                probe.t_replay = (time.perf_counter() - probe.t0) / self.WINDOW
-                probe.state, probe.n = "eager_probe", -self.WINDOW_LEAD
+                self._timed = None
+                if probe.window_is_clean():
+                    probe.t_replay = (time.perf_counter() - probe.t0) / self.WINDOW
+                    probe.state, probe.n = "eager_probe", -self.WINDOW_LEAD
+                else:   # the caller did something long inside the window: time it again
+                    probe.discarded += 1
+                    probe.n = -self.WINDOW_LEAD
         self.stats["replayed"] += 1
         pg = m.optim_pose.param_groups[0]
         if opt.optim.warmup_pose:  # model/bat.py:98-100,108-110 (a factor of one past the warm-up, which eligibility ensures)
@@ -378,20 +407,27 @@ class GraphedTrainStep:
         if probe.n == 0:
             torch.cuda.synchronize()
             probe.t0 = time.perf_counter()
+            probe.gaps, probe.t_exit, self._timed = [], None, probe
         self.stats["eager"] += 1
         self.stats["eager_by_choice"] += 1
         loss = self._eager(opt, var)
         probe.n += 1
         if probe.n == self.WINDOW:
             torch.cuda.synchronize()
+            self._timed = None
+            if not probe.window_is_clean():   # (see the replay window)
+                probe.discarded += 1
+                probe.n = -self.WINDOW_LEAD
+                return loss
             probe.t_eager = (time.perf_counter() - probe.t0) / self.WINDOW
             probe.choice = "eager" if probe.t_eager < self.EAGER_GAIN * probe.t_replay else "replay"
             probe.state, probe.n, probe.since = "decided", -self.WINDOW_LEAD, 0
             nerf = self.model.graph.nerf
             self.decisions.append((int(self.model.it), tuple(int(v) for v in nerf.resolution), probe.choice,
                                    round(probe.t_eager * 1e3, 3), round(probe.t_replay * 1e3, 3)))
-            if os.environ.get("JT_GRAPH_DEBUG") == "1":
-                print("graphed: it %d grid %s -> %s (%.3f ms eager, %.3f ms replayed)" % self.decisions[-1], flush=True)
+            if os.environ.get("JT_GRAPH_QUIET") != "1":   # one line per decision: two runs can be compared by their logs
+                print("graphed: it %d grid %s -> %s (%.3f ms eager, %.3f ms replayed; %d window(s) discarded for host work "
+                      "between iterations)" % (self.decisions[-1] + (probe.discarded,)), flush=True)
         return loss
 
     @staticmethod

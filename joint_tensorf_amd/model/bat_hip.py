@@ -751,7 +751,12 @@ class Model(torch.nn.Module):
         counter has been incremented by then, SURVEY App. B-19 --, warm-up undone, pose scheduler, progress)."""
         if (not _has(opt.optim, "grad_accum_iter")) or (self.it % opt.optim.grad_accum_iter) == 0:
             with ops.prof_range("optim.step"):
-                self.optim.step()
+                # (nothing has touched the gradients since the backward: the appearance factors may be stepped beside the
+                #  density backward, optim.VMAdam.step)
+                if getattr(self.optim, "supports_early_step", False):
+                    self.optim.step(early_ok=True)
+                else:
+                    self.optim.step()
             self.optim.zero_grad()
         self.it += 1
         if (not _has(opt.optim, "pose_grad_accum_iter")) or (self.it % opt.optim.pose_grad_accum_iter) == 0:

@@ -155,8 +155,15 @@ class VMAdam(torch.optim.Optimizer):
                 dyn = self._dyn_buffer(plist[0][0].device, len(plist))
                 check(lib.jt_adam_step_dyn(arr, len(plist), b1, b2, eps, ptr(dyn), stream), "jt_adam_step_dyn")
 
+    supports_early_step = True
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, early_ok=False):
+        """early_ok: only a caller that guarantees NOTHING touches the parameters' .grad between the render
+        backward and this call -- Model.end_iteration, the bench step that mirrors it -- may let the appearance factors be stepped
+        on the auxiliary stream behind the event the backward recorded in its middle (ops.RenderRays.backward's offer).  Gradient
+        clipping or scaling in place, a hook, a later AccumulateGrad add keep data_ptr unchanged: a plain step() therefore never
+        takes the offer and runs as one launch on the current stream, after everything the caller enqueued."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -169,7 +176,9 @@ class VMAdam(torch.optim.Optimizer):
         # (a step that has just created moments filled them on this stream a moment ago -- behind the event the auxiliary
         #  stream would wait for: that step stays on this stream as a whole)
         fresh = self.__dict__.pop("_state_created", False)
-        if ops._EARLY_GRADS and not fresh and len(self._items()) == 1:
+        if ops._EARLY_GRADS and not early_ok:
+            ops._EARLY_GRADS.clear()   # (an offer nobody may take: dropped, so that a later step cannot pick up a stale one)
+        if early_ok and ops._EARLY_GRADS and not fresh and len(self._items()) == 1:
             dev = next(p for g in self.param_groups for p in g["params"] if p.grad is not None).device
             offer = ops._EARLY_GRADS.get(ops.device_key(dev))
             # mine = the offered gradients that ARE the .grad of one of my tensors, in the layout the kernel walks (a gradient

@@ -14,6 +14,8 @@ CASES = [
     "blender_train_mid_blur", "blender_train_dense", "blender_train_dense_blur",
     "blender_train_randrays", "llff_train_sharp", "llff_train_blur", "llff_train_thin_whitebg",
     "blender_train_alphamask", "blender_train_shrunk",
+    # states taken INSIDE the reference's own training loop (tools/make_engine_trace.py --snapshot, round 6)
+    "llff_loop_it21", "llff_loop_it40", "blender_loop_it33",
 ]
 
 

@@ -337,30 +337,41 @@ def _run_on_gpu(name):
 def test_engine_on_gpu_follows_the_reference_loop(name):
     arr, meta, ref_rows, losses, se3, model = _run_on_gpu(name)
     ref_se3 = arr["trace.se3_after"]
+    # How far the two runs can be compared loss by loss is a property of the REFERENCE's loop, measured on the reference itself
+    # (tools/round6/loop_sensitivity.py, profiles/round6_llff_loop_sensitivity.txt): the LLFF loop turns a 1e-7 perturbation of
+    # its parameters into 3e-3 at the iteration where the scheduled near plane has gone negative and into 0.3 twenty iterations
+    # later -- behind that point only the SCHEDULE (compared above, all 64 iterations) and finiteness are held here, and the
+    # renderer is pinned on states of the reference's loop by the fixtures llff_loop_it21 / llff_loop_it40.  The Blender loop has
+    # no such event: every iteration is compared.
+    strict = STRICT_ITERATIONS[name] or len(losses)
     worst = dict(render=0.0, all=0.0, L1=0.0, se3=0.0)
-    for k, (got, ref) in enumerate(zip(losses, ref_rows)):
+    for k, (got, ref) in enumerate(zip(losses[:strict], ref_rows[:strict])):
         for key in ("render", "L1", "all"):
             worst[key] = max(worst[key], abs(got[key] - ref["loss"][key]) / max(abs(ref["loss"][key]), 1e-12))
         worst["se3"] = max(worst["se3"], float(np.abs(se3[k] - ref_se3[k]).max()))
-    print("\n[engine trace] %s: worst relative loss deviation render %.2e  L1 %.2e  all %.2e; worst |se3 - ref| %.2e over %d "
-          "iterations (final |se3| %.3e)" % (name, worst["render"], worst["L1"], worst["all"], worst["se3"], len(losses),
-                                            float(np.abs(ref_se3[-1]).max())))
+    dev = [abs(g_["render"] - r_["loss"]["render"]) / max(abs(r_["loss"]["render"]), 1e-12) for g_, r_ in zip(losses, ref_rows)]
+    first = next((k for k, d in enumerate(dev) if d > 1e-3), None)
+    print("\n[engine trace] %s: %d iterations compared loss by loss: worst relative deviation render %.2e  L1 %.2e  all %.2e; worst "
+          "|se3 - ref| %.2e (|se3| reaches %.3e); first iteration whose render loss is off by more than 1e-3: %s"
+          % (name, strict, worst["render"], worst["L1"], worst["all"], worst["se3"], float(np.abs(ref_se3[:strict]).max()), first))
     # iteration 0 is a pure forward + loss comparison from the same state on the same draws
     # (a regulariser whose weight is zero -- the TV terms of bat_blender_VM -- is not evaluated by the build at all; the reference
     #  computes it for its log)
     keys = ["render", "L1", "all"] + [k for k in ("TV_density", "TV_color") if ref_rows[0][k + "_weight"] > 0]
     for key in keys:
         np.testing.assert_allclose(losses[0][key], ref_rows[0]["loss"][key], rtol=5e-5, atol=1e-9, err_msg=key)
-    # later iterations carry everything both engines did in between (six Adam groups + the pose Adam, upsamplings through
-    # two different interpolation kernels, optimizer rebuilds): Adam turns round-off in a near-zero gradient into a full
-    # +-lr step of that element, so the two runs separate slowly; tolerances = ~4x what MI355X measured
-    tol = TOL[name]
-    assert worst["render"] <= tol["render"] and worst["all"] <= tol["render"] and worst["L1"] <= tol["L1"], worst
-    assert worst["se3"] <= tol["se3"], worst
-    # the pose trajectory is the reference's: same direction of travel, view by view, at the end of the run
-    a, b = se3[-1].reshape(-1), ref_se3[-1].reshape(-1)
-    cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
-    assert cos > 0.995, cos
+    # later iterations carry everything both engines did in between (six Adam groups + the pose Adam, upsamplings through two
+    # different interpolation kernels, optimizer rebuilds, the pose reset).  Measured on MI355X: Blender 9.5e-7 / 1.7e-7 / 9.5e-8
+    # (render / L1 / se3) over 48 iterations, LLFF 2.7e-6 over its first 19; the bounds are ~20 x that
+    # (LLFF: 2.2e-5 / 5.2e-5 / 1.5e-6 in another run -- the order of the float atomics differs from run to run, and iteration 8,
+    #  the first one behind an upsampling, is already a small amplifier: profiles/round6_llff_loop_sensitivity.txt)
+    tol = dict(blender=(5e-5, 1e-5, 5e-6), llff=(2e-4, 2e-4, 1e-5))[name]
+    assert worst["render"] <= tol[0] and worst["all"] <= tol[0] and worst["L1"] <= tol[1] and worst["se3"] <= tol[2], worst
+    assert all(np.isfinite(v) for row in losses for v in row.values())
+    if strict == len(losses):
+        # ... and the pose parameters end where the reference's do
+        np.testing.assert_allclose(se3[-1], ref_se3[-1], atol=5e-6)
 
 
-TOL = dict(blender=dict(render=2e-2, L1=2e-3, se3=2e-3), llff=dict(render=2e-2, L1=2e-3, se3=2e-3))
+# iterations compared loss by loss (None: all); see the comment in the test
+STRICT_ITERATIONS = dict(blender=None, llff=19)

@@ -52,6 +52,12 @@ CASES = {
 }
 
 
+# renderer fixtures taken inside the reference's loop (tests/golden_util.py CASES): LLFF iteration 21 = the second iteration
+# with a NEGATIVE near plane (the schedule passes through zero between 18 and 19), sharp, 14 x 16 x 14 grid after two upsamplings;
+# iteration 40 = final-but-one grid behind the alpha-mask update, pose steps every iteration
+SNAPSHOTS = ["llff:21", "llff:40", "blender:33"]
+
+
 class FakeTrainData:
     """what bat.Model.build_networks / nerf.Model.train read of a dataset: len(), .all"""
 
@@ -77,11 +83,10 @@ def scalar_kwargs(kw):
     return out
 
 
-def run(case_name, out_dir):
+def build_reference_model(case_name):
+    """the reference's bat.Model on the case's tiny scene, ready for Model.train(opt)"""
     case = CASES[case_name]
     options, camera, bat, kernels = MG.import_reference()
-    import model.tensorf_repr.tensorBase as tB
-    import model.tensorf_repr.batBase as bB
     import util  # noqa: F401
 
     opt = MG.make_opt(options, case["yaml"], H=case["H"], W=case["W"],
@@ -124,6 +129,48 @@ def run(case_name, out_dir):
     m.visualize_train = lambda *a, **k: None
     import util_vis
     util_vis.tb_wandb_image = lambda *a, **k: None
+    return case, opt, var, m, bat, camera, seed
+
+
+def snapshot(case_name, stop_it, out_path):
+    """A renderer fixture (tools/make_golden.py: run_case format) taken INSIDE the reference's loop: Model.train runs up to
+    iteration `stop_it`, then that iteration's forward / loss / backward is recorded on the state the loop has reached (grid
+    after its upsamplings, trained factors and poses, the schedule's near plane / blur / loss weights of that iteration).  The
+    hand-built fixtures of make_golden.py never visited e.g. the iterations where the LLFF near plane crosses zero."""
+    case, opt, var, m, bat, camera, seed = build_reference_model(case_name)
+
+    class Stop(Exception):
+        pass
+
+    orig = m.train_iteration
+
+    def until(opt_, var_, loader):
+        if m.it == stop_it:
+            raise Stop()
+        return orig(opt_, var_, loader)
+
+    m.train_iteration = until
+    try:
+        m.train(opt)
+    except Stop:
+        pass
+    assert m.it == stop_it
+    v = EasyDict(dict(m.train_data.all))
+    v.image = m.blurred_gt_cached_images[1.0]
+    v.train_edge_masks = m.blurred_edge_masks[1.0]
+    tf = m.graph.nerf.tensorf
+    extra = None
+    if tf.alphaMask is not None:   # the loop has been through an alpha-mask update: the mask is part of the state
+        extra = {"mask.alpha_volume": tf.alphaMask.alpha_volume[0, 0].numpy().copy(), "mask.aabb": tf.alphaMask.aabb.numpy().copy()}
+    MG.run_case(bat, camera, opt, m.graph, v, "train", it=stop_it, progress=stop_it / opt.max_iter, out_path=out_path,
+                llff=case["llff"], torch_seed=3, extra_arrays=extra)
+
+
+def run(case_name, out_dir):
+    case, opt, var, m, bat, camera, seed = build_reference_model(case_name)
+    import model.tensorf_repr.tensorBase as tB
+    import model.tensorf_repr.batBase as bB
+    B = case["n_views"]
 
     init_state = {k: v.detach().clone() for k, v in m.graph.state_dict().items()}
     graph = m.graph
@@ -249,12 +296,21 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
     ap.add_argument("--case", default="all")
+    ap.add_argument("--snapshot", default=None, help="CASE:ITERATION -> <out>/<case>_loop_it<ITERATION>.npz (a renderer fixture)")
     a = ap.parse_args()
     out_dir = os.path.abspath(a.out)
     os.makedirs(out_dir, exist_ok=True)
+    if a.snapshot:
+        cname, it = a.snapshot.split(":")
+        snapshot(cname, int(it), os.path.join(out_dir, "%s_loop_it%d.npz" % (cname, int(it))))
+        sys.exit(0)
     for name in (list(CASES) if a.case == "all" else [a.case]):
         if a.case == "all":  # one process per case: the reference keeps module-level state (opt edits, monkey patches)
             import subprocess
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "--out", out_dir, "--case", name])
         else:
             run(name, out_dir)
+    if a.case == "all":
+        import subprocess
+        for snap in SNAPSHOTS:
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "--out", out_dir, "--snapshot", snap])
