@@ -408,10 +408,13 @@ def instep_roofline(timers, n_comp_app, n_comp_density=16):
             if n_comp_app >= 48 and os.environ.get("JT_NO_AUX") != "1" and not os.environ.get("JT_SCATTER_WGS"):
                 # (jt_shade.hip: scatter_wgs) the scatter shares the chip ON PURPOSE: its launch takes 1.25 ms instead of the
                 # 0.96 ms of a 256-workgroup launch, the step 2 % less
-                out[kind]["shares_the_chip"] = ("k_shade_scatter runs on 192 of the 256 CUs (24 per XCD) while the four "
-                                                "weight-gradient GEMMs run on the other 64 from the auxiliary stream: launch_ms "
-                                                "is the duration of a launch that has 3/4 of the chip (0.96 ms scatter + chain on "
-                                                "all of it: JT_SCATTER_WGS=256, where the step is 2 % slower)")
+                from joint_tensorf_amd._lib import lib as _jl
+                lean = bool(_jl.jt_shade_lean_tape()) and _jl.jt_shade_bwd_split() in (-1, 8, 16)
+                out[kind]["shares_the_chip"] = (
+                    "k_shade_scatter runs on %d of the 256 CUs (%d per XCD) while the %s weight-gradient GEMMs run on the other %d "
+                    "from the auxiliary stream: launch_ms is the duration of a launch that has %s of the chip (chain + scatter "
+                    "with all of it: extra.default_every_kernel_alone, where the step is slower)"
+                    % ((224, 28, "three", 32, "7/8") if lean else (192, 24, "four", 64, "3/4")))
     return out
 
 
@@ -504,7 +507,15 @@ def pmc_traffic_instep(roof, hidden=None, live=None):
             # the second bound of a scatter kernel: the chip retires ~20.9 G float-atomic 64-byte segments per second
             # whatever the access pattern (tools/atomic_rate.hip, profiles/round2_atomic_rate.txt).  Segments of a launch =
             # (WRITE_SIZE bytes - the gradient records and coordinate gradients the kernel stores) / 64.
-            stored = 4 * (3 + 2 * hidden + 32) + 12   # record rows GO, G2, G1, GF + g_xyz, bytes per sample
+            # stored (not atomically added) bytes per sample: the chain's record rows GO, G1, GF (+ G2 unless the tape is lean:
+            # the dW2 GEMM derives it then) and the coordinate gradients, which the split backward's scatter writes once per
+            # plane (store, then two read-add-writes); its dBasis slabs are 3 bytes per sample at this workload and ignored.
+            # (DESIGN.md quoted 18.5 M segments per launch for this kernel until round 5: that was round 4's scatter, which
+            #  still sent the LINE gradients to global memory; with the line summed in LDS it is the ~15 M this formula reports)
+            from joint_tensorf_amd._lib import lib as _jl
+            split_on = _jl.jt_shade_bwd_split() != 0
+            lean_on = bool(_jl.jt_shade_lean_tape()) and _jl.jt_shade_bwd_split() in (-1, 8, 16)
+            stored = 4 * (3 + (1 if lean_on else 2) * hidden + 32) + (36 if split_on else 12)
             seg = (k["write_bytes_per_launch"] / rec["process_samples_per_launch"] - stored) / 64.0 * n
             out["atomic_unit"] = {"segments_per_launch": seg, "rate_segments_per_s": ATOMIC_SEGMENTS_PER_S,
                                   "floor_ms": seg / ATOMIC_SEGMENTS_PER_S * 1e3,

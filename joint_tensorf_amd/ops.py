@@ -88,7 +88,7 @@ def poke_floats(dst, values, offset=0):
 
 
 # shaded-sample capacity above which the render reads the actual shaded count back instead of allocating for rays x samples
-TAPE_SYNC_ENTRIES = int(float(os.environ.get("JT_TAPE_SYNC_GB", "8")) * 2 ** 30 / 1920)
+TAPE_SYNC_ENTRIES = int(float(os.environ.get("JT_TAPE_SYNC_GB", "8")) * 2 ** 30 / 1920)   # (worst-case bytes per sample: the full tape)
 KEEP_INTERMEDIATES = False
 # roctx ranges with the reference's record_function names (model/base.py:119-153, tensorBase.py:774) when
 # opt.profiling is set (Model.train_iteration switches this on): they show up in rocprofv3 --marker-trace output.
