@@ -532,6 +532,11 @@ def gpu_clocks():
     fields found, or an error string: never fatal."""
     import shutil
     import subprocess
+    # under rocprofv3 the profiler's preloaded library initialises the GPU in every process it is inherited by, and a child that
+    # then execs (rocm-smi is a `#!/usr/bin/env python3` script: two hops) is refused on this pool: no clocks in profiled runs
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR")) \
+            or any(k.startswith("ROCPROF") for k in os.environ):
+        return {"skipped": "running under rocprofv3"}
     smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
     if not os.path.exists(smi):
         return {"error": "rocm-smi not found"}
