@@ -640,7 +640,7 @@ def run_extras(steps=20, warmup=5):
              ("default_headline_child", same, {}),
              # round 5's default: the full tape (product rows recorded, dBasis by a fourth GEMM), scatter on 192 CUs
              ("default_round5_full_tape", same, {"JT_LEAN_TAPE": "0"}),
-             ("default_tile_owned_scatter", same, {"JT_BWD_SPLIT": "1", "JT_TILE_CFG": "1"}),
+             ("default_tile_owned_scatter", same, {"JT_BWD_SPLIT": "1"}),
              # ... and through the ONE-kernel backward of rounds 2-4 (fp32 chain + scatter fused, weight gradients on the launch
              # stream): what the default's chain-on-bf16 + scatter + forked weight-gradient GEMMs replaced in round 5
              ("default_fused_backward_kernel", same, {"JT_BWD_SPLIT": "0", "JT_NO_AUX": "1"}),

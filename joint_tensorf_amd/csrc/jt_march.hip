@@ -1061,7 +1061,8 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
   } while (0)
   if (D.Cd == 16) JT_WALK(16);
   else if (D.Cd == 8) JT_WALK(8);
-  else if (D.Cd == 32) JT_WALK(32);
+  // (32 density components: no configuration of the reference's yamls has them, and two of that width's shapes spilled; the
+  //  instantiations were removed in round 6 -- such a scene is JT_ERR_UNSUPPORTED here as it is in the shade kernels)
   else return JT_ERR_UNSUPPORTED;
 #undef JT_WALK
 #undef JT_WALK_NW

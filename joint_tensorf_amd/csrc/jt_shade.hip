@@ -2072,10 +2072,10 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   typedef TileSel<C> TS;
   int tile_line_len = 0;
   for (int a = 0; a < 3; ++a) tile_line_len = std::max(tile_line_len, D.ll[a]);
-  static const int tile_cfg_env = [] { const char* e = getenv("JT_TILE_CFG"); return e ? atoi(e) : 1; }();
-  int tile_cfg = (tile_cfg_env == 0) ? 0 : 1;
+  // (one workgroup shape since round 6: eight waves, one channel class; the sixteen-wave two-class shape of round 5 spilled
+  //  184-264 bytes per lane, took 2.7-3.4 ms and was removed -- a line too long for this shape falls back to the walker scatter)
+  const int tile_cfg = 1;
   if (split == 1) {
-    if (TS::lds_bytes(tile_cfg, tile_line_len) > 160 * 1024) tile_cfg ^= 1;  // the other workgroup shape may still fit
     bool ok = !det && G.app_plane[0] && G.app_line[0] && TS::lds_bytes(tile_cfg, tile_line_len) <= 160 * 1024;
     for (int a = 0; a < 3 && ok; ++a) ok = TS::tiles(D.ph[a], D.pw[a]) <= kTileMaxTiles;
     if (!ok) split = split_dflt;
@@ -2162,8 +2162,7 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
       return JT_OK;
     }
     if (tile) {
-      int rc_ = (tile_cfg == 1) ? TS::template launch<1>(D, M, G, TW, offset, R, g_xyz, rc, start, ccap, cap, tile_line_len, st)
-                                : TS::template launch<0>(D, M, G, TW, offset, R, g_xyz, rc, start, ccap, cap, tile_line_len, st);
+      int rc_ = TS::template launch<1>(D, M, G, TW, offset, R, g_xyz, rc, start, ccap, cap, tile_line_len, st);
       if (rc_) return rc_;
       JT_LAUNCH_CHECK();
       return JT_OK;

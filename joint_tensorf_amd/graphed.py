@@ -609,6 +609,13 @@ class GraphedTestOptim:
                     self.static[k].copy_(var[k])
         with torch.no_grad():
             self.se3.zero_()
+            # the view's pose in the optimised cameras' frame, once per view, into a static buffer the graphs read
+            pa = self.model.graph.aligned_pose(self.static["pose"]).contiguous()
+            if "pose_aligned" not in self.static or self.static["pose_aligned"].shape != pa.shape:
+                self.static["pose_aligned"] = pa.clone()
+                self.cache.clear()
+            else:
+                self.static["pose_aligned"].copy_(pa)
         self.se3.grad = None
         st = self.optim.state[self.se3]
         if st:
@@ -619,7 +626,8 @@ class GraphedTestOptim:
 
     def _iteration(self, opt, v, se3_leaf):
         m, g = self.model, self.model.graph
-        v.pose_refine_test = ops.train_pose(se3_leaf, None, self.eye)  # se3_to_SE3 (camera.py:81-99)
+        v.pose_refine_test = ops.train_pose(se3_leaf, None, self.eye)  # se3_to_SE3 (camera.py:81-99): what the eval render reads
+        v.se3_refine_test = se3_leaf    # (Graph.get_pose composes exp(se3) with the view's aligned pose from THIS tensor)
         v = g.forward(opt, v, mode="test-optim")
         loss = g.compute_loss(opt, v, mode="test-optim")
         loss = m.summarize_loss(opt, v, loss)

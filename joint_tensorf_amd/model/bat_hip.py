@@ -248,18 +248,33 @@ class Graph(torch.nn.Module):
                 return ops.train_pose(var.se3_refine, noise, var.pose)
             return ops.train_pose(var.se3_refine, None, self.pose_eye)
         if mode in ("val", "eval", "test-optim"):
-            sim3 = self.sim3
-            R, t = var.pose[..., :3], var.pose[..., 3:]
-            center = (-R.transpose(-1, -2) @ t)[..., 0]  # camera centres in world coordinates
-            center_aligned = (center - sim3.t0) / sim3.s0 @ sim3.R * sim3.s1 + sim3.t1
-            R_aligned = R @ sim3.R
-            t_aligned = (-R_aligned @ center_aligned[..., None])[..., 0]
-            pose = torch.cat([R_aligned, t_aligned[..., None]], -1)
+            # the view's pose in the optimised cameras' frame does not change while its refinement is optimised: callers that
+            # iterate (test-time optimisation) hand it over once as var.pose_aligned instead of a dozen small launches per call
+            pose = var.get("pose_aligned")
+            if pose is None:
+                pose = self.aligned_pose(var.pose)
             if opt.optim.test_photo and mode != "val":
+                se3 = var.get("se3_refine_test")
+                if mode == "test-optim" and se3 is not None and se3.requires_grad and torch.is_grad_enabled() \
+                        and se3.dim() == 2 and se3.shape[0] == pose.shape[0]:   # (one refinement per view: no broadcasting)
+                    # compose([se3_to_SE3(se3), pose]) (model/bat.py:360-363) as ONE launch each way: the pose kernel of the
+                    # training path with the aligned pose as its base (round 6; was two matrix products, a sum and a cat on top
+                    # of var.pose_refine_test, with their autograd nodes)
+                    return ops.train_pose(se3, None, pose)
                 pr = var.pose_refine_test
                 pose = torch.cat([pose[..., :3] @ pr[..., :3], pose[..., :3] @ pr[..., 3:] + pose[..., 3:]], -1)
             return pose
         return var.pose
+
+    def aligned_pose(self, pose):
+        """model/bat.py:354-359: a ground-truth pose carried into the frame of the optimised cameras (self.sim3)"""
+        sim3 = self.sim3
+        R, t = pose[..., :3], pose[..., 3:]
+        center = (-R.transpose(-1, -2) @ t)[..., 0]  # camera centres in world coordinates
+        center_aligned = (center - sim3.t0) / sim3.s0 @ sim3.R * sim3.s1 + sim3.t1
+        R_aligned = R @ sim3.R
+        t_aligned = (-R_aligned @ center_aligned[..., None])[..., 0]
+        return torch.cat([R_aligned, t_aligned[..., None]], -1)
 
     def _is_all_views(self, idx, n):
         """idx == arange(n)?  Decided once per index tensor (one host read), remembered by its storage."""
@@ -1084,6 +1099,8 @@ class Model(torch.nn.Module):
         for p in frozen:
             p.requires_grad_(False)
         eye = torch.eye(3, 4, device=opt.device)
+        with torch.no_grad():
+            var.pose_aligned = g.aligned_pose(var.pose).contiguous()
         try:
             for it in range(opt.optim.test_iter):
                 g.nerf.set_test_time_progress(it / opt.optim.test_iter)
@@ -1161,13 +1178,17 @@ class Model(torch.nn.Module):
         w_render = float(opt.loss_weight.render)
         voff = torch.zeros(V + 1, device=dev, dtype=torch.int32)        # rewritten every iteration (launch arguments: no copy)
         pose_refine = None
+        bv.se3_refine_test = se3
+        with torch.no_grad():
+            bv.pose_aligned = g.aligned_pose(bv.pose).contiguous()       # once: the views do not move, their refinements do
         try:
             for it in range(T):
                 g.nerf.set_test_time_progress(it / T)
                 optim_pose.zero_grad()
-                pose_refine = ops.train_pose(se3, None, eye)               # se3_to_SE3 of every view (camera.py:81-99)
-                bv.pose_refine_test = pose_refine
-                pose = g.get_pose(opt, bv, mode="test-optim")              # [V, 3, 4]
+                if it == T - 1:
+                    with torch.no_grad():                                  # what the eval render will see (the reference's quirk)
+                        pose_refine = ops.train_pose(se3, None, eye)       # se3_to_SE3 of every view (camera.py:81-99)
+                pose = g.get_pose(opt, bv, mode="test-optim")              # [V, 3, 4]: exp(se3) composed with the aligned pose
                 idxs, offs = [], [0]
                 for v in range(V):
                     ox, oy = draws[v][it]
