@@ -723,6 +723,14 @@ class GraphedTestOptim:
         g.lattice_override = lattice
         leaf = self.se3.detach().requires_grad_(True)   # fresh leaf alias: see GraphedTrainStep._capture
         self.se3.grad = None
+        # the regularisers of the FROZEN scene are the same in every iteration (the reference evaluates them per iteration and
+        # adds the constants to loss.all, model/bat.py:277-279): evaluated once here, outside the graph, so that the captured
+        # iteration finds them in the scene's cache (keyed by the parameters' versions) instead of carrying their launch; the
+        # entry keeps the tensors alive as long as its graph reads them
+        with torch.enable_grad():
+            tf = g.nerf.tensorf
+            tf.reg_with_tv = (float(opt.loss_weight.TV_density or 0) != 0.0, float(opt.loss_weight.TV_color or 0) != 0.0)
+            e.keep_reg = tf._reg()
         try:
             def body():
                 v, loss = self._iteration(opt, Opt(dict(svar)), leaf)
