@@ -963,18 +963,38 @@ __global__ __launch_bounds__(256) void k_dbasis_reduce(const float* __restrict__
 // tile land in the lane half that gathers those channel quads, so the sum over the channels is lane-local -- no walkers, no step
 // records, no scatter tile.  On its own (not behind the chain in one kernel: the chain's 190 registers plus the taps in flight
 // spill, jt_fused.hip) it needs 18 KB of LDS for basis_mat and runs at its own occupancy.
-template <class C>
+// B16 (round 6, with matrix-mode bit 2 as the chain): basis^T GF on the bf16 matrix cores with three-piece operands -- per plane
+// and M tile two 16-deep K steps of six v_mfma_f32_32x32x16_bf16 (12 MFMAs of 32 cycles) instead of sixteen fp32 MFMAs of 64;
+// the A operands are pre-split images of basis^T [plane][M tile][K step][piece][lane] (36 KB for VM-48), GF is split once per tile.
+template <class C, bool B16 = false>
 __global__ __launch_bounds__(256, 3) void k_pose_gather(Dev D, MlpDev M, const int* __restrict__ offset, int R,
                                                      float* __restrict__ g_xyz, const float* __restrict__ rec, int chunk_start,
                                                      int chunk_cap, int cap, int rrows) {
   typedef BwdCfg<C> B;
-  __shared__ float smem[32 * C::LDB];
+  constexpr int IMG_VECS = 3 * B::PT * 2 * 3 * 64;
+  __shared__ __align__(16) float smem[B16 ? IMG_VECS * 4 : 32 * C::LDB];
+  const uint4* img = reinterpret_cast<const uint4*>(smem);
   const int total = min(offset[R], cap);
   const int n_chunk = min(total - chunk_start, chunk_cap);
   const int ntiles = (n_chunk + 31) >> 5;
   const int nblk = min((int)gridDim.x, (ntiles + 3) / 4);
   if ((int)blockIdx.x >= nblk) return;
-  {
+  if (B16) {
+    // block (pl, TT, st): lane (i, h) holds basis[a][col] for the eight K values a = rowmap(8 st + e, 0) + 4 h of its half --
+    // the order in which split8 of the GF registers 8 st .. 8 st + 7 supplies the B operand; col = channel 32 TT + i of plane pl
+    for (int it = threadIdx.x; it < 3 * B::PT * 2 * 64; it += blockDim.x) {
+      const int ln = it & 63, blk = it >> 6, i = ln & 31, h = ln >> 5;
+      const int st = blk & 1, TT = (blk >> 1) % B::PT, pl = (blk >> 1) / B::PT;
+      const int ch = TT * 32 + i;
+      float w[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int a = rowmap(8 * st + e, 0) + 4 * h;
+        w[e] = (a < C::APP && ch < C::CA) ? M.basis[a * C::NC + pl * C::CA + ch] : 0.f;
+      }
+      store_b3(reinterpret_cast<uint4*>(smem), blk * 3 * 64, ln, w);
+    }
+  } else {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int a = wv; a < 32; a += 4) {  // basis [APP][NC] -> [32][LDB], rows >= APP and the pad column zero
       const bool row = a < C::APP;
@@ -1006,6 +1026,16 @@ __global__ __launch_bounds__(256, 3) void k_pose_gather(Dev D, MlpDev M, const i
     const float n0 = rec_ld(rec_at(rt, B::R_GEO + 0, 4u * (unsigned)jj)), n1 = rec_ld(rec_at(rt, B::R_GEO + 1, 4u * (unsigned)jj)),
                 n2 = rec_ld(rec_at(rt, B::R_GEO + 2, 4u * (unsigned)jj));
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    B3 gs[B16 ? 2 : 1];   // (B16) GF split once per tile: the B operand of both K steps of every plane and M tile
+    if (B16) {
+      float v8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v8[e] = gf[e];
+      gs[0] = split8(v8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v8[e] = gf[8 + e];
+      gs[B16 ? 1 : 0] = split8(v8);
+    }
 #pragma unroll 1
     for (int pl = 0; pl < 3; ++pl) {
       // matMode / vecMode: plane 0 (x, y | z), plane 1 (x, z | y), plane 2 (y, z | x)
@@ -1030,7 +1060,11 @@ __global__ __launch_bounds__(256, 3) void k_pose_gather(Dev D, MlpDev M, const i
         f32x16 gpt;
 #pragma unroll
         for (int r = 0; r < 16; ++r) gpt[r] = 0.f;
-        {
+        if (B16) {
+#pragma unroll
+          for (int st = 0; st < 2; ++st)
+            gpt = mfma6(load_b3(img, (((pl * B::PT + TT) * 2) + st) * 3 * 64, lane), gs[B16 ? st : 0], gpt);
+        } else {
           const int ch = TT * 32 + j;
           const int col = (ch < C::CA) ? pl * C::CA + ch : C::NC;  // (NC: the zero pad column)
 #pragma unroll
@@ -2157,7 +2191,12 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     if (pose_only) {
       const long tiles = ((long)ccap + 31) / 32;
       const int pblocks = (int)std::min<long>((tiles + 3) / 4, 2048L);
-      hipLaunchKernelGGL((k_pose_gather<C>), dim3(pblocks), dim3(256), 0, st, D, M, offset, R, g_xyz, rc, start, ccap, cap, RR);
+      // (the 20-channel scene keeps the fp32 product: its bf16 instantiation needs 168 registers + 8 bytes of scratch at three
+      //  waves per SIMD, for a product that is a third of VM-48's)
+      if ((bf16x3_mode() & 4) && C::CA >= 48)
+        hipLaunchKernelGGL((k_pose_gather<C, (C::CA >= 48)>), dim3(pblocks), dim3(256), 0, st, D, M, offset, R, g_xyz, rc, start, ccap, cap, RR);
+      else
+        hipLaunchKernelGGL((k_pose_gather<C, false>), dim3(pblocks), dim3(256), 0, st, D, M, offset, R, g_xyz, rc, start, ccap, cap, RR);
       JT_LAUNCH_CHECK();
       return JT_OK;
     }
