@@ -414,7 +414,8 @@ def instep_roofline(timers, n_comp_app, n_comp_density=16):
                     "k_shade_scatter runs on %d of the 256 CUs (%d per XCD) while the %s weight-gradient GEMMs run on the other %d "
                     "from the auxiliary stream: launch_ms is the duration of a launch that has %s of the chip (chain + scatter "
                     "with all of it: extra.default_every_kernel_alone, where the step is slower)"
-                    % ((224, 28, "three", 32, "7/8") if lean else (192, 24, "four", 64, "3/4")))
+                    % ((224, 28, "three", 32, "7/8") if (lean and os.environ.get("JT_SCATTER_WAVES") == "8")
+                       else (192, 24, "three" if lean else "four", 64, "3/4")))
     return out
 
 
@@ -640,6 +641,9 @@ def run_extras(steps=20, warmup=5):
              ("default_headline_child", same, {}),
              # round 5's default: the full tape (product rows recorded, dBasis by a fourth GEMM), scatter on 192 CUs
              ("default_round5_full_tape", same, {"JT_LEAN_TAPE": "0"}),
+             # the lean tape with the scatter in its eight-wave shape (runs of 16, 224 workgroups): the state before the
+             # twelve-wave scatter (three waves per SIMD, runs of 8, 192 workgroups) became the default
+             ("default_scatter_8_waves", same, {"JT_SCATTER_WAVES": "8"}),
              ("default_tile_owned_scatter", same, {"JT_BWD_SPLIT": "1"}),
              # ... and through the ONE-kernel backward of rounds 2-4 (fp32 chain + scatter fused, weight gradients on the launch
              # stream): what the default's chain-on-bf16 + scatter + forked weight-gradient GEMMs replaced in round 5

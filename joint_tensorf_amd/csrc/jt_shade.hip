@@ -789,11 +789,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_shade_scatter(Dev D, MlpDev M, J
                       geo[tq * 4 + kM1(pl)], geo[tq * 4 + kV(pl)], has_prev, D.ph[pl], D.pw[pl], D.ll[pl], C::CA,
                       recs + t * kRecWords);
       }
-      float bop[NCH][KS];
+      // (twelve-wave workgroups have 168 registers per lane: there the basis^T operands are read from LDS where they are used,
+      //  once per block of four steps, instead of living in 21 registers across the batch)
+      constexpr bool BOP_LDS = WAVES == 12 && C::CA >= 48;
+      float bop[BOP_LDS ? 1 : NCH][BOP_LDS ? 1 : KS];
+      if (!BOP_LDS) {
 #pragma unroll
-      for (int c = 0; c < NCH; ++c)
+        for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int k = 0; k < KS; ++k) bop[c][k] = smem[(c * KS + k) * 64 + ln];
+          for (int k = 0; k < KS; ++k) bop[BOP_LDS ? 0 : c][BOP_LDS ? 0 : k] = smem[(c * KS + k) * 64 + ln];
+      }
       wave_lds_sync();
       const float* P = D.aP[pl];
       const float* Ln = D.aL[pl];
@@ -835,7 +840,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_shade_scatter(Dev D, MlpDev M, J
         for (int c = 0; c < NCH; ++c) {
           dv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int k = 0; k < KS; ++k) dv[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], bop[c][k], dv[c], 0, 0, 0);
+          for (int k = 0; k < KS; ++k)
+            dv[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], BOP_LDS ? smem[(c * KS + k) * 64 + ln] : bop[BOP_LDS ? 0 : c][BOP_LDS ? 0 : k],
+                                                         dv[c], 0, 0, 0);
         }
         if (DB) {
           // the block's GF rows once more, transposed through the wave's LDS tile: lane (cl, grp) holds GF[4 k + grp][sample cl]
@@ -1753,9 +1760,11 @@ static std::atomic<int> g_bwd_split{-2};
 // balance moves to 224 workgroups = 28 per XCD = 7 per shader engine: 2.88 against 2.93 (192) and 2.97 ms (256) per step
 // (profiles/round6_lean_tape_ab.txt).
 // (the counts are those of a full MI355X -- 256 CUs in 8 XCDs --; Chip::wgs scales them to the device the library runs on)
-static int scatter_wgs(bool gemms_beside, bool lean = false) {
+// Later in round 6: the twelve-wave scatter (three waves per SIMD, runs of 8) is faster per CU and hands the GEMMs 64 CUs again:
+// 192 workgroups, 2.81 against 2.85-2.89 ms per step (profiles/round6_scatter_12_waves.txt).
+static int scatter_wgs(bool gemms_beside, bool lean = false, bool w12 = false) {
   static const int v = [] { const char* e = getenv("JT_SCATTER_WGS"); const int n = e ? atoi(e) : 0; return n > 0 ? n : 0; }();
-  return v ? std::min(v, chip().cus) : chip().wgs(gemms_beside ? (lean ? 224 : 192) : 256);
+  return v ? std::min(v, chip().cus) : chip().wgs(gemms_beside ? ((lean && !w12) ? 224 : 192) : 256);
 }
 static int bwd_split_mode() {
   int m = g_bwd_split.load(std::memory_order_relaxed);
@@ -2183,6 +2192,20 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
   // (with dBasis formed in the scatter the sixteen-wave shape's 128 registers spill 44-96 bytes per lane -- and it is still the
   //  faster shape where it fits: LLFF stage 0, 20 480 rays, 4.01 against 4.24 ms per step with eight waves)
   if (C::CA < 48 && split && !tile && (sw_env == 16 || (sw_env == 0 && scatter_lds(split, sflags, 16) <= 160 * 1024))) sw = 16;
+  // The 48-channel scatter at THREE waves per SIMD (round 6): twelve-wave workgroups, runs of 8 (the step records of runs of 16
+  // do not fit beside the LDS line twelve times), 168 registers with the basis^T operands read from LDS at their use (12 bytes of
+  // scratch remain).  The kernel waits on memory for half of its wave cycles (SQ counters, profiles/round6_held_flush_experiment.txt),
+  // and the third wave hides more of that than the shorter runs' extra flushes cost: scatter alone 1.05 -> 0.99 ms, and with
+  // 192 workgroups beside the three GEMMs the step 2.85-2.89 -> 2.81 ms.  Chosen when the split mode is left to the library
+  // (or JT_BWD_SPLIT=8 JT_SCATTER_WAVES=12), dBasis is formed in the kernel, accumulation is float and the line fits;
+  // JT_SCATTER_WAVES=8 keeps the eight-wave shape.
+  bool w12 = false;
+  // (the 20-channel scene gains nothing from it: final LLFF grid, scatter 0.288 ms in both shapes -- its instantiation was removed)
+  if (C::CA >= 48 && !det && !tile && !pose_only && dbs && sflags == 1 && (sw_env == 0 || sw_env == 12) &&
+      ((bwd_split_mode() == -1 && split == 16) || (bwd_split_mode() == 8 && sw_env == 12)) &&
+      scatter_lds(8, sflags, 12) <= 160 * 1024) {
+    split = 8, sw = 12, w12 = true;
+  }
   if (split && !tile && scatter_lds(split, sflags, sw) > 160 * 1024) sflags &= ~1;  // a line too long for the LDS: global atomics as before
   auto launch_scatter = [&](int ci) -> int {
     if (!split || (ablate & 1)) return JT_OK;
@@ -2216,7 +2239,7 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
       attr = true;                                                                                                      \
     }                                                                                                                   \
     const long nbatch = ((long)ccap + 4 * RUN_ - 1) / (4 * RUN_);                                                       \
-    const int sblocks = (int)std::min<long>((nbatch + SW_ - 1) / SW_, (long)scatter_wgs(use_aux && C::CA >= 48, dbs));                             \
+    const int sblocks = (int)std::min<long>((nbatch + SW_ - 1) / SW_, (long)scatter_wgs(use_aux && C::CA >= 48, dbs, w12));                             \
     hipLaunchKernelGGL((k_shade_scatter<C, DET_, RUN_, SW_, FL_>), dim3(sblocks), dim3(SW_ * 64), lds_s, st, D, M, G,   \
                        offset, R, g_xyz, rc, start, ccap, cap, bad, line_floats, RR,                                    \
                        slabs + (size_t)ci * cstride + (W::P3 + W::P2 + W::P1) * nb);                                    \
@@ -2235,7 +2258,10 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     if (C::CA < 48 && sw == 16) JT_SCATTER_FL(RUN_, (C::CA < 48 ? 16 : 8))                      \
     else JT_SCATTER_FL(RUN_, 8)                                                                 \
   }
-    if (split == 8) JT_SCATTER_RUN(8) else JT_SCATTER_RUN(16)
+    // (experiment, JT_SCATTER_WAVES=12 with JT_BWD_SPLIT=8: three waves per SIMD for the 48-channel scatter)
+    if (w12)
+      JT_SCATTER_LAUNCH(8, false, 3, (C::CA >= 48 ? 12 : 8))
+    else if (split == 8) JT_SCATTER_RUN(8) else JT_SCATTER_RUN(16)
 #undef JT_SCATTER_RUN
 #undef JT_SCATTER_FL
 #undef JT_SCATTER_LAUNCH
@@ -2296,7 +2322,7 @@ static int launch_shade_bwd(const Dev& D, const MlpDev& M, const PeMask& pm, con
     // dBasis: the sum of the scatter workgroups' slabs, on the launch stream behind the last scatter
     const int ry = det ? 1 : 8;
     hipLaunchKernelGGL((k_dbasis_reduce<C>), dim3((ScatCfg<C>::DB_SLAB + 255) / 256, ry), dim3(256), 0, st,
-                       slabs + (W::P3 + W::P2 + W::P1) * nb, cstride, chunk, scatter_wgs(use_aux && C::CA >= 48, dbs), 4 * split,
+                       slabs + (W::P3 + W::P2 + W::P1) * nb, cstride, chunk, scatter_wgs(use_aux && C::CA >= 48, dbs, w12), 4 * split,
                        sw, offset, R, cap, GM.basis);
     JT_LAUNCH_CHECK();
   }
