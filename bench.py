@@ -785,6 +785,8 @@ def main():
     use_graph = [False]
     tape_groups_used = [1]
 
+    from joint_tensorf_amd import ops as jops_b
+
     def one_step():
         nonlocal rays_total
         from joint_tensorf_amd.options import Opt
@@ -810,7 +812,7 @@ def main():
             loss = g.compute_loss(opt, var, mode="train")
             loss = model.summarize_loss(opt, var, loss)
             # (render term scaled to its share of the global mean: var.dp_render_scale; the seed is Model.train_iteration's cached ones)
-            loss.all.backward(gradient=model._backward_seed(loss.all))
+            jops_b.backward(loss.all, gradient=model._backward_seed(loss.all))   # as Model.forward_backward
             n_step = var.rgb.shape[0] * var.rgb.shape[1]
         model.reduce_pose_gradients()
         if os.environ.get("JT_BENCH_CHECKSUM") == "1":

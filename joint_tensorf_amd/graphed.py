@@ -665,7 +665,7 @@ class GraphedTestOptim:
                 if e is None:   # eager iteration on the same state
                     self.se3.grad = None
                     v, loss = self._iteration(opt, Opt(dict(svar)), self.se3)
-                    loss.all.backward()
+                    ops.backward(loss.all)
                     self.optim.step()
                     last = v
                     self.stats["eager"] += 1

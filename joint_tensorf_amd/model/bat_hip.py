@@ -757,7 +757,7 @@ class Model(torch.nn.Module):
             with ops.prof_range("summarize_loss"):
                 loss = self.summarize_loss(opt, var, loss)
             with ops.prof_range("loss.all.backward()"):
-                loss.all.backward(gradient=self._backward_seed(loss.all))  # (a cached ones tensor: no fill launch per iteration)
+                ops.backward(loss.all, gradient=self._backward_seed(loss.all))  # (a cached ones tensor: no fill launch per iteration)
         self.reduce_pose_gradients()
         return loss
 
@@ -824,7 +824,7 @@ class Model(torch.nn.Module):
                 v = g.forward(opt, Opt(dict(var)), mode="train")
                 loss = g.compute_loss(opt, v, mode="train")
                 loss = self.summarize_loss(opt, v, loss)
-                loss.all.backward(gradient=self._backward_seed(loss.all))
+                ops.backward(loss.all, gradient=self._backward_seed(loss.all))
                 total = loss.all.detach() if total is None else total + loss.all.detach()
                 g._group_rays.append(int(v.rgb.shape[0] * v.rgb.shape[1]))
                 if out is None:
@@ -1109,7 +1109,7 @@ class Model(torch.nn.Module):
                 var = g.forward(opt, var, mode="test-optim")
                 loss = g.compute_loss(opt, var, mode="test-optim")
                 loss = self.summarize_loss(opt, var, loss)
-                loss.all.backward()
+                ops.backward(loss.all)
                 optim_pose.step()
                 sched_pose.step()
         finally:
@@ -1205,7 +1205,7 @@ class Model(torch.nn.Module):
                 g._blur_memo = (None, None, None, None)                    # (this call's blur draw was taken above)
                 ret = g.render_rays(opt, center[None], ray[None], mode="test-optim", n_views=1, n_pixels_per_view=center.shape[0])
                 per_view = ops.render_loss_views(ret.rgb.view(-1, 3), images, ridx, voff)
-                (w_render * per_view.sum()).backward()
+                ops.backward(w_render * per_view.sum())
                 optim_pose.step()
                 sched_pose.step()
         finally:

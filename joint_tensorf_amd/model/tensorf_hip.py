@@ -3,6 +3,7 @@ TensorVMSplit, alpha-mask updates + AABB shrink on the yaml's schedule) on top o
 bat_hip -- only the pose handling differs (model/nerf.py:703-704: `get_pose` returns the dataset pose)."""
 import torch
 
+from .. import ops
 from . import bat_hip
 from .bat_hip import NeRF  # noqa: F401  (same scene owner and schedules)
 
@@ -37,7 +38,7 @@ class Model(bat_hip.Model):
         var = g.forward(opt, var, mode="train")
         loss = g.compute_loss(opt, var, mode="train")
         loss = self.summarize_loss(opt, var, loss)
-        loss.all.backward()
+        ops.backward(loss.all)
         self.optim.step()
         self.optim.zero_grad()
         self.it += 1

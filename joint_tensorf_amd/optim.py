@@ -3,11 +3,15 @@
 (jt_adam_step).  State keys are Adam's (`step`, `exp_avg`, `exp_avg_sq`), so optimizer
 checkpoints interchange with torch.optim.Adam."""
 import math
+import os
 
 import torch
 
 from ._lib import JtAdamItem, check, lib, ptr
 from .ops import _stream
+
+# JT_ADAM_PLAN=0: every eager step through the general path (the planned step is the same launch with the same arguments)
+PLAN_STEPS = os.environ.get("JT_ADAM_PLAN", "1") != "0"
 
 
 def _same_layout(a, b):
@@ -37,6 +41,7 @@ class VMAdam(torch.optim.Optimizer):
                     if k in st and torch.is_tensor(st[k]) and not _same_layout(st[k], p):
                         st[k] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[k])
         self.__dict__.pop("_layout_memo", None)
+        self.__dict__.pop("_plan", None)
 
     # The step is split in two so that a hipGraph can hold the launch (graphed.GraphedTrainStep): `prepare_step`
     # is the host half -- Adam's step counters, lr and bias corrections in Python doubles exactly as
@@ -168,6 +173,8 @@ class VMAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if PLAN_STEPS and self._planned_step(early_ok):
+            return loss
         coefs = self.prepare_step(poke=False)
         if not coefs:
             return loss
@@ -190,6 +197,7 @@ class VMAdam(torch.optim.Optimizer):
                 early = ops.take_early_grads(dev)
         if early is None:
             self.launch_step(coefs)
+            self._make_plan(None, None)
             return loss
         # The tensors whose gradients the render backward declared final behind its appearance half (ops.RenderRays.backward)
         # are stepped on the auxiliary stream from that point on, i.e. beside the density backward, which waits on the
@@ -205,4 +213,132 @@ class VMAdam(torch.optim.Optimizer):
         self.launch_step(coefs, only=(addresses, False))
         torch.cuda.current_stream().wait_event(done)
         self.early_steps = getattr(self, "early_steps", 0) + 1
+        self._make_plan(offer[1], addresses)
         return loss
+
+    # ---- the steady state: an eager step whose tensors are where they were one step ago ---------------------------------------
+    # Walking param_groups three times, building the launch's item array and checking every tensor's layout is ~0.2 ms of host
+    # time per step for the 22 tensors of the scene -- as much as a host-bound iteration spends in all its forward launches.
+    # After a step that went through the general path above, `_make_plan` keeps what that step established: the item arrays
+    # (one, or the early / late pair), and per tensor what was CHECKED to get there (addresses of parameter and gradient, the
+    # gradient's strides and dtype, the identity of the moment tensors).  `_planned_step` re-verifies exactly those facts and, when
+    # they all hold, only computes this step's coefficients (the same Python doubles as prepare_step) and launches; anything
+    # else -- a gradient somewhere else, another set of tensors with a gradient, changed betas, a different early offer -- falls
+    # back to the general path, which re-plans.
+
+    def _make_plan(self, offer_addresses, early_addresses):
+        import ctypes
+        recs, groups = [], []
+        for group in self.param_groups:
+            groups.append((group, group["params"], len(group["params"]),
+                           (float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]))))
+            for p in group["params"]:
+                g = p.grad
+                if g is None:
+                    recs.append((p, None, None, None, None, None, None))
+                    continue
+                st = self.state[p]
+                if g.dtype != torch.float32 or not self._layout_ok(g, p) or not p.is_cuda:
+                    self._plan = None      # (a gradient that needs a layout copy every step: the general path does that)
+                    return
+                recs.append((p, st, int(p.data_ptr()), int(g.data_ptr()), g.stride(), st["exp_avg"], st["exp_avg_sq"]))
+        live = [r for r in recs if r[1] is not None]
+        if not live or len({g[3] for g in groups}) != 1:
+            self._plan = None
+            return
+
+        def items(sel):
+            arr = (JtAdamItem * max(len(sel), 1))()
+            for k, j in enumerate(sel):
+                p, st, pp, gp, _, m, v = live[j]
+                arr[k].p, arr[k].g, arr[k].m, arr[k].v, arr[k].n = pp, gp, ptr(m), ptr(v), p.numel()
+            return arr, (ctypes.c_float * max(2 * len(sel), 2))(), sel
+        every = list(range(len(live)))
+        if early_addresses is None:
+            parts = (items(every),)
+        else:
+            parts = (items([j for j in every if live[j][3] in early_addresses]),
+                     items([j for j in every if live[j][3] not in early_addresses]))
+            if not parts[0][2]:
+                self._plan = None
+                return
+        self._plan = dict(recs=recs, groups=groups, parts=parts, offer=offer_addresses, key=groups[0][3], dev=live[0][0].device)
+
+    def _planned_step(self, early_ok):
+        plan = self.__dict__.get("_plan")
+        if plan is None:
+            return False
+        from . import ops
+        groups = plan["groups"]
+        if len(self.param_groups) != len(groups):
+            return False
+        for have, (group, plist, n, key) in zip(self.param_groups, groups):
+            if have is not group or group["params"] is not plist or len(plist) != n or \
+                    (float(group["betas"][0]), float(group["betas"][1]), float(group["eps"])) != key:
+                return False
+        offer = None
+        if ops._EARLY_GRADS:
+            if not early_ok:
+                ops._EARLY_GRADS.clear()
+            else:
+                offer = ops._EARLY_GRADS.get(ops.device_key(plan["dev"]))
+        if (None if offer is None else offer[1]) != plan["offer"]:
+            return False
+        for p, st, pp, gp, gs, m, v in plan["recs"]:
+            g = p.grad
+            if st is None:
+                if g is not None:
+                    return False
+                continue
+            # (the gradient's dtype is the parameter's -- torch refuses any other .grad --; the parameter's state entry is replaced
+            #  only by load_state_dict, which drops the plan)
+            if (g is None or g.data_ptr() != gp or p.data_ptr() != pp or g.stride() != gs
+                    or st["exp_avg"] is not m or st["exp_avg_sq"] is not v):
+                return False
+        # everything is where the plan was made: this step's coefficients, in prepare_step's arithmetic
+        b1, b2, _ = plan["key"]
+        c1, c2 = {}, {}
+        coefs = []
+        gi = iter(groups)
+        left = 0
+        for p, st, pp, gp, gs, m, v in plan["recs"]:
+            while left == 0:
+                group, _, left, _ = next(gi)
+                lr = float(group["lr"])
+            left -= 1
+            if st is None:
+                continue
+            t = float(st["step"]) + 1.0
+            st["step"] = t
+            a = c1.get(t)
+            if a is None:
+                a, b = c1[t], c2[t] = 1.0 - b1 ** t, 1.0 / math.sqrt(1.0 - b2 ** t)
+            else:
+                b = c2[t]
+            coefs.append(lr / a)
+            coefs.append(b)
+        eps = plan["key"][2]
+        parts = plan["parts"]
+
+        def launch(part, stream):
+            arr, host, sel = part
+            if len(sel) == len(coefs) // 2:
+                host[:] = coefs
+            else:
+                host[:] = [c for j in sel for c in (coefs[2 * j], coefs[2 * j + 1])]
+            check(lib.jt_adam_step_coefs(arr, len(sel), b1, b2, eps, host, stream), "jt_adam_step_coefs")
+        self.planned_steps = getattr(self, "planned_steps", 0) + 1
+        if len(parts) == 1:
+            launch(parts[0], _stream())
+            return True
+        ev, _, storage, aux = ops.take_early_grads(plan["dev"])
+        aux.wait_event(ev)
+        storage.record_stream(aux)
+        launch(parts[0], aux.cuda_stream)
+        done = self.__dict__.setdefault("_early_done", {}).setdefault(ops.device_key(plan["dev"]), torch.cuda.Event())
+        done.record(aux)
+        if parts[1][2]:
+            launch(parts[1], _stream())
+        torch.cuda.current_stream().wait_event(done)
+        self.early_steps = getattr(self, "early_steps", 0) + 1
+        return True

@@ -461,6 +461,66 @@ def test_vmadam_matches_torch_adam():
     np.testing.assert_allclose(ref2.state[ref_p[0]]["exp_avg"].numpy(), m_ref, rtol=2e-6, atol=1e-7 * np.abs(m_ref).max())
 
 
+def test_vmadam_planned_step_is_the_general_step():
+    """optim.VMAdam keeps, after a step through the general path, the launch's item array and what it checked to build it
+    (`_make_plan`); the next step re-verifies those facts and launches (`_planned_step`).  Two optimizers over copies of the same
+    tensors, one with the plan switched off, through a history that keeps and breaks the plan: gradients rewritten in place
+    (kept), the learning rate changed (kept), a gradient in a new tensor (broken), a parameter sitting a step out (broken),
+    moments replaced by load_state_dict (broken) -- parameters and moments bit-identical after every step."""
+    from joint_tensorf_amd import optim as jopt
+    from joint_tensorf_amd.tensorf_repr import _channel_last_param
+    g = torch.Generator().manual_seed(5)
+    shapes = [(1, 16, 9, 7), (1, 48, 5, 1), (27, 144), (64,), (3,)]
+    base = [torch.randn(*s, generator=g) for s in shapes]
+    mk = lambda: [_channel_last_param(b.clone().to(DEV)) if b.dim() == 4 else torch.nn.Parameter(b.clone().to(DEV)) for b in base]
+    pa, pb = mk(), mk()
+    groups = lambda ps: [dict(params=ps[:2], lr=0.02), dict(params=ps[2:], lr=1e-3)]
+    a, b = jopt.VMAdam(groups(pa), betas=(0.9, 0.99)), jopt.VMAdam(groups(pb), betas=(0.9, 0.99))
+
+    def general_step(o):
+        keep, jopt.PLAN_STEPS = jopt.PLAN_STEPS, False
+        try:
+            o.step()
+        finally:
+            jopt.PLAN_STEPS = keep
+    assert jopt.PLAN_STEPS
+    for x, y in zip(pa, pb):   # gradients in the parameters' own memory order: no layout copy, a plan can be made
+        x.grad, y.grad = torch.empty_like(x, memory_format=torch.preserve_format), torch.empty_like(y, memory_format=torch.preserve_format)
+    hits = []
+    for step in range(12):
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            gr = (torch.randn(x.shape, generator=g) * (10.0 ** (step % 5 - 3))).to(DEV)
+            if step == 5 and i == 2:     # a gradient that lives somewhere else from now on
+                x.grad, y.grad = torch.empty_like(x.grad), torch.empty_like(y.grad)
+            if step == 8 and i == 4:     # a parameter that sits this step out ...
+                x.grad = y.grad = None
+                continue
+            if step == 9 and i == 4:     # ... and comes back
+                x.grad, y.grad = torch.empty_like(x), torch.empty_like(y)
+            x.grad.copy_(gr)
+            y.grad.copy_(gr)
+        if step == 10:
+            a.load_state_dict(a.state_dict())
+            b.load_state_dict(b.state_dict())
+        if step in (3, 7):
+            for o in (a, b):
+                for grp in o.param_groups:
+                    grp["lr"] *= 0.5
+        before = getattr(a, "planned_steps", 0)
+        a.step()
+        general_step(b)
+        hits.append(getattr(a, "planned_steps", 0) - before)
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            assert torch.equal(x.detach(), y.detach()), "step %d tensor %d" % (step, i)
+            if x.grad is not None:
+                assert a.state[x]["step"] == b.state[y]["step"]
+                for k in ("exp_avg", "exp_avg_sq"):
+                    assert torch.equal(a.state[x][k], b.state[y][k]), "step %d tensor %d %s" % (step, i, k)
+    #       0  1  2  3  4  5  6  7  8  9 10 11      (a broken plan is re-made by the general step that follows)
+    assert hits == [0, 1, 1, 1, 1, 0, 1, 1, 0, 0, 0, 1], hits
+    assert not hasattr(b, "planned_steps")
+
+
 def test_adam_entry_points_by_value_and_device_coefficients_agree():
     """jt_adam_step (coefficients as launch arguments) and jt_adam_step_dyn (coefficients poked into device memory
     with jt_poke, the variant a hipGraph replays) are the same update (to the last-bit rounding of the coefficient)."""
