@@ -39,7 +39,7 @@ extern "C" {
  * jt_shade_lean_tape / jt_shade_set_lean_tape, the workspace no longer carries the tile lists unless that variant is selected;
  * 1201: + jt_chip_geometry; 1202: + jt_shade_workspace_layout.  Additions bump the last two digits, anything a caller built against the old header would get wrong
  * bumps the hundreds). */
-#define JT_VERSION 1202
+#define JT_VERSION 1203
 
 #define JT_OK 0
 #define JT_ERR_ARG 1         /* null pointer / bad size */
@@ -240,6 +240,22 @@ int jt_march_backward(const JtScene* scene, const JtFactors* factors, const floa
                       const JtFactors* g_factors, float* g_rays_o, float* g_rays_d, void* workspace,
                       size_t workspace_bytes, void* stream);
 size_t jt_march_backward_workspace_bytes(const JtScene* scene, int n_rays);
+/* The pair for a render of which only the RAYS want a gradient (test-time pose optimisation, model/bat.py:265-292: the scene is
+ * frozen).  jt_march_forward_pose is jt_march_forward that also leaves d(density feature) / d(normalised coordinates) of every
+ * in-box sample in dfeat_dn -- three planes of [n_rays * n_samples] floats (x, y, z), written while the taps of
+ * compute_densityfeature (bateRF.py:41-94) are in registers; jt_march_backward_pose is jt_march_backward with g_factors = NULL
+ * that reads them back instead of gathering the density factors a second time (same sums, same order per ray). */
+int jt_march_forward_pose(const JtScene* scene, const JtFactors* factors, const float* rays_o, const float* rays_d,
+                          const float* jitter, const float* zvals, int n_rays, float* sigma_feat, float* weight,
+                          float* tmin, int32_t* shade_count, int32_t* shade_offset, uint16_t* shade_idx,
+                          float* opacity, float* depth, float* dfeat_dn, void* stream);
+int jt_march_backward_pose(const JtScene* scene, const JtFactors* factors, const float* rays_o, const float* rays_d,
+                           const float* jitter, const float* zvals, int n_rays, const float* sigma_feat,
+                           const float* weight, const float* tmin, const int32_t* shade_offset,
+                           const uint16_t* shade_idx, const float* rgb_s, const int32_t* clamp_mask,
+                           const float* g_rgb, const float* g_opacity, const float* g_xyz_app,
+                           const float* dfeat_dn, float* g_rays_o, float* g_rays_d, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused appearance path on the matrix cores (fp32 accuracy: fp32 MFMA, or bf16 MFMA on three-piece operands, see

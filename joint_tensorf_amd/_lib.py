@@ -89,10 +89,12 @@ SIGNATURES = {
     "jt_blur_forward": (I, [P, P, P, I, I, I, P, I, P]),
     "jt_blur_backward": (I, [P, P, P, I, I, I, P, I, P]),
     "jt_march_forward": (I, [SP, FP, P, P, P, P, I, P, P, P, P, P, P, P, P, P]),
+    "jt_march_forward_pose": (I, [SP, FP, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P]),
     "jt_shade_list": (I, [SP, P, I, P, P, P, P, P, I, P]),
     "jt_composite_forward": (I, [SP, I, P, P, P, P, P, P, P, P]),
     "jt_composite_backward": (I, [SP, I, P, P, P, P, P, P, P, I, P]),
     "jt_march_backward": (I, [SP, FP, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, FP, P, P, P, ctypes.c_size_t, P]),
+    "jt_march_backward_pose": (I, [SP, FP, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, ctypes.c_size_t, P]),
     "jt_march_backward_workspace_bytes": (ctypes.c_size_t, [SP, I]),
     "jt_shade_workspace_bytes": (ctypes.c_size_t, [SP, I]),
     "jt_shade_record_layout": (I, [SP, P]),
@@ -169,7 +171,7 @@ def fused_lib():
 # the JT_VERSION of include/jt_render.h that SIGNATURES and the struct mirrors above were written against.  A constant, not a
 # read of the header at import time: a vendored copy of the package has no include/ directory beside it (tests/test_abi.py
 # holds this number, the header's and the library's together)
-JT_ABI_VERSION = 1202
+JT_ABI_VERSION = 1203
 
 
 def header_version():

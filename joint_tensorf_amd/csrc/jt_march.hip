@@ -77,6 +77,49 @@ __device__ inline void density_feature_grad(const Dev& D, const float n[3], floa
   }
 }
 
+// density feature AND its coordinate gradient from one gather of the taps (the forward march of a pose-only render: the backward
+// then needs no second walk over the density factors) -- density_feature's sum and density_feature_grad's sums, term by term
+__device__ inline float density_feature_with_grad(const Dev& D, const float n[3], float gn[3]) {
+  gn[0] = gn[1] = gn[2] = 0.f;
+  float feat = 0.f;
+  const int C = D.Cd;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const PlaneTaps t = plane_taps(n[kM0(i)], n[kM1(i)], D.ph[i], D.pw[i], C);
+    const Axis l = axis_taps(n[kV(i)], D.ll[i]);
+    const float* P = D.dP[i];
+    const float* L = D.dL[i];
+    const int l0 = l.c0 * C, l1 = l.c1 * C;
+    const float m00 = t.ax.m0 * t.ay.m0, m10 = t.ax.m1 * t.ay.m0, m01 = t.ax.m0 * t.ay.m1, m11 = t.ax.m1 * t.ay.m1;
+    const float fx = t.ax.f, fy = t.ay.f;
+    float s = 0.f, sx = 0.f, sy = 0.f, sl = 0.f;
+    for (int q = 0; q < C; q += 4) {
+      const float4 a = ld4(P + t.o00 + q), b = ld4(P + t.o10 + q), c = ld4(P + t.o01 + q), d = ld4(P + t.o11 + q);
+      const float4 u = ld4(L + l0 + q), v = ld4(L + l1 + q);
+      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, cv[4] = {c.x, c.y, c.z, c.w},
+                  dv[4] = {d.x, d.y, d.z, d.w}, uv[4] = {u.x, u.y, u.z, u.w}, vv[4] = {v.x, v.y, v.z, v.w};
+      float part = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float am = av[k] * m00, bm = bv[k] * m10, cm = cv[k] * m01, dm = dv[k] * m11;
+        const float um = uv[k] * l.m0, vm = vv[k] * l.m1;
+        const float pv = t.w00 * av[k] + t.w10 * bv[k] + t.w01 * cv[k] + t.w11 * dv[k];
+        const float lv = l.w0 * uv[k] + l.w1 * vv[k];
+        part += pv * lv;
+        sx += lv * ((1.f - fy) * (bm - am) + fy * (dm - cm));
+        sy += lv * ((1.f - fx) * (cm - am) + fx * (dm - bm));
+        sl += pv * (vm - um);
+      }
+      s += part;
+    }
+    feat += s;
+    gn[kM0(i)] += sx * t.ax.scale;
+    gn[kM1(i)] += sy * t.ay.scale;
+    gn[kV(i)] += sl * l.scale;
+  }
+  return feat;
+}
+
 // alpha_i = 1 - exp(-sigma_i * (delta_i * distance_scale))    (tensorBase.py:59, batBase.py:122)
 __device__ inline float sample_alpha(const Dev& D, float feat, bool valid, float delta, float* sigma_out) {
   float sigma = valid ? density_act(D.act, feat + D.shift) : 0.f;
@@ -100,6 +143,9 @@ __device__ inline float wave_prod_scan(float f, int lane, float* excl) {
 // ---------------------------------------------------------------------------------------------
 // K1: march forward
 // ---------------------------------------------------------------------------------------------
+// GRAD (a pose-only render): d feature / d normalised coordinates of every in-box sample goes to dfeat_dn, three planes of
+// [R * S] floats -- the taps are in registers here; k_march_bwd_scan<2> reads them back instead of gathering a second time
+template <bool GRAD>
 __global__ __launch_bounds__(256) void k_march_fwd(Dev D, const float* __restrict__ rays_o,
                                                    const float* __restrict__ rays_d,
                                                    const float* __restrict__ jitter,
@@ -107,7 +153,7 @@ __global__ __launch_bounds__(256) void k_march_fwd(Dev D, const float* __restric
                                                    float* __restrict__ sigma_feat, float* __restrict__ weight,
                                                    float* __restrict__ tmin_out, int* __restrict__ count,
                                                    uint16_t* __restrict__ sidx, float* __restrict__ opacity,
-                                                   float* __restrict__ depth) {
+                                                   float* __restrict__ depth, float* __restrict__ dfeat_dn) {
   const int lane = threadIdx.x & 63;
   // (workgroups that share an XCD take neighbouring rays: in a full-image render those are neighbouring pixels)
   const int ray = xcd_swizzle(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
@@ -130,7 +176,16 @@ __global__ __launch_bounds__(256) void k_march_fwd(Dev D, const float* __restric
       valid = sample_valid(D, r, z0, p);
       if (valid) {
         normalize(D, p, n);
-        feat = density_feature(D, n);
+        if (GRAD) {
+          float gn[3];
+          feat = density_feature_with_grad(D, n, gn);
+          const size_t RS = (size_t)R * S;
+          dfeat_dn[row + i] = gn[0];
+          dfeat_dn[RS + row + i] = gn[1];
+          dfeat_dn[2 * RS + row + i] = gn[2];
+        } else {
+          feat = density_feature(D, n);
+        }
       }
     }
     float sigma;
@@ -300,7 +355,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd(Dev D, const int* __restr
 // LDS of the scan kernel per wave: 3 float arrays of S entries.
 // ---------------------------------------------------------------------------------------------
 // POSE: the pose-only form (density coordinate gradients taken here, 179 registers); the training form keeps its occupancy
-template <bool POSE>
+//       POSE = 2: the same from the derivatives the pose-only forward march stored (dfeat_dn): no gather here at all
+template <int POSE>
 __global__ __launch_bounds__(256) void k_march_bwd_scan(Dev D, const float* __restrict__ rays_o,
                                                         const float* __restrict__ rays_d,
                                                         const float* __restrict__ jitter,
@@ -318,7 +374,7 @@ __global__ __launch_bounds__(256) void k_march_bwd_scan(Dev D, const float* __re
                                                         float* __restrict__ gfeat, uint16_t* __restrict__ vlist,
                                                         int* __restrict__ nvalid_out, float* __restrict__ g_rays_o,
                                                         float* __restrict__ g_rays_d, long long* __restrict__ rays_fixed,
-                                                        int Spad) {
+                                                        int Spad, const float* __restrict__ dfeat_dn) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
@@ -431,10 +487,18 @@ __global__ __launch_bounds__(256) void k_march_bwd_scan(Dev D, const float* __re
     // as in the forward march) -- the walk, whose only product would be these sums, is not launched
     if (POSE && live && g_feat != 0.f) {
       const float z0 = sample_z(D, r, zvals, i);
-      float p[3], nrm[3], gn[3];
-      sample_point(D, r, z0, p);
-      normalize(D, p, nrm);
-      density_feature_grad(D, nrm, gn);
+      float gn[3];
+      if (POSE == 2) {
+        const size_t RS = (size_t)R * S;
+        gn[0] = dfeat_dn[row + i];
+        gn[1] = dfeat_dn[RS + row + i];
+        gn[2] = dfeat_dn[2 * RS + row + i];
+      } else {
+        float p[3], nrm[3];
+        sample_point(D, r, z0, p);
+        normalize(D, p, nrm);
+        density_feature_grad(D, nrm, gn);
+      }
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         const float g = g_feat * gn[a] * D.inv[a];
@@ -840,11 +904,11 @@ extern "C" int jt_dense_alpha(const JtScene* scene, const JtFactors* factors, co
 }
 
 
-extern "C" int jt_march_forward(const JtScene* scene, const JtFactors* factors, const float* rays_o,
-                                const float* rays_d, const float* jitter, const float* zvals, int n_rays,
-                                float* sigma_feat, float* weight, float* tmin, int32_t* shade_count,
-                                int32_t* shade_offset, uint16_t* shade_idx, float* opacity, float* depth,
-                                void* stream) {
+static int march_forward(const JtScene* scene, const JtFactors* factors, const float* rays_o,
+                         const float* rays_d, const float* jitter, const float* zvals, int n_rays,
+                         float* sigma_feat, float* weight, float* tmin, int32_t* shade_count,
+                         int32_t* shade_offset, uint16_t* shade_idx, float* opacity, float* depth,
+                         float* dfeat_dn, void* stream) {
   Dev D;
   int rc = make_dev(scene, factors, &D);
   if (rc) return rc;
@@ -854,12 +918,35 @@ extern "C" int jt_march_forward(const JtScene* scene, const JtFactors* factors, 
   if (D.ndc && !zvals) return JT_ERR_ARG;
   if ((rc = check_density_shape(D))) return rc;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_march_fwd, dim3((n_rays + 3) / 4), dim3(256), 0, st, D, rays_o, rays_d, jitter, zvals,
-                     n_rays, sigma_feat, weight, tmin, shade_count, shade_idx, opacity, depth);
+  if (dfeat_dn)
+    hipLaunchKernelGGL(k_march_fwd<true>, dim3((n_rays + 3) / 4), dim3(256), 0, st, D, rays_o, rays_d, jitter, zvals,
+                       n_rays, sigma_feat, weight, tmin, shade_count, shade_idx, opacity, depth, dfeat_dn);
+  else
+    hipLaunchKernelGGL(k_march_fwd<false>, dim3((n_rays + 3) / 4), dim3(256), 0, st, D, rays_o, rays_d, jitter, zvals,
+                       n_rays, sigma_feat, weight, tmin, shade_count, shade_idx, opacity, depth, dfeat_dn);
   JT_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, shade_count, shade_offset, n_rays);
   JT_LAUNCH_CHECK();
   return JT_OK;
+}
+
+extern "C" int jt_march_forward(const JtScene* scene, const JtFactors* factors, const float* rays_o,
+                                const float* rays_d, const float* jitter, const float* zvals, int n_rays,
+                                float* sigma_feat, float* weight, float* tmin, int32_t* shade_count,
+                                int32_t* shade_offset, uint16_t* shade_idx, float* opacity, float* depth,
+                                void* stream) {
+  return march_forward(scene, factors, rays_o, rays_d, jitter, zvals, n_rays, sigma_feat, weight, tmin, shade_count,
+                       shade_offset, shade_idx, opacity, depth, nullptr, stream);
+}
+
+extern "C" int jt_march_forward_pose(const JtScene* scene, const JtFactors* factors, const float* rays_o,
+                                     const float* rays_d, const float* jitter, const float* zvals, int n_rays,
+                                     float* sigma_feat, float* weight, float* tmin, int32_t* shade_count,
+                                     int32_t* shade_offset, uint16_t* shade_idx, float* opacity, float* depth,
+                                     float* dfeat_dn, void* stream) {
+  if (!dfeat_dn) return JT_ERR_ARG;
+  return march_forward(scene, factors, rays_o, rays_d, jitter, zvals, n_rays, sigma_feat, weight, tmin, shade_count,
+                       shade_offset, shade_idx, opacity, depth, dfeat_dn, stream);
 }
 
 extern "C" int jt_shade_list(const JtScene* scene, const float* rays_d, int n_rays, const int32_t* shade_offset,
@@ -928,13 +1015,13 @@ extern "C" size_t jt_march_backward_workspace_bytes(const JtScene* scene, int n_
   return march_bwd_ws_layout(scene->n_samples, n_rays, &a, &b);
 }
 
-extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors, const float* rays_o,
-                                 const float* rays_d, const float* jitter, const float* zvals, int n_rays,
-                                 const float* sigma_feat, const float* weight, const float* tmin,
-                                 const int32_t* shade_offset, const uint16_t* shade_idx, const float* rgb_s,
-                                 const int32_t* clamp_mask, const float* g_rgb, const float* g_opacity,
-                                 const float* g_xyz_app, const JtFactors* g_factors, float* g_rays_o,
-                                 float* g_rays_d, void* workspace, size_t workspace_bytes, void* stream) {
+static int march_backward(const JtScene* scene, const JtFactors* factors, const float* rays_o,
+                          const float* rays_d, const float* jitter, const float* zvals, int n_rays,
+                          const float* sigma_feat, const float* weight, const float* tmin,
+                          const int32_t* shade_offset, const uint16_t* shade_idx, const float* rgb_s,
+                          const int32_t* clamp_mask, const float* g_rgb, const float* g_opacity,
+                          const float* g_xyz_app, const JtFactors* g_factors, float* g_rays_o,
+                          float* g_rays_d, void* workspace, size_t workspace_bytes, const float* dfeat_dn, void* stream) {
   Dev D;
   int rc = make_dev(scene, factors, &D);
   if (rc) return rc;
@@ -963,18 +1050,24 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
   // scan kernel, lane per sample, and the walk is skipped (JT_POSE_BWD=0, read once: the walk with its targets switched off)
   static const bool pose_env = [] { const char* e = getenv("JT_POSE_BWD"); return !e || atoi(e) != 0; }();
   const bool pose_density = pose_env && !g_factors && !det;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_bwd_scan<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (!pose_density) dfeat_dn = nullptr;   // (the stored derivatives serve the pose-only form; the walk gathers for itself)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_bwd_scan<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_bwd_scan<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_bwd_scan<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
-  if (pose_density)
-    hipLaunchKernelGGL(k_march_bwd_scan<true>, dim3((n_rays + 3) / 4), dim3(256), lds, st, D, rays_o, rays_d, jitter, zvals,
-                       n_rays, sigma_feat, weight, tmin, shade_offset, shade_idx, rgb_s, clamp_mask, g_rgb, g_opacity,
-                       g_xyz_app, gfeat, vlist, nvalid, g_rays_o, g_rays_d, rays_fixed, Spad);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_bwd_scan<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+#define JT_SCAN_LAUNCH(POSE)                                                                                                   \
+  hipLaunchKernelGGL(k_march_bwd_scan<POSE>, dim3((n_rays + 3) / 4), dim3(256), lds, st, D, rays_o, rays_d, jitter, zvals,     \
+                     n_rays, sigma_feat, weight, tmin, shade_offset, shade_idx, rgb_s, clamp_mask, g_rgb, g_opacity,           \
+                     g_xyz_app, gfeat, vlist, nvalid, g_rays_o, g_rays_d, rays_fixed, Spad, dfeat_dn)
+  if (pose_density && dfeat_dn)
+    JT_SCAN_LAUNCH(2);
+  else if (pose_density)
+    JT_SCAN_LAUNCH(1);
   else
-    hipLaunchKernelGGL(k_march_bwd_scan<false>, dim3((n_rays + 3) / 4), dim3(256), lds, st, D, rays_o, rays_d, jitter, zvals,
-                       n_rays, sigma_feat, weight, tmin, shade_offset, shade_idx, rgb_s, clamp_mask, g_rgb, g_opacity,
-                       g_xyz_app, gfeat, vlist, nvalid, g_rays_o, g_rays_d, rays_fixed, Spad);
+    JT_SCAN_LAUNCH(0);
+#undef JT_SCAN_LAUNCH
   JT_LAUNCH_CHECK();
   if (pose_density) return JT_OK;  // the ray gradients are complete: no walk, no fixed-point sums to add
   unsigned* bad = jt::fixed_bad_flag();
@@ -1072,4 +1165,28 @@ extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors,
                      g_rays_d, bad, g_status_word.load(std::memory_order_relaxed));
   JT_LAUNCH_CHECK();
   return JT_OK;
+}
+extern "C" int jt_march_backward(const JtScene* scene, const JtFactors* factors, const float* rays_o,
+                                 const float* rays_d, const float* jitter, const float* zvals, int n_rays,
+                                 const float* sigma_feat, const float* weight, const float* tmin,
+                                 const int32_t* shade_offset, const uint16_t* shade_idx, const float* rgb_s,
+                                 const int32_t* clamp_mask, const float* g_rgb, const float* g_opacity,
+                                 const float* g_xyz_app, const JtFactors* g_factors, float* g_rays_o,
+                                 float* g_rays_d, void* workspace, size_t workspace_bytes, void* stream) {
+  return march_backward(scene, factors, rays_o, rays_d, jitter, zvals, n_rays, sigma_feat, weight, tmin, shade_offset, shade_idx,
+                        rgb_s, clamp_mask, g_rgb, g_opacity, g_xyz_app, g_factors, g_rays_o, g_rays_d, workspace, workspace_bytes,
+                        nullptr, stream);
+}
+
+extern "C" int jt_march_backward_pose(const JtScene* scene, const JtFactors* factors, const float* rays_o,
+                                      const float* rays_d, const float* jitter, const float* zvals, int n_rays,
+                                      const float* sigma_feat, const float* weight, const float* tmin,
+                                      const int32_t* shade_offset, const uint16_t* shade_idx, const float* rgb_s,
+                                      const int32_t* clamp_mask, const float* g_rgb, const float* g_opacity,
+                                      const float* g_xyz_app, const float* dfeat_dn, float* g_rays_o,
+                                      float* g_rays_d, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dfeat_dn) return JT_ERR_ARG;
+  return march_backward(scene, factors, rays_o, rays_d, jitter, zvals, n_rays, sigma_feat, weight, tmin, shade_offset, shade_idx,
+                        rgb_s, clamp_mask, g_rgb, g_opacity, g_xyz_app, nullptr, g_rays_o, g_rays_d, workspace, workspace_bytes,
+                        dfeat_dn, stream);
 }

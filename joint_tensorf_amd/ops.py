@@ -25,6 +25,8 @@ def _stream():
     return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
+# JT_POSE_MARCH=0: the pose-only render keeps the plain march, its backward gathers the density taps a second time
+POSE_MARCH_DERIVATIVES = os.environ.get("JT_POSE_MARCH", "1") != "0"
 # JT_AUTOGRAD_THREAD=1: the engine's device thread runs the backward, as torch does by default
 BACKWARD_ON_CALLER = os.environ.get("JT_AUTOGRAD_THREAD", "0") != "1"
 
@@ -488,9 +490,21 @@ class RenderRays(torch.autograd.Function):
         sidx = torch.empty(R, S, device=dev, dtype=torch.int16)
         opacity = torch.empty(R, **f32)
         depth = torch.empty(R, **f32)
-        check(lib.jt_march_forward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals), R,
-                                   ptr(sigma_feat), ptr(weight), ptr(tmin), ptr(count), ptr(offset), ptr(sidx),
-                                   ptr(opacity), ptr(depth), st), "jt_march_forward")
+        # only the rays want a gradient (test-time pose optimisation): the march also leaves the density feature's coordinate
+        # derivatives, taken from the taps it has in registers, and the backward reads them instead of gathering again
+        recording = getattr(cfg, "grad_enabled", True) and any(ctx.needs_input_grad)
+        ctx.pose_only = recording and not any(ctx.needs_input_grad[5:])
+        dfeat_dn = None
+        if ctx.pose_only and POSE_MARCH_DERIVATIVES and not bool(lib.jt_set_deterministic(-1)):
+            dfeat_dn = torch.empty(3, R, S, **f32)
+            check(lib.jt_march_forward_pose(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals), R,
+                                            ptr(sigma_feat), ptr(weight), ptr(tmin), ptr(count), ptr(offset), ptr(sidx),
+                                            ptr(opacity), ptr(depth), ptr(dfeat_dn), st), "jt_march_forward_pose")
+        else:
+            check(lib.jt_march_forward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals), R,
+                                       ptr(sigma_feat), ptr(weight), ptr(tmin), ptr(count), ptr(offset), ptr(sidx),
+                                       ptr(opacity), ptr(depth), st), "jt_march_forward")
+        ctx.dfeat_dn = dfeat_dn
         n = cap = R * S  # worst case; kernels bound themselves by shade_offset[R] on the device
         if cap > TAPE_SYNC_ENTRIES and not torch.cuda.is_current_stream_capturing():
             # a batch whose worst-case tape (1.9 KB per sample) would run into tens of GB: ONE host read of the shaded
@@ -512,14 +526,13 @@ class RenderRays(torch.autograd.Function):
                                 cap, st), "jt_shade_list")
         rgb_s = torch.empty(cap_alloc, 3, **f32)
         mlp = _mlp_struct(*mlp_t)
-        if getattr(cfg, "grad_enabled", True) and any(ctx.needs_input_grad):
+        if recording:
             # training: the forward leaves the layer inputs of every shaded sample in the (persistent)
             # workspace; the backward consumes them instead of gathering / evaluating the chain again
             nbytes = lib.jt_shade_workspace_bytes(scene, cap)
             ws = _workspace(dev, "shade", nbytes)
             ctx.ws_ticket = _workspace_claim(dev, "shade")
-            # only the rays want a gradient (test-time pose optimisation): the light set of records
-            ctx.pose_only = not any(ctx.needs_input_grad[5:])
+            # (ctx.pose_only: the light set of records)
             ws_args = (ptr(ws), nbytes, _lib.JT_SHADE_POSE_ONLY if ctx.pose_only else 0)
         else:
             ws_args = (None, 0, 0)
@@ -754,10 +767,16 @@ class RenderRays(torch.autograd.Function):
         if timed:
             t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0.record()
-        check(lib.jt_march_backward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals), R,
-                                    ptr(sigma_feat), ptr(weight), ptr(tmin), ptr(offset), ptr(sidx), ptr(rgb_s),
-                                    ptr(cmask), ptr(g_rgb), ptr(g_op), ptr(g_xyz), gfac, ptr(g_o), ptr(g_d),
-                                    ptr(mws), mws_bytes, st), "jt_march_backward")
+        if getattr(ctx, "dfeat_dn", None) is not None and gfac is None:
+            check(lib.jt_march_backward_pose(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals), R,
+                                             ptr(sigma_feat), ptr(weight), ptr(tmin), ptr(offset), ptr(sidx), ptr(rgb_s),
+                                             ptr(cmask), ptr(g_rgb), ptr(g_op), ptr(g_xyz), ptr(ctx.dfeat_dn), ptr(g_o), ptr(g_d),
+                                             ptr(mws), mws_bytes, st), "jt_march_backward_pose")
+        else:
+            check(lib.jt_march_backward(scene, fac, ptr(rays_o), ptr(rays_d), ptr(jitter), ptr(zvals), R,
+                                        ptr(sigma_feat), ptr(weight), ptr(tmin), ptr(offset), ptr(sidx), ptr(rgb_s),
+                                        ptr(cmask), ptr(g_rgb), ptr(g_op), ptr(g_xyz), gfac, ptr(g_o), ptr(g_d),
+                                        ptr(mws), mws_bytes, st), "jt_march_backward")
         if timed:
             t1.record()
             # listed samples of this call (in-box samples with a density gradient): the per-ray counts sit behind

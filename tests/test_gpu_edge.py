@@ -130,3 +130,35 @@ def test_pose_only_backward_matches_full():
         ga, gb = a.grad.cpu().numpy(), b.grad.cpu().numpy()
         np.testing.assert_allclose(ga, gb, rtol=1e-5, atol=1e-6 * float(np.abs(gb).max()))
     _check_ray_grads(cpu, gpu_pose)
+
+
+def test_pose_only_backward_from_the_march_s_stored_density_derivatives():
+    """A render of which only the rays want a gradient goes through jt_march_forward_pose / jt_march_backward_pose: the forward
+    march leaves d(density feature) / d(coordinates) of every in-box sample and the backward reads them back (the default); with
+    ops.POSE_MARCH_DERIVATIVES off the backward gathers the density taps a second time (rounds 4-5).  Same ray gradients, and
+    both agree with the oracle's."""
+    from joint_tensorf_amd import ops
+    fx = Fixture("blender_train_mid")
+    o, d = _batch([("hit", 10), ("graze", 3), ("miss", 2)], seed=3)
+    seen = []
+    orig = ops.check
+
+    def spy(rc, what):
+        seen.append(what)
+        return orig(rc, what)
+    grads = {}
+    keep = ops.POSE_MARCH_DERIVATIVES
+    ops.check = spy
+    try:
+        for stored in (True, False):
+            ops.POSE_MARCH_DERIVATIVES = stored
+            del seen[:]
+            _, _, _, _, cpu, gpu = _run_both(fx, o, d, want="pose")
+            assert ("jt_march_backward_pose" in seen) == stored and ("jt_march_forward_pose" in seen) == stored, seen
+            _check_ray_grads(cpu, gpu)
+            grads[stored] = [t.grad.cpu().numpy() for t in gpu]
+    finally:
+        ops.check = orig
+        ops.POSE_MARCH_DERIVATIVES = keep
+    for a, b in zip(grads[True], grads[False]):
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6 * float(np.abs(b).max()))
