@@ -39,7 +39,7 @@ extern "C" {
  * jt_shade_lean_tape / jt_shade_set_lean_tape, the workspace no longer carries the tile lists unless that variant is selected;
  * 1201: + jt_chip_geometry; 1202: + jt_shade_workspace_layout.  Additions bump the last two digits, anything a caller built against the old header would get wrong
  * bumps the hundreds). */
-#define JT_VERSION 1203
+#define JT_VERSION 1204
 
 #define JT_OK 0
 #define JT_ERR_ARG 1         /* null pointer / bad size */
@@ -138,6 +138,10 @@ int jt_raygen_forward(const float* pose, const float* intr_inv, const float* int
 int jt_raygen_backward(const float* pose, const float* intr_inv, const float* intr, const int64_t* ray_idx,
                        int n_views, int rays_per_view, int image_w, int ndc, float ndc_near,
                        const float* g_rays_o, const float* g_rays_d, float* g_pose, void* stream);
+/* Flat pixel indices of the `all_view_rand_grid` lattice (model/nerf.py:660-667: x = ox + i * step, y = oy + j * step, index
+ * y * image_w + x, row-major over (j, i)) with the two offsets read from DEVICE memory (offsets: int32[2]) -- the form a replayed
+ * hipGraph needs: the host draws ox, oy per iteration and pokes them in front of the replay.  ray_idx: [ny * nx] int64. */
+int jt_lattice_indices(const int32_t* offsets, int step, int nx, int ny, int image_w, int64_t* ray_idx, void* stream);
 /* The same for a RAGGED batch of views (batched test-time pose optimisation of model/bat.py:265-292: every held-out view on its own
  * pixel lattice): ray_idx [n_rays] is the concatenation of the views' pixel lists, view b owns rays view_offset[b] ..
  * view_offset[b + 1] - 1 (view_offset [n_views + 1], int32, device memory).  Per ray / per view the arithmetic and the order of

@@ -88,6 +88,7 @@ SIGNATURES = {
     "jt_pose_backward": (I, [P, P, P, I, I, P, P, P]),
     "jt_blur_forward": (I, [P, P, P, I, I, I, P, I, P]),
     "jt_blur_backward": (I, [P, P, P, I, I, I, P, I, P]),
+    "jt_lattice_indices": (I, [P, I, I, I, I, P, P]),
     "jt_march_forward": (I, [SP, FP, P, P, P, P, I, P, P, P, P, P, P, P, P, P]),
     "jt_march_forward_pose": (I, [SP, FP, P, P, P, P, I, P, P, P, P, P, P, P, P, P, P]),
     "jt_shade_list": (I, [SP, P, I, P, P, P, P, P, I, P]),
@@ -171,7 +172,7 @@ def fused_lib():
 # the JT_VERSION of include/jt_render.h that SIGNATURES and the struct mirrors above were written against.  A constant, not a
 # read of the header at import time: a vendored copy of the package has no include/ directory beside it (tests/test_abi.py
 # holds this number, the header's and the library's together)
-JT_ABI_VERSION = 1203
+JT_ABI_VERSION = 1204
 
 
 def header_version():

@@ -361,6 +361,25 @@ extern "C" int jt_pose_backward(const float* se3, const float* noise, const floa
   return JT_OK;
 }
 
+// pixel indices of the all_view_rand_grid lattice (model/nerf.py:660-667) from offsets that live in device memory: what a
+// replayed hipGraph computes per iteration (the host pokes the two draws in front of the replay)
+__global__ __launch_bounds__(256) void k_lattice(const int32_t* __restrict__ offsets, int step, int nx, int ny, int width,
+                                                 int64_t* __restrict__ ray_idx) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nx * ny) return;
+  const int ix = k % nx, iy = k / nx;
+  ray_idx[k] = (int64_t)(offsets[0] + ix * step) + (int64_t)(offsets[1] + iy * step) * width;
+}
+
+extern "C" int jt_lattice_indices(const int32_t* offsets, int step, int nx, int ny, int image_w, int64_t* ray_idx,
+                                  void* stream) {
+  if (!offsets || !ray_idx || step < 1 || nx < 1 || ny < 1 || image_w < 1 || (long)nx * ny > (1l << 30)) return JT_ERR_ARG;
+  hipLaunchKernelGGL(k_lattice, dim3((nx * ny + 255) / 256), dim3(256), 0, (hipStream_t)stream, offsets, step, nx, ny,
+                     image_w, ray_idx);
+  JT_LAUNCH_CHECK();
+  return JT_OK;
+}
+
 extern "C" int jt_raygen_forward(const float* pose, const float* intr_inv, const float* intr,
                                  const int64_t* ray_idx, int n_views, int rays_per_view, int image_w, int ndc,
                                  float ndc_near, float* rays_o, float* rays_d, void* stream) {

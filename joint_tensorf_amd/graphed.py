@@ -499,14 +499,10 @@ class GraphedTrainStep:
         ops.poke_words(e.off, [0, 0] + self._supervision_words(var, sig[8]))
         ops.SUPERVISION_SLOTS_STATIC = e.off[2:6].view(torch.int64)
         # allocated OUTSIDE the capture: the entry must keep them alive for as long as the graph exists
-        e.base_x = base_x = torch.arange(nx, device=dev) * step
-        e.base_y = base_y = torch.arange(ny, device=dev) * step
         W = int(opt.W)
 
         def lattice(_step):
-            off = e.off.long()
-            sx, sy = base_x + off[0], base_y + off[1]
-            return (sx[None, :] + sy[:, None] * W).reshape(-1), ny, nx
+            return ops.lattice_indices(e.off, step, nx, ny, W), ny, nx
 
         m.optim.zero_grad()
         # pose gradients may be mid-accumulation (pose_grad_accum_iter > 1, model/bat.py:103-106): the capture must not lose
@@ -709,14 +705,10 @@ class GraphedTestOptim:
         dev = opt.device
         e = _Entry()
         e.off = torch.zeros(2, device=dev, dtype=torch.int32)
-        e.base_x = base_x = torch.arange(nx, device=dev) * step
-        e.base_y = base_y = torch.arange(ny, device=dev) * step
         W = int(opt.W)
 
         def lattice(_step):
-            off = e.off.long()
-            sx, sy = base_x + off[0], base_y + off[1]
-            return (sx[None, :] + sy[:, None] * W).reshape(-1), ny, nx
+            return ops.lattice_indices(e.off, step, nx, ny, W), ny, nx
 
         np_state = np.random.get_state()
         ws_gen = ops.workspace_generation()
@@ -731,10 +723,11 @@ class GraphedTestOptim:
             tf = g.nerf.tensorf
             tf.reg_with_tv = (float(opt.loss_weight.TV_density or 0) != 0.0, float(opt.loss_weight.TV_color or 0) != 0.0)
             e.keep_reg = tf._reg()
+        m._backward_seed(torch.empty((), device=dev, dtype=torch.float32))   # the cached unit seed exists before the capture
         try:
             def body():
                 v, loss = self._iteration(opt, Opt(dict(svar)), leaf)
-                (gr,) = torch.autograd.grad(loss.all, [leaf])
+                (gr,) = torch.autograd.grad(loss.all, [leaf], grad_outputs=[m._backward_seed(loss.all)])  # (no fill launch)
                 self.se3.grad = gr
                 self.optim.launch_step()
                 return v, loss

@@ -45,6 +45,15 @@ def backward(loss, gradient=None):
         loss.backward(gradient=gradient)
 
 
+def lattice_indices(offsets, step, nx, ny, width):
+    """[ny * nx] int64 pixel indices of the all_view_rand_grid lattice (model/nerf.py:660-667) whose two offsets are in device
+    memory (`offsets`: int32, the first two elements): one launch inside a replayed graph instead of five elementwise ones."""
+    assert offsets.is_cuda and offsets.dtype == torch.int32 and offsets.is_contiguous() and offsets.numel() >= 2
+    out = torch.empty(ny * nx, device=offsets.device, dtype=torch.int64)
+    check(lib.jt_lattice_indices(ptr(offsets), int(step), int(nx), int(ny), int(width), ptr(out), _stream()), "jt_lattice_indices")
+    return out
+
+
 def poke_words(dst, words, offset=0):
     """Write up to 256 32-bit words (Python ints) into the device tensor `dst` (4-byte elements) at element
     `offset`, on the current stream: the values travel as launch arguments (jt_poke) -- no staging buffer, no

@@ -449,7 +449,11 @@ class BAT_VMSplit(torch.nn.Module):
                 is_test_optim=False, view_pe_progress=1.0, fea_pe_progress=1.0):
         self._check_flags(opt)
         self.opt = opt
-        self.__dict__.setdefault("_reg_cache", {}).clear()  # regulariser sums are per forward call
+        # regulariser sums are per forward call (they hang on this call's autograd graph) -- unless the scene is frozen (test-time
+        # pose optimisation, model/bat.py:265-292: 400 iterations per view over the same factors): plain values then, kept for as
+        # long as the factors' versions stand (_reg_key)
+        if self.density_plane[0].requires_grad or self.app_plane[0].requires_grad or self.density_line[0].requires_grad:
+            self.__dict__.setdefault("_reg_cache", {}).clear()
         dev = center.device
         S = N_samples if N_samples > 0 else self.nSamples
         near, far = float(self.near_far[0]), float(self.near_far[1])

@@ -583,3 +583,19 @@ def test_library_import_order_does_not_split_the_hip_runtime():
             "print('ok')\n" % root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_lattice_indices_from_device_offsets():
+    """jt_lattice_indices (the all_view_rand_grid lattice of model/nerf.py:660-667 with its two offsets in device memory) against
+    the host form Graph._lattice_at builds: every offset of a small stride, both lattice shapes an axis can take."""
+    from joint_tensorf_amd import ops
+    H, W, step = 37, 53, 7
+    off = torch.zeros(6, device=DEV, dtype=torch.int32)
+    for ox in range(step):
+        for oy in (0, 2, step - 1):
+            nx, ny = len(range(ox, W, step)), len(range(oy, H, step))
+            ops.poke_words(off, [ox, oy])
+            got = ops.lattice_indices(off, step, nx, ny, W).cpu()
+            xs, ys = torch.arange(ox, W, step), torch.arange(oy, H, step)
+            want = (xs[None, :] + ys[:, None] * W).reshape(-1)
+            assert got.dtype == torch.int64 and torch.equal(got, want), (ox, oy)
