@@ -37,8 +37,9 @@ extern "C" {
  * version it was taken at: tests/test_abi.py fails when the hash changes without this number changing (round 5 added
  * jt_reg_losses_fused, removed jt_pose_fused* and redefined matrix-mode bit 2 at version 1100; 1200 = round 6: those changes,
  * jt_shade_lean_tape / jt_shade_set_lean_tape, the workspace no longer carries the tile lists unless that variant is selected;
- * 1201: + jt_chip_geometry; 1202: + jt_shade_workspace_layout.  Additions bump the last two digits, anything a caller built against the old header would get wrong
- * bumps the hundreds). */
+ * 1201: + jt_chip_geometry; 1202: + jt_shade_workspace_layout; 1203: + jt_march_forward_pose / jt_march_backward_pose; 1204: +
+ * jt_lattice_indices.  Additions bump the last two digits, anything a caller built against the old header would get wrong bumps the
+ * hundreds). */
 #define JT_VERSION 1204
 
 #define JT_OK 0
