@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(Dev D, const int* __restr
 // k_march_bwd_walk -- one 16-lane group per run of 32 listed samples (lane = density channel):
 //   re-gathers the density taps of the three planes, run-length scatters the plane / line gradients
 //   (jt_walk.h) and adds the run's coordinate gradients to g_rays_o / g_rays_d.
-// LDS of the scan kernel per wave: 3 float arrays of S entries.
+// LDS of the scan kernel per wave: 2 float arrays of S entries + one float per 64-sample chunk.
 // ---------------------------------------------------------------------------------------------
 // POSE: the pose-only form (density coordinate gradients taken here, 179 registers); the training form keeps its occupancy
 //       POSE = 2: the same from the derivatives the pose-only forward march stored (dfeat_dn): no gather here at all
@@ -380,9 +380,14 @@ __global__ __launch_bounds__(256) void k_march_bwd_scan(Dev D, const float* __re
   const int wv = threadIdx.x >> 6;
   const int ray = blockIdx.x * 4 + wv;
   if (ray >= R) return;
-  float* s_alpha = reinterpret_cast<float*>(smem) + (size_t)wv * 3 * Spad;
-  float* s_T = s_alpha + Spad;
-  float* s_G = s_T + Spad;
+  // per wave: alpha [Spad], G [Spad] and the transmittance carried INTO each 64-sample chunk [Spad / 64]: pass B rebuilds a sample's
+  // transmittance as (carry of its chunk) x (exclusive wave product of the chunk's factors) -- the forward's own two factors, bit
+  // for bit -- instead of reading a third array back: 8 instead of 12 KB per ray at S = 1 000, five workgroups per CU instead
+  // of three, so that the 4 071 rays of the forward-facing configuration are resident at once (one round instead of two)
+  const int wstride = 2 * Spad + (Spad >> 6);
+  float* s_alpha = reinterpret_cast<float*>(smem) + (size_t)wv * wstride;
+  float* s_G = s_alpha + Spad;
+  float* s_carry = s_G + Spad;
 
   Ray r;
   load_ray(D, rays_o, rays_d, jitter, tmin_in, ray, r);
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(256) void k_march_bwd_scan(Dev D, const float* __re
     float f = live ? (1.f - alpha + 1e-10f) : 1.f;
     float excl;
     float total = wave_prod_scan(f, lane, &excl);
-    float T = carry * excl;
+    if (lane == 0) s_carry[base >> 6] = carry;
     carry *= total;
     const bool shade = live && (wst > D.thres);
     unsigned long long bal = __ballot(shade);
@@ -431,7 +436,6 @@ __global__ __launch_bounds__(256) void k_march_bwd_scan(Dev D, const float* __re
     cnt += __popcll(bal);
     if (live) {
       s_alpha[i] = alpha;
-      s_T[i] = T;
       s_G[i] = Gw;
     }
   }
@@ -447,13 +451,17 @@ __global__ __launch_bounds__(256) void k_march_bwd_scan(Dev D, const float* __re
     bool valid = false;
     if (live) {
       alpha = s_alpha[i];
-      T = s_T[i];
       Gw = s_G[i];
       float z0 = sample_z(D, r, zvals, i);
       if (i < S - 1) delta = (sample_z(D, r, zvals, i + 1) - z0) * r.norm;
       float p[3];
       valid = sample_valid(D, r, z0, p);
       feat = sigma_feat[row + i];
+    }
+    {
+      float excl_t;
+      (void)wave_prod_scan(live ? (1.f - alpha + 1e-10f) : 1.f, lane, &excl_t);
+      T = s_carry[c] * excl_t;   // = the forward's carry * excl of this sample
     }
     float v = live ? Gw * (alpha * T) : 0.f;
     float inc = v;  // inclusive suffix scan over lanes
@@ -1043,7 +1051,7 @@ static int march_backward(const JtScene* scene, const JtFactors* factors, const 
   uint16_t* vlist = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + o_vlist);
   int* nvalid = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + o_nvalid);
   const int Spad = (D.S + 63) & ~63;
-  const size_t lds = (size_t)4 * 3 * Spad * sizeof(float);
+  const size_t lds = (size_t)4 * (2 * Spad + (Spad >> 6)) * sizeof(float);
   if (lds > 160 * 1024) return JT_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   // nothing but the rays wants a gradient (test-time pose optimisation): the density path's coordinate gradient is taken in the
