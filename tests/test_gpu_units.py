@@ -599,3 +599,33 @@ def test_lattice_indices_from_device_offsets():
             xs, ys = torch.arange(ox, W, step), torch.arange(oy, H, step)
             want = (xs[None, :] + ys[:, None] * W).reshape(-1)
             assert got.dtype == torch.int64 and torch.equal(got, want), (ox, oy)
+
+
+def test_backward_runs_on_the_calling_thread():
+    """ops.backward (the training loop's loss.backward(), model/base.py:162): the autograd engine walks the graph ON THE CALLING
+    THREAD -- every node of this package's backward is a Python function, a worker thread only adds two hand-overs per iteration --
+    with the same gradients as torch's default (a per-device worker thread)."""
+    import threading
+    from joint_tensorf_amd import ops
+    seen = {}
+
+    def run(on_caller):
+        keep = ops.BACKWARD_ON_CALLER
+        ops.BACKWARD_ON_CALLER = on_caller
+        try:
+            se3 = torch.zeros(2, 6, device=DEV, requires_grad=True)
+            base = torch.eye(3, 4, device=DEV).repeat(2, 1, 1)
+            pose = ops.train_pose(se3, None, base)
+
+            def note(_g):
+                seen.setdefault(on_caller, threading.get_ident())   # (a hook that returns None leaves the gradient as it is)
+            pose.register_hook(note)
+            w = torch.arange(24, device=DEV, dtype=torch.float32).view(2, 3, 4)
+            ops.backward((pose * w).sum())
+            return se3.grad.clone()
+        finally:
+            ops.BACKWARD_ON_CALLER = keep
+    g_caller, g_worker = run(True), run(False)
+    assert seen[True] == threading.get_ident() and seen[False] != threading.get_ident()
+    assert torch.equal(g_caller, g_worker)
+    assert ops.BACKWARD_ON_CALLER   # the default
