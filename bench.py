@@ -630,9 +630,11 @@ def run_extras(steps=20, warmup=5):
              # the N = 1 point of the strong-scaling curve: the WHOLE 62 500-ray iteration of BASELINE.json configs[3]
              ("configs3_single_gpu", ["--total-rays", "65536", "--steps", "8", "--warmup", "2"], {}),
              # the sharp last stage of a CONVERGED run on the self-consistent scene (few per cent of the samples shaded)
-             ("fitted_scene_eager", ["--scene", "fitted"], {}),
+             # (host-bound eager lines: 100 timed steps behind 20 warm-up steps -- the first iterations of a process still build
+             #  the optimizer's launch plan and grow the allocator's pools, a visible share of a 20-step window at ~1 ms per step)
+             ("fitted_scene_eager", ["--scene", "fitted", "--steps", "100", "--warmup", "20"], {}),
              ("fitted_scene_hipgraph", ["--scene", "fitted"], {"JT_GRAPH": "1"}),
-             ("blobs_eager", ["--scene", "blobs"], {}),
+             ("blobs_eager", ["--scene", "blobs", "--steps", "100", "--warmup", "20"], {}),
              ("blobs_hipgraph", ["--scene", "blobs"], {"JT_GRAPH": "1"}),
              # the headline workload with the appearance gradients through the TILE-OWNED scatter of round 5 (chain kernel +
              # binning + one wave per 4 x 4-texel tile on the matrix cores) instead of the fused kernel's run-length atomics:
